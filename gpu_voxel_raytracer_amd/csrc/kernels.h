@@ -1,0 +1,88 @@
+// kernels.h — device-side argument blocks and launchers of libvxrt (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace vxrt {
+
+// Compact sparse voxel octree, the device scene format ("SVO record"): the same tree as the
+// reference's 8-ints-per-node buffer (shaders/voxels.comp:58-63, built by src/context.rs:710-773) but
+// 8 bytes per node instead of 32, in breadth-first order with the children of a node contiguous:
+//   .x = child_mask (bits 0-7: slot holds a child node) | leaf_mask << 8 (bits 8-15: slot holds a leaf)
+//   .y = index of the node's first child record (or of its first leaf word, for a node of leaves)
+// Slot s of a node is child  base + popcount(child_mask & ((1<<s)-1)).  A traversal step that stays
+// inside a node (sibling advance) needs no memory access at all; a descend is one 8-byte load.
+struct SvoRecord {
+    uint32_t masks;
+    uint32_t base;
+};
+
+struct Cam {  // first 64 bytes of Uniforms, without padding
+    float o[3], r[3], u[3], f[3];
+};
+
+struct BandMap {  // which rows of the frame this context owns (vxrt_config.rank/nranks/band_rows)
+    int width, height, local_rows, band_rows, rank, nranks;
+};
+
+struct TraceArgs {
+    const SvoRecord* svo;
+    const int32_t* leaves;
+    const float* noise;
+    float4* out_color;
+    float4* out_nd;
+    float4* out_albedo;
+    unsigned long long* ray_counter;
+    float root_center[3];
+    float root_size;
+    BandMap band;
+    int max_bounces;
+    uint32_t frame_number;
+    int stack_levels;  // LDS stack entries per thread (= octree depth, >= 1)
+    Cam cam;
+    // per-frame constants hoisted from voxels.comp main() (identical for every pixel)
+    float sun_dir[3];        // voxels.comp:296
+    float sun_dir_n[3];      // normalize(sun_dir)      voxels.comp:347
+    float neg_sun_dir_n[3];  // normalize(-sun_dir)     voxels.comp:379
+    float sun_color[3];      // SUN_COLOR               voxels.comp:6
+    float sky_color[3];
+    float sun_exponent;      // 1.0 / pow(sun_size, 2)  voxels.comp:380
+    float sun_size, sun_strength, emit_strength, specularity;
+};
+
+struct TemporalArgs {
+    const float4* sampled_color;
+    const float4* new_nd;
+    const float4* old_color;
+    const float4* old_nd;
+    float4* new_color;
+    BandMap band;
+    Cam cam, old_cam;
+    float inv[12];  // affine inverse of the old camera matrix (temporal.comp:75-82), rows + translation
+    float sample_blending, maximum_blending, blending_distance_cutoff;
+    int has_history;
+};
+
+struct DenoiseArgs {
+    const float4* colors;
+    const float4* nd;
+    const float4* albedo;
+    float4* output;
+    // rows just outside this context's bands, received from the neighbouring ranks (may be null):
+    // [band][side][r rows][width] of (colour, nd, albedo)
+    const float4* halo;
+    BandMap band;
+    Cam cam;
+    uint32_t radius;
+    float sigma_distance_2, sigma_range_2, albedo_factor;
+};
+
+hipError_t launch_trace(const TraceArgs& a, hipStream_t s);
+hipError_t launch_temporal(const TemporalArgs& a, hipStream_t s);
+hipError_t launch_denoise(const DenoiseArgs& a, hipStream_t s);
+hipError_t launch_noise_fill(float* dst, uint32_t seed, size_t n, hipStream_t s);
+// detmath probe for the device-vs-host bit-equality test (tests/test_detmath_gpu.py)
+hipError_t launch_detmath_probe(int fn, const float* x, const float* y, float* out, size_t n, hipStream_t s);
+
+}  // namespace vxrt

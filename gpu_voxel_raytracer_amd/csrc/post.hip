@@ -1,0 +1,254 @@
+// post.hip — temporal accumulation and spatial denoise kernels of libvxrt (gfx950), plus two small
+// utility kernels (noise-table fill, detmath probe).
+//
+//  temporal_kernel : shaders/temporal.comp:48-125 — reproject into the previous frame, validate by
+//                    world-space distance, blend with the per-pixel decaying factor kept in .a.
+//                    80 algorithmic bytes per pixel (64 read + 16 written); the per-pixel
+//                    inverse(mat4) of the shader is hoisted to the host (one matrix per frame).
+//  denoise_kernel  : shaders/denoise.comp:24-93 — (2r+1)^2 cross-bilateral window.  A 16x16 block
+//                    stages its (16+2r)^2 apron once in LDS as 8 floats per pixel (rgb, normal,
+//                    log|depth|, material id), so a tap is LDS reads + ~45 flops + one exp instead
+//                    of three 16-byte global loads and two logs.
+#include "kernels.h"
+#include "vx_vec.h"
+
+namespace vxrt {
+namespace {
+
+__device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+__device__ __forceinline__ f3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
+
+__device__ __forceinline__ f3 pixel_dir(const Cam& c, int x, int y) {
+    return norm3((float(x) * ld3(c.r) - float(y) * ld3(c.u)) + ld3(c.f));
+}
+
+// frame row -> local row of this context, or -1 when another rank owns it
+__device__ __forceinline__ int local_row(const BandMap& b, int y) {
+    int band = y / b.band_rows;
+    if (band % b.nranks != b.rank) return -1;
+    return (band / b.nranks) * b.band_rows + (y - band * b.band_rows);
+}
+__device__ __forceinline__ int frame_row(const BandMap& b, int lrow) {
+    int lband = lrow / b.band_rows;
+    return (lband * b.nranks + b.rank) * b.band_rows + (lrow - lband * b.band_rows);
+}
+
+// texture() through the reference's Linear / ClampToEdge sampler (src/context.rs:980-989): bilinear,
+// weights quantised to 8 fractional bits (oracle U4).  A row another rank owns makes the lookup fail.
+__device__ __forceinline__ bool sample_bilinear(const float4* img, const BandMap& b, float u, float v, float4& out) {
+    float fx = u * float(b.width) - 0.5f, fy = v * float(b.height) - 0.5f;
+    float x0f = vx_floor(fx), y0f = vx_floor(fy);
+    float ax = vx_floor((fx - x0f) * 256.0f + 0.5f) / 256.0f, ay = vx_floor((fy - y0f) * 256.0f + 0.5f) / 256.0f;
+    int x0 = int(x0f), y0 = int(y0f);
+    int xa = min(max(x0, 0), b.width - 1), xb = min(max(x0 + 1, 0), b.width - 1);
+    int ya = min(max(y0, 0), b.height - 1), yb = min(max(y0 + 1, 0), b.height - 1);
+    int la = local_row(b, ya), lb = ay == 0.0f ? la : local_row(b, yb);
+    if (la < 0 || lb < 0) return false;
+    float4 t00 = img[size_t(la) * b.width + xa], t10 = img[size_t(la) * b.width + xb];
+    float4 t01 = img[size_t(lb) * b.width + xa], t11 = img[size_t(lb) * b.width + xb];
+    const float* p00 = &t00.x; const float* p10 = &t10.x; const float* p01 = &t01.x; const float* p11 = &t11.x;
+    float* o = &out.x;
+    for (int k = 0; k < 4; k++) {
+        float top = ax == 0.0f ? p00[k] : (p00[k] * (1.0f - ax) + p10[k] * ax);
+        float bot = ax == 0.0f ? p01[k] : (p01[k] * (1.0f - ax) + p11[k] * ax);
+        o[k] = ay == 0.0f ? top : (top * (1.0f - ay) + bot * ay);
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void temporal_kernel(const TemporalArgs a) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int lrow = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.band.width || lrow >= a.band.local_rows) return;
+    const int y = frame_row(a.band, lrow);
+    const size_t pix = size_t(lrow) * a.band.width + x;
+
+    const f3 color = xyz(a.sampled_color[pix]);
+    const float4 nd = a.new_nd[pix];
+    const f3 normal = xyz(nd);
+    const float depth = nd.w;
+    const f3 cam_o = ld3(a.cam.o);
+    const f3 world_pos = cam_o + depth * pixel_dir(a.cam, x, y);
+
+    float4 old_color = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float blending = 1.0f;
+    if (depth >= 0.0f && a.has_history) {
+        const float* m = a.inv;  // old_world_to_screen * vec4(world_pos, 1)   temporal.comp:82-85
+        float sx = ((m[0] * world_pos.x + m[1] * world_pos.y) + m[2] * world_pos.z) + m[3];
+        float sy = ((m[4] * world_pos.x + m[5] * world_pos.y) + m[6] * world_pos.z) + m[7];
+        float sz = ((m[8] * world_pos.x + m[9] * world_pos.y) + m[10] * world_pos.z) + m[11];
+        sx = sx / sz;
+        sy = sy / sz;
+        float tu = (sx + 0.5f) * (1.0f / float(a.band.width));     // temporal.comp:89
+        float tv = (sy + -0.5f) * (-1.0f / float(a.band.height));
+        if (0.0f <= tu && tu <= 1.0f && 0.0f <= tv && tv <= 1.0f) {
+            float4 old_nd;
+            if (sample_bilinear(a.old_nd, a.band, tu, tv, old_nd)) {
+                f3 old_dir = norm3((float(int(sx + 0.5f)) * ld3(a.old_cam.r) + float(int(sy - 0.5f)) * ld3(a.old_cam.u)) + ld3(a.old_cam.f));
+                f3 old_position = ld3(a.old_cam.o) + old_nd.w * old_dir;
+                f3 camera_dir = norm3(cam_o - world_pos);
+                float bias = vx_max(0.0f, dot3(camera_dir, normal));
+                float dist = len3(old_position - world_pos);
+                if (dist < (bias * a.blending_distance_cutoff) * depth) {
+                    sample_bilinear(a.old_color, a.band, tu, tv, old_color);
+                    blending = old_color.w;
+                }
+            }
+        }
+    }
+    f3 blended = depth >= 0.0f ? mix3(xyz(old_color), color, blending) : color;
+    float next_blending = vx_clamp((1.0f - a.sample_blending) * blending, 1.0f - a.maximum_blending, 1.0f);
+    a.new_color[pix] = make_float4(blended.x, blended.y, blended.z, next_blending);
+}
+
+struct Tap {  // one staged pixel of the denoise apron: 32 bytes
+    float r, g, b, nx, ny, nz, logd;
+    int32_t mat;
+};
+
+// One 16x16 output tile per block.  R = max radius the LDS apron is sized for.
+__global__ __launch_bounds__(256) void denoise_kernel(const DenoiseArgs a) {
+    extern __shared__ float4 lds_raw[];
+    Tap* tile = reinterpret_cast<Tap*>(lds_raw);
+    const int r = int(a.radius);
+    const int tw = 16 + 2 * r;
+    const int x0 = blockIdx.x * 16 - r;
+    const int lrow0 = blockIdx.y * 16;  // band_rows is a multiple of 16: a tile never straddles two bands
+    const int y0 = frame_row(a.band, lrow0) - r;
+    const int lband = lrow0 / a.band.band_rows;
+    const int band_y0 = (lband * a.band.nranks + a.band.rank) * a.band.band_rows;  // first frame row of the band
+
+    for (int i = threadIdx.x; i < tw * tw; i += 256) {
+        int tx = i % tw, ty = i / tw;
+        int gx = x0 + tx, gy = y0 + ty;
+        Tap t;
+        t.r = t.g = t.b = t.nx = t.ny = t.nz = t.logd = 0.0f;
+        t.mat = int32_t(0x7fffffff);  // marks "outside the frame" (denoise.comp:57 skips the tap)
+        if (gx >= 0 && gx < a.band.width && gy >= 0 && gy < a.band.height) {
+            int l = local_row(a.band, gy);
+            float4 c, nd, al;
+            bool have = true;
+            if (l >= 0) {
+                size_t p = size_t(l) * a.band.width + gx;
+                c = a.colors[p]; nd = a.nd[p]; al = a.albedo[p];
+            } else if (a.halo != nullptr) {
+                // row of a neighbouring rank: halo[(lband*2 + side)*r + k][3][width]
+                // side 0 = the r rows above the band, side 1 = the r rows below it
+                int side = gy < band_y0 ? 0 : 1;
+                int k = side == 0 ? gy - (band_y0 - r) : gy - (band_y0 + a.band.band_rows);
+                const float4* row = a.halo + (size_t((lband * 2 + side) * r + k) * 3) * a.band.width;
+                c = row[gx]; nd = row[a.band.width + gx]; al = row[2 * a.band.width + gx];
+            } else {
+                have = false;
+            }
+            if (have) {
+                t.r = c.x; t.g = c.y; t.b = c.z;
+                t.nx = nd.x; t.ny = nd.y; t.nz = nd.z;
+                t.logd = vx_log(vx_abs(nd.w));
+                t.mat = __float_as_int(al.w) >> 24;
+            }
+        }
+        tile[i] = t;
+    }
+    __syncthreads();
+
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int x = blockIdx.x * 16 + lx, lrow = lrow0 + ly;
+    if (x >= a.band.width || lrow >= a.band.local_rows) return;
+    const int y = frame_row(a.band, lrow);
+    if (y >= a.band.height) return;
+    const size_t pix = size_t(lrow) * a.band.width + x;
+
+    const Tap ct = tile[(ly + r) * tw + (lx + r)];
+    const f3 cc = mk3(ct.r, ct.g, ct.b), cn = mk3(ct.nx, ct.ny, ct.nz);
+    const f3 ray_dir = pixel_dir(a.cam, x, y);
+    const float depth_bias = vx_max(0.0f, dot3(cn, -ray_dir));
+
+    float normalization = 0.0f;
+    f3 sum = splat3(0.0f);
+    for (int dy = -r; dy <= r; dy++) {
+        for (int dx = -r; dx <= r; dx++) {
+            const Tap w = tile[(ly + r + dy) * tw + (lx + r + dx)];
+            if (w.mat == int32_t(0x7fffffff)) continue;
+            f3 wc = mk3(w.r, w.g, w.b);
+            f3 color_delta = cc - wc;
+            f3 normal_delta = cn - mk3(w.nx, w.ny, w.nz);
+            float depth_delta = ct.logd - w.logd;
+            float material_delta = ct.mat != w.mat ? 1.0f : 0.0f;
+            float bd = depth_bias * depth_delta;
+            float factor_range = (((dot3(color_delta, color_delta) + 1e4f * dot3(normal_delta, normal_delta)) + 1e4f * (bd * bd)) +
+                                  1e4f * material_delta) / a.sigma_range_2;
+            float factor_distance = float(dx * dx + dy * dy) / a.sigma_distance_2;
+            float factor = vx_exp(-factor_range - factor_distance);
+            normalization += factor;
+            sum = sum + wc * factor;
+        }
+    }
+    f3 out = a.radius == 0u ? cc : sum / normalization;
+    f3 alb = xyz(a.albedo[pix]);
+    out = mix3(out, alb * out, a.albedo_factor);
+    a.output[pix] = make_float4(out.x, out.y, out.z, 1.0f);
+}
+
+__global__ void noise_fill_kernel(float* dst, uint32_t seed, size_t n) {
+    size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    size_t stride = size_t(gridDim.x) * blockDim.x;
+    for (; i < n; i += stride) {
+        uint32_t z = uint32_t(i) * 0x9E3779B9u + seed;
+        z ^= z >> 16; z *= 0x85EBCA6Bu;
+        z ^= z >> 13; z *= 0xC2B2AE35u;
+        z ^= z >> 16;
+        dst[i] = float(z >> 8) * (1.0f / 16777216.0f);
+    }
+}
+
+__global__ void detmath_probe_kernel(int fn, const float* x, const float* y, float* out, size_t n) {
+    size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = 0.0f;
+    switch (fn) {
+        case 0: v = vx_sin(x[i]); break;
+        case 1: v = vx_cos(x[i]); break;
+        case 2: v = vx_exp(x[i]); break;
+        case 3: v = vx_log(x[i]); break;
+        case 4: v = vx_pow(x[i], y[i]); break;
+        case 5: v = vx_sqrt(x[i]); break;
+        case 6: v = x[i] / y[i]; break;
+        case 7: v = vx_tan(x[i]); break;
+        case 8: {  // normalize + dot + cross chain, the shape of most shading arithmetic
+            f3 a = norm3(mk3(x[i], y[i], x[i] * y[i] + 0.25f));
+            f3 b = cross3(a, mk3(y[i], x[i], 1.0f));
+            v = dot3(a, b) + len3(b);
+            break;
+        }
+    }
+    out[i] = v;
+}
+
+}  // namespace
+
+hipError_t launch_temporal(const TemporalArgs& a, hipStream_t s) {
+    dim3 grid((a.band.width + 63) / 64, (a.band.local_rows + 3) / 4);
+    hipLaunchKernelGGL(temporal_kernel, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_denoise(const DenoiseArgs& a, hipStream_t s) {
+    dim3 grid((a.band.width + 15) / 16, (a.band.local_rows + 15) / 16);
+    int tw = 16 + 2 * int(a.radius);
+    size_t lds = size_t(tw) * tw * sizeof(Tap);
+    hipLaunchKernelGGL(denoise_kernel, grid, dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_noise_fill(float* dst, uint32_t seed, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(noise_fill_kernel, dim3(2048), dim3(256), 0, s, dst, seed, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_detmath_probe(int fn, const float* x, const float* y, float* out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(detmath_probe_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, fn, x, y, out, n);
+    return hipGetLastError();
+}
+
+}  // namespace vxrt

@@ -1,0 +1,53 @@
+// scene_host.h — host-side scene preparation of libvxrt: .vox decoding, the voxel-list adapter,
+// the reference-layout sparse octree, the camera basis, the noise table and procedural scenes.
+// Pure C++17, no GPU; compiled into libvxrt.so by hipcc as ordinary host code.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/vxrt.h"
+
+namespace vxrt {
+
+void set_error(const std::string& msg);  // thread-local text behind vxrt_last_error()
+
+struct Voxel {
+    int16_t x, y, z;
+    uint8_t m, r, g, b;
+};
+
+struct VoxScene {
+    uint32_t size[3] = {0, 0, 0};  // SIZE chunk of model 0 (x, y, z in file axes)
+    std::vector<Voxel> voxels;     // already in the renderer's axes (x, z_file, y_file)
+};
+
+// MagicaVoxel v150 -> voxel list with the semantics of vox::parse + Context::voxels_from_vox
+// (src/vox.rs:11-101, src/context.rs:913-933).
+int decode_vox(const uint8_t* bytes, size_t len, VoxScene* out);
+
+// Sparse octree in the layout shaders/voxels.comp:58-63 reads: 5-word header
+// [cx, cy, cz, root_size, child_size] (f32 bits) followed by 8 int32 slots per node
+// (0 empty, >0 child node, <0 leaf word).  Built with the insertion order and overwrite rule of
+// Context::create_octree_nodes (src/context.rs:710-773).
+struct Octree {
+    std::vector<int32_t> words;
+    uint32_t depth = 0;  // root_size = 2^depth
+    size_t node_count() const { return words.size() < 5 ? 0 : (words.size() - 5) / 8; }
+};
+int build_octree(const Voxel* voxels, size_t n, Octree* out);
+
+struct CameraBasis {
+    float right[3], up[3], forward_ray[3];
+};
+// Camera::axis_scaled (src/camera.rs:19-28).
+CameraBasis camera_axis_scaled(const float dir[3], float fov, uint32_t width, uint32_t height);
+
+float noise_value(uint32_t seed, uint32_t index);  // documented in vxrt.h (vxrt_noise_table)
+
+// Level-L Menger sponge: cell (x,y,z) in [0,3^L)^3 is solid unless, at some base-3 digit position,
+// at least two of its three digits equal 1.
+bool menger_solid(uint32_t level, uint32_t x, uint32_t y, uint32_t z);
+
+}  // namespace vxrt

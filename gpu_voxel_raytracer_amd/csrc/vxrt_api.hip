@@ -1,0 +1,794 @@
+// vxrt_api.hip — the C ABI of libvxrt (include/vxrt.h): context, scene upload, frame sequencing.
+// Stands where the reference's wgpu `Context` stands (src/context.rs); each entry point cites the
+// call site it replaces in vxrt.h.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iterator>
+#include <string>
+#include <vector>
+
+#include "../../include/vxrt.h"
+#include "kernels.h"
+#include "scene_host.h"
+#include "vx_vec.h"
+
+namespace vxrt {
+const std::string& last_error();
+}
+using namespace vxrt;
+
+namespace {
+
+constexpr size_t kNoiseCount = size_t(512) * 128 * 128;  // shaders/voxels.comp:65-67
+
+int hip_fail(hipError_t e, const char* what) {
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return VXRT_E_DEVICE;
+}
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t e_ = (expr);                         \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr); \
+    } while (0)
+
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    int stage = 0;  // 0 trace, 1 temporal, 2 denoise
+};
+
+}  // namespace
+
+struct vxrt_ctx {
+    vxrt_config cfg{};
+    BandMap band{};
+    hipStream_t stream = nullptr;
+
+    // scene
+    bool has_scene = false;
+    SvoRecord* d_svo = nullptr;
+    int32_t* d_leaves = nullptr;
+    size_t svo_count = 0, leaf_count = 0;
+    float root_center[3] = {0, 0, 0};
+    float root_size = 1.0f;
+    uint32_t depth = 0;
+    float* d_noise = nullptr;
+
+    // images (local rows x width, rgba32f)
+    float4* sampled_color = nullptr;
+    float4* albedo = nullptr;
+    float4* nd[2] = {nullptr, nullptr};
+    float4* accum[2] = {nullptr, nullptr};
+    float4* denoised = nullptr;
+    float4* halo = nullptr;  // rows of neighbouring ranks for the denoise window
+    uint32_t halo_radius = 0;
+    bool halo_valid = false;
+    int cur = 0;             // nd[cur]/accum[cur] are written this frame, [cur^1] hold the history
+    bool has_history = false;
+    bool accum_is_sampled = true;  // the latest "accumulated" image is sampled_color (temporal never ran)
+    int last = 0;                   // index of the most recently completed nd/accum pair
+
+    // parameters
+    vxrt_uniforms uniforms{};
+    vxrt_temporal temporal{};
+    vxrt_denoise denoise{};
+    float cam_pos[3] = {0, 0, -2}, cam_dir[3] = {0, 0, 1}, cam_fov = 1.2217305f;  // src/context.rs:618-622
+    Cam cam{}, old_cam{};
+    bool old_cam_valid = false;
+
+    // stats
+    unsigned long long* d_rays = nullptr;
+    uint64_t frames = 0, pixels = 0, timed_frames = 0;
+    double ms[3] = {0, 0, 0};
+    std::vector<EventPair> pending, free_pairs;
+};
+
+namespace {
+
+size_t image_bytes(const vxrt_ctx* c) { return size_t(c->band.local_rows) * c->band.width * sizeof(float4); }
+
+int count_local_rows(const BandMap& b) {
+    int rows = 0;
+    for (int y0 = 0, band = 0; y0 < b.height; y0 += b.band_rows, band++)
+        if (band % b.nranks == b.rank) rows += (y0 + b.band_rows <= b.height) ? b.band_rows : b.height - y0;
+    return rows;
+}
+
+int local_band_count(const BandMap& b) {
+    int bands = (b.height + b.band_rows - 1) / b.band_rows;
+    return bands <= b.rank ? 0 : (bands - b.rank + b.nranks - 1) / b.nranks;
+}
+
+void free_images(vxrt_ctx* c) {
+    float4** imgs[] = {&c->sampled_color, &c->albedo, &c->nd[0], &c->nd[1], &c->accum[0], &c->accum[1], &c->denoised, &c->halo};
+    for (float4** p : imgs) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+}
+
+int alloc_images(vxrt_ctx* c) {
+    free_images(c);
+    size_t bytes = image_bytes(c);
+    if (bytes == 0) bytes = sizeof(float4);
+    float4** imgs[] = {&c->sampled_color, &c->albedo, &c->nd[0], &c->nd[1], &c->accum[0], &c->accum[1], &c->denoised};
+    for (float4** p : imgs) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), bytes));
+        HIP_TRY(hipMemsetAsync(*p, 0, bytes, c->stream));
+    }
+    c->cur = 0;
+    c->last = 0;
+    c->has_history = false;
+    c->accum_is_sampled = true;
+    c->halo_valid = false;
+    c->halo_radius = 0;
+    return VXRT_OK;
+}
+
+int set_band(vxrt_ctx* c, uint32_t width, uint32_t height) {
+    const vxrt_config& cfg = c->cfg;
+    BandMap b;
+    b.width = int(width);
+    b.height = int(height);
+    b.nranks = cfg.nranks == 0 ? 1 : int(cfg.nranks);
+    b.rank = int(cfg.rank);
+    b.band_rows = cfg.band_rows == 0 ? 16 : int(cfg.band_rows);
+    if (b.nranks == 1) b.rank = 0;
+    b.local_rows = count_local_rows(b);
+    c->band = b;
+    return VXRT_OK;
+}
+
+Cam make_cam(const float pos[3], const CameraBasis& b) {
+    Cam c;
+    for (int i = 0; i < 3; i++) { c.o[i] = pos[i]; c.r[i] = b.right[i]; c.u[i] = b.up[i]; c.f[i] = b.forward_ray[i]; }
+    return c;
+}
+
+// inverse of [R U F O; 0 0 0 1] (temporal.comp:75-82) by adjugate / determinant in binary64, rounded
+// once to binary32: rows of A^-1 and the translation -A^-1 O.
+void affine_inverse(const Cam& c, float inv[12]) {
+    const double a = c.r[0], b = c.u[0], cc = c.f[0], d = c.r[1], e = c.u[1], f = c.f[1], g = c.r[2], h = c.u[2], i = c.f[2];
+    const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+    const double det = a * A + b * B + cc * C;
+    const double m[9] = {A, -(b * i - cc * h), b * f - cc * e, B, a * i - cc * g, -(a * f - cc * d), C, -(a * h - b * g), a * e - b * d};
+    for (int r = 0; r < 3; r++) {
+        const double r0 = m[3 * r] / det, r1 = m[3 * r + 1] / det, r2 = m[3 * r + 2] / det;
+        inv[4 * r] = float(r0); inv[4 * r + 1] = float(r1); inv[4 * r + 2] = float(r2);
+        inv[4 * r + 3] = float(-(r0 * double(c.o[0]) + r1 * double(c.o[1]) + r2 * double(c.o[2])));
+    }
+}
+
+EventPair take_pair(vxrt_ctx* c, int stage) {
+    EventPair p;
+    if (!c->free_pairs.empty()) {
+        p = c->free_pairs.back();
+        c->free_pairs.pop_back();
+    } else {
+        (void)hipEventCreate(&p.a);
+        (void)hipEventCreate(&p.b);
+    }
+    p.stage = stage;
+    return p;
+}
+
+int resolve_events(vxrt_ctx* c) {
+    for (EventPair& p : c->pending) {
+        HIP_TRY(hipEventSynchronize(p.b));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
+        c->ms[p.stage] += double(ms);
+        c->free_pairs.push_back(p);
+    }
+    c->pending.clear();
+    return VXRT_OK;
+}
+
+// reference-layout octree words -> breadth-first SVO records + leaf words (kernels.h)
+int flatten_svo(const Octree& tree, std::vector<SvoRecord>* recs, std::vector<int32_t>* leaves) {
+    const int32_t* nodes = tree.words.data() + 5;
+    std::vector<uint32_t> order{0};
+    order.reserve(tree.node_count());
+    recs->clear();
+    recs->reserve(tree.node_count());
+    leaves->clear();
+    for (size_t i = 0; i < order.size(); i++) {
+        const int32_t* slot = nodes + size_t(8) * order[i];
+        uint32_t child_mask = 0, leaf_mask = 0;
+        for (int s = 0; s < 8; s++) {
+            if (slot[s] > 0) child_mask |= 1u << s;
+            else if (slot[s] < 0) leaf_mask |= 1u << s;
+        }
+        if (child_mask && leaf_mask) { set_error("node mixes children and leaves"); return VXRT_E_SCENE; }
+        SvoRecord r;
+        r.masks = child_mask | leaf_mask << 8;
+        if (leaf_mask) {
+            r.base = uint32_t(leaves->size());
+            for (int s = 0; s < 8; s++) if (slot[s] < 0) leaves->push_back(slot[s]);
+        } else {
+            r.base = uint32_t(order.size());
+            for (int s = 0; s < 8; s++) if (slot[s] > 0) order.push_back(uint32_t(slot[s]));
+        }
+        recs->push_back(r);
+    }
+    return VXRT_OK;
+}
+
+int upload_scene(vxrt_ctx* c, const Voxel* voxels, size_t n) {
+    Octree tree;
+    if (int rc = build_octree(voxels, n, &tree)) return rc;
+    std::vector<SvoRecord> recs;
+    std::vector<int32_t> leaves;
+    if (int rc = flatten_svo(tree, &recs, &leaves)) return rc;
+    if (leaves.empty()) leaves.push_back(0);
+
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_svo) (void)hipFree(c->d_svo);
+    if (c->d_leaves) (void)hipFree(c->d_leaves);
+    c->d_svo = nullptr;
+    c->d_leaves = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_svo), recs.size() * sizeof(SvoRecord)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_leaves), leaves.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(c->d_svo, recs.data(), recs.size() * sizeof(SvoRecord), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_leaves, leaves.data(), leaves.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    c->svo_count = recs.size();
+    c->leaf_count = leaves.size();
+    float hdr[5];
+    memcpy(hdr, tree.words.data(), sizeof hdr);
+    c->root_center[0] = hdr[0]; c->root_center[1] = hdr[1]; c->root_center[2] = hdr[2];
+    c->root_size = hdr[3];
+    c->depth = tree.depth;
+    c->has_scene = true;
+    return VXRT_OK;
+}
+
+bool valid_ctx(const vxrt_ctx* c) {
+    if (!c) { set_error("null context"); return false; }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t vxrt_abi_version(void) { return 1; }
+
+const char* vxrt_last_error(void) { return vxrt::last_error().c_str(); }
+
+const char* vxrt_status_string(int status) {
+    switch (status) {
+        case VXRT_OK: return "ok";
+        case VXRT_E_INVALID: return "invalid argument";
+        case VXRT_E_DEVICE: return "HIP runtime error";
+        case VXRT_E_VOX_MAGIC: return "invalid magic number";
+        case VXRT_E_VOX_VERSION: return "unsupported VOX-format";
+        case VXRT_E_VOX_NOMAIN: return "missing MAIN chunk";
+        case VXRT_E_VOX_EOF: return "unexpected end of file";
+        case VXRT_E_VOX_CHUNK: return "unexpected chunk";
+        case VXRT_E_VOX_MATERIAL: return "unsupported material";
+        case VXRT_E_VOX_NOMATL: return "voxel colour without material";
+        case VXRT_E_VOX_NOMODEL: return "no model in file";
+        case VXRT_E_IO: return "failed to read file";
+        case VXRT_E_SCENE: return "voxel list cannot be represented";
+        case VXRT_E_NOSCENE: return "no scene set";
+        default: return "unknown status";
+    }
+}
+
+void vxrt_default_uniforms(vxrt_uniforms* u) {
+    memset(u, 0, sizeof *u);
+    u->emit_strength = 4.0f;
+    u->sun_strength = 4.0f;
+    u->sun_size = 0.05f;
+    u->sun_yaw = 1.32f;
+    u->sun_pitch = 1.0f;
+    u->sun_color[0] = u->sun_color[1] = u->sun_color[2] = 1.0f;
+    u->sky_color[0] = 0.45f; u->sky_color[1] = 0.6f; u->sky_color[2] = 0.65f;
+    u->specularity = 0.0f;
+}
+void vxrt_default_temporal(vxrt_temporal* t) { t->sample_blending = 0.5f; t->maximum_blending = 0.98f; t->blending_distance_cutoff = 1e-2f; }
+void vxrt_default_denoise(vxrt_denoise* d) { d->radius = 0; d->sigma_distance = 2.0f; d->sigma_range = 1.5f; d->albedo_factor = 1.0f; }
+
+int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) {
+    if (!cfg || !out) { set_error("null argument"); return VXRT_E_INVALID; }
+    *out = nullptr;
+    if (cfg->width == 0 || cfg->height == 0 || cfg->width > 65536 || cfg->height > 65536) { set_error("bad frame size"); return VXRT_E_INVALID; }
+    if (cfg->max_bounces < 1 || cfg->max_bounces > 16) { set_error("max_bounces must be 1..16"); return VXRT_E_INVALID; }
+    uint32_t nranks = cfg->nranks == 0 ? 1 : cfg->nranks;
+    if (nranks > 1 && cfg->rank >= nranks) { set_error("rank >= nranks"); return VXRT_E_INVALID; }
+    uint32_t band_rows = cfg->band_rows == 0 ? 16 : cfg->band_rows;
+    if (band_rows % 16 != 0) { set_error("band_rows must be a multiple of 16"); return VXRT_E_INVALID; }
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) { return hip_fail(e == hipSuccess ? hipErrorNoDevice : e, "hipGetDeviceCount"); }
+    if (cfg->device < 0 || cfg->device >= ndev) { set_error("device ordinal out of range"); return VXRT_E_INVALID; }
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    vxrt_ctx* c = new vxrt_ctx();
+    c->cfg = *cfg;
+    c->cfg.noise = nullptr;  // borrowed for this call only
+    vxrt_default_uniforms(&c->uniforms);
+    vxrt_default_temporal(&c->temporal);
+    vxrt_default_denoise(&c->denoise);
+    int rc = VXRT_OK;
+    auto fail = [&](int code) { vxrt_destroy(c); return code; };
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipStreamCreate"));
+    set_band(c, cfg->width, cfg->height);
+    if ((rc = alloc_images(c)) != VXRT_OK) return fail(rc);
+    if (hipMalloc(reinterpret_cast<void**>(&c->d_noise), kNoiseCount * sizeof(float)) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipMalloc noise"));
+    if (cfg->noise) {
+        if (hipMemcpy(c->d_noise, cfg->noise, kNoiseCount * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(hip_fail(hipGetLastError(), "noise upload"));
+    } else {
+        if (launch_noise_fill(c->d_noise, cfg->noise_seed, kNoiseCount, c->stream) != hipSuccess) return fail(hip_fail(hipGetLastError(), "noise fill"));
+    }
+    if (hipMalloc(reinterpret_cast<void**>(&c->d_rays), sizeof(unsigned long long)) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipMalloc counter"));
+    if (hipMemsetAsync(c->d_rays, 0, sizeof(unsigned long long), c->stream) != hipSuccess) return fail(hip_fail(hipGetLastError(), "memset counter"));
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(hip_fail(hipGetLastError(), "sync"));
+    *out = c;
+    return VXRT_OK;
+}
+
+int vxrt_destroy(vxrt_ctx* c) {
+    if (!c) return VXRT_OK;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto* v : {&c->pending, &c->free_pairs})
+        for (EventPair& p : *v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    free_images(c);
+    if (c->d_svo) (void)hipFree(c->d_svo);
+    if (c->d_leaves) (void)hipFree(c->d_leaves);
+    if (c->d_noise) (void)hipFree(c->d_noise);
+    if (c->d_rays) (void)hipFree(c->d_rays);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return VXRT_OK;
+}
+
+int vxrt_resize(vxrt_ctx* c, uint32_t width, uint32_t height) {
+    if (!valid_ctx(c)) return VXRT_E_INVALID;
+    if (width == 0 || height == 0 || width > 65536 || height > 65536) { set_error("bad frame size"); return VXRT_E_INVALID; }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->cfg.width = width;
+    c->cfg.height = height;
+    set_band(c, width, height);
+    return alloc_images(c);  // new zeroed images: the history is gone (src/context.rs:1440-1448)
+}
+
+int vxrt_set_voxels(vxrt_ctx* c, const int16_t (*pos)[3], const uint8_t (*mrgb)[4], size_t n) {
+    if (!valid_ctx(c)) return VXRT_E_INVALID;
+    if (n != 0 && (!pos || !mrgb)) { set_error("null voxel arrays"); return VXRT_E_INVALID; }
+    std::vector<Voxel> v(n);
+    for (size_t i = 0; i < n; i++) {
+        v[i].x = pos[i][0]; v[i].y = pos[i][1]; v[i].z = pos[i][2];
+        v[i].m = mrgb[i][0]; v[i].r = mrgb[i][1]; v[i].g = mrgb[i][2]; v[i].b = mrgb[i][3];
+    }
+    return upload_scene(c, v.data(), n);
+}
+
+int vxrt_load_vox_memory(vxrt_ctx* c, const uint8_t* bytes, size_t len) {
+    if (!valid_ctx(c)) return VXRT_E_INVALID;
+    if (!bytes) { set_error("null bytes"); return VXRT_E_INVALID; }
+    VoxScene scene;
+    if (int rc = decode_vox(bytes, len, &scene)) return rc;
+    return upload_scene(c, scene.voxels.data(), scene.voxels.size());
+}
+
+int vxrt_load_vox(vxrt_ctx* c, const char* path) {
+    if (!valid_ctx(c)) return VXRT_E_INVALID;
+    if (!path) { set_error("null path"); return VXRT_E_INVALID; }
+    std::ifstream f(path, std::ios::binary);
+    if (!f) { set_error(std::string("failed to read file: ") + path); return VXRT_E_IO; }
+    std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    return vxrt_load_vox_memory(c, bytes.data(), bytes.size());
+}
+
+int vxrt_set_camera(vxrt_ctx* c, const float position[3], const float direction[3], float fov) {
+    if (!valid_ctx(c)) return VXRT_E_INVALID;
+    if (!position || !direction) { set_error("null camera vectors"); return VXRT_E_INVALID; }
+    memcpy(c->cam_pos, position, sizeof c->cam_pos);
+    memcpy(c->cam_dir, direction, sizeof c->cam_dir);
+    c->cam_fov = fov;
+    return VXRT_OK;
+}
+
+int vxrt_set_scene_params(vxrt_ctx* c, const vxrt_uniforms* u) {
+    if (!valid_ctx(c) || !u) { set_error("null argument"); return VXRT_E_INVALID; }
+    uint32_t frame = c->uniforms.frame_number;
+    c->uniforms = *u;
+    c->uniforms.frame_number = frame;  // owned by the library, like update_bindings (src/context.rs:2152)
+    return VXRT_OK;
+}
+int vxrt_set_temporal(vxrt_ctx* c, const vxrt_temporal* t) {
+    if (!valid_ctx(c) || !t) { set_error("null argument"); return VXRT_E_INVALID; }
+    c->temporal = *t;
+    return VXRT_OK;
+}
+int vxrt_set_denoise(vxrt_ctx* c, const vxrt_denoise* d) {
+    if (!valid_ctx(c) || !d) { set_error("null argument"); return VXRT_E_INVALID; }
+    if (d->radius > 8) { set_error("denoise radius must be 0..8"); return VXRT_E_INVALID; }
+    c->denoise = *d;
+    return VXRT_OK;
+}
+
+int vxrt_reset_history(vxrt_ctx* c) {
+    if (!valid_ctx(c)) return VXRT_E_INVALID;
+    c->has_history = false;
+    c->old_cam_valid = false;
+    return VXRT_OK;
+}
+
+int vxrt_set_frame_number(vxrt_ctx* c, uint32_t frame_number) {
+    if (!valid_ctx(c)) return VXRT_E_INVALID;
+    c->uniforms.frame_number = frame_number;
+    return VXRT_OK;
+}
+
+int vxrt_render(vxrt_ctx* c, uint32_t flags) {
+    if (!valid_ctx(c)) return VXRT_E_INVALID;
+    if ((flags & VXRT_ALL) == 0) { set_error("no stage selected"); return VXRT_E_INVALID; }
+    if (!c->has_scene) { set_error("vxrt_render before any scene was set"); return VXRT_E_NOSCENE; }
+    const bool multi = c->band.nranks > 1;
+    if ((flags & VXRT_DENOISE) && multi && c->denoise.radius > 0 && (flags & (VXRT_TRACE | VXRT_TEMPORAL))) {
+        set_error("multi-rank denoise with radius > 0 needs the halo: render TRACE|TEMPORAL, exchange, then DENOISE");
+        return VXRT_E_INVALID;
+    }
+    if ((flags & VXRT_DENOISE) && multi && c->denoise.radius > 0 && !(c->halo_valid && c->halo_radius == c->denoise.radius)) {
+        set_error("multi-rank denoise: halo not imported for this frame/radius");
+        return VXRT_E_INVALID;
+    }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const bool timed = (flags & VXRT_TIMED) != 0;
+
+    if (flags & (VXRT_TRACE | VXRT_TEMPORAL)) {
+        // Context::update_bindings (src/context.rs:2136-2162): old <- current, current <- camera, frame_number + 1
+        if (flags & VXRT_TRACE) {
+            c->old_cam = c->cam;
+            CameraBasis basis = camera_axis_scaled(c->cam_dir, c->cam_fov, c->cfg.width, c->cfg.height);
+            c->cam = make_cam(c->cam_pos, basis);
+            for (int i = 0; i < 3; i++) {
+                c->uniforms.camera_origin[i] = c->cam.o[i]; c->uniforms.camera_right[i] = c->cam.r[i];
+                c->uniforms.camera_up[i] = c->cam.u[i]; c->uniforms.camera_forward[i] = c->cam.f[i];
+            }
+            c->uniforms.still_sample += 1;
+            c->uniforms.frame_number += 1;  // wrapping
+        }
+    }
+
+    if (flags & VXRT_TRACE) {
+        const vxrt_uniforms& u = c->uniforms;
+        TraceArgs a;
+        a.svo = c->d_svo; a.leaves = c->d_leaves; a.noise = c->d_noise;
+        a.out_color = c->sampled_color; a.out_nd = c->nd[c->cur]; a.out_albedo = c->albedo;
+        a.ray_counter = c->d_rays;
+        memcpy(a.root_center, c->root_center, sizeof a.root_center);
+        a.root_size = c->root_size;
+        a.band = c->band;
+        a.max_bounces = int(c->cfg.max_bounces);
+        a.frame_number = u.frame_number;
+        a.stack_levels = c->depth < 1 ? 1 : int(c->depth);
+        a.cam = c->cam;
+        // voxels.comp:296 and the other per-frame constants, evaluated once with the same operations
+        f3 sun_dir = mk3(vx_cos(u.sun_yaw) * vx_cos(u.sun_pitch), -vx_sin(u.sun_pitch), vx_sin(u.sun_yaw) * vx_cos(u.sun_pitch));
+        f3 sun_n = norm3(sun_dir), neg_sun_n = norm3(-sun_dir);
+        f3 sun_color = u.sun_strength * mk3(u.sun_color[0], u.sun_color[1], u.sun_color[2]);
+        a.sun_dir[0] = sun_dir.x; a.sun_dir[1] = sun_dir.y; a.sun_dir[2] = sun_dir.z;
+        a.sun_dir_n[0] = sun_n.x; a.sun_dir_n[1] = sun_n.y; a.sun_dir_n[2] = sun_n.z;
+        a.neg_sun_dir_n[0] = neg_sun_n.x; a.neg_sun_dir_n[1] = neg_sun_n.y; a.neg_sun_dir_n[2] = neg_sun_n.z;
+        a.sun_color[0] = sun_color.x; a.sun_color[1] = sun_color.y; a.sun_color[2] = sun_color.z;
+        a.sky_color[0] = u.sky_color[0]; a.sky_color[1] = u.sky_color[1]; a.sky_color[2] = u.sky_color[2];
+        a.sun_exponent = 1.0f / (u.sun_size * u.sun_size);
+        a.sun_size = u.sun_size; a.sun_strength = u.sun_strength; a.emit_strength = u.emit_strength; a.specularity = u.specularity;
+        if (c->band.local_rows > 0) {
+            EventPair p;
+            if (timed) { p = take_pair(c, 0); HIP_TRY(hipEventRecord(p.a, c->stream)); }
+            HIP_TRY(launch_trace(a, c->stream));
+            if (timed) { HIP_TRY(hipEventRecord(p.b, c->stream)); c->pending.push_back(p); }
+        }
+        c->frames += 1;
+        c->pixels += uint64_t(c->band.local_rows) * c->band.width;
+        if (timed) c->timed_frames += 1;
+        c->accum_is_sampled = true;
+        c->last = c->cur;
+        c->halo_valid = false;
+    }
+
+    if (flags & VXRT_TEMPORAL) {
+        TemporalArgs a;
+        a.sampled_color = c->sampled_color; a.new_nd = c->nd[c->cur];
+        a.old_color = c->accum[c->cur ^ 1]; a.old_nd = c->nd[c->cur ^ 1];
+        a.new_color = c->accum[c->cur];
+        a.band = c->band;
+        a.cam = c->cam;
+        a.old_cam = c->old_cam;
+        a.has_history = (c->has_history && c->old_cam_valid) ? 1 : 0;
+        memset(a.inv, 0, sizeof a.inv);
+        if (a.has_history) affine_inverse(c->old_cam, a.inv);
+        a.sample_blending = c->temporal.sample_blending;
+        a.maximum_blending = c->temporal.maximum_blending;
+        a.blending_distance_cutoff = c->temporal.blending_distance_cutoff;
+        if (c->band.local_rows > 0) {
+            EventPair p;
+            if (timed) { p = take_pair(c, 1); HIP_TRY(hipEventRecord(p.a, c->stream)); }
+            HIP_TRY(launch_temporal(a, c->stream));
+            if (timed) { HIP_TRY(hipEventRecord(p.b, c->stream)); c->pending.push_back(p); }
+        }
+        c->accum_is_sampled = false;
+        c->last = c->cur;
+        c->cur ^= 1;  // hand the G-buffer over: what was written becomes the history (src/context.rs:2041-2043)
+        c->has_history = true;
+    }
+    if (flags & VXRT_TRACE) c->old_cam_valid = true;  // the next frame's "old" camera is this frame's
+
+    if (flags & VXRT_DENOISE) {
+        DenoiseArgs a;
+        a.colors = c->accum_is_sampled ? c->sampled_color : c->accum[c->last];
+        a.nd = c->nd[c->last];
+        a.albedo = c->albedo;
+        a.output = c->denoised;
+        a.halo = (multi && c->denoise.radius > 0) ? c->halo : nullptr;
+        a.band = c->band;
+        a.cam = c->cam;
+        a.radius = c->denoise.radius;
+        a.sigma_distance_2 = 2.0f * (c->denoise.sigma_distance * c->denoise.sigma_distance);  // denoise.comp:39-40
+        a.sigma_range_2 = 2.0f * (c->denoise.sigma_range * c->denoise.sigma_range);
+        a.albedo_factor = c->denoise.albedo_factor;
+        if (c->band.local_rows > 0) {
+            EventPair p;
+            if (timed) { p = take_pair(c, 2); HIP_TRY(hipEventRecord(p.a, c->stream)); }
+            HIP_TRY(launch_denoise(a, c->stream));
+            if (timed) { HIP_TRY(hipEventRecord(p.b, c->stream)); c->pending.push_back(p); }
+        }
+    }
+    return VXRT_OK;
+}
+
+int vxrt_sync(vxrt_ctx* c) {
+    if (!valid_ctx(c)) return VXRT_E_INVALID;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return resolve_events(c);
+}
+
+static float4* image_ptr(vxrt_ctx* c, vxrt_image which) {
+    switch (which) {
+        case VXRT_SAMPLED_COLOR: return c->sampled_color;
+        case VXRT_NORMAL_DEPTH: return c->nd[c->last];
+        case VXRT_ALBEDO_NODE: return c->albedo;
+        case VXRT_ACCUM_COLOR: return c->accum_is_sampled ? c->sampled_color : c->accum[c->last];
+        case VXRT_DENOISED: return c->denoised;
+        default: return nullptr;
+    }
+}
+
+int vxrt_read(vxrt_ctx* c, vxrt_image which, float* dst, size_t bytes) {
+    if (!valid_ctx(c)) return VXRT_E_INVALID;
+    float4* src = image_ptr(c, which);
+    if (!src || !dst) { set_error("bad image or null destination"); return VXRT_E_INVALID; }
+    if (bytes != image_bytes(c)) { set_error("vxrt_read: bytes must equal local_rows*width*16"); return VXRT_E_INVALID; }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (bytes) HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return VXRT_OK;
+}
+
+int vxrt_device_image(vxrt_ctx* c, vxrt_image which, void** device_ptr, size_t* bytes) {
+    if (!valid_ctx(c) || !device_ptr) { set_error("null argument"); return VXRT_E_INVALID; }
+    float4* src = image_ptr(c, which);
+    if (!src) { set_error("bad image"); return VXRT_E_INVALID; }
+    *device_ptr = src;
+    if (bytes) *bytes = image_bytes(c);
+    return VXRT_OK;
+}
+
+int vxrt_local_rows(const vxrt_ctx* c, uint32_t* count, uint32_t* rows) {
+    if (!valid_ctx(c) || !count) { set_error("null argument"); return VXRT_E_INVALID; }
+    const BandMap& b = c->band;
+    uint32_t n = 0;
+    for (int y = 0; y < b.height; y++)
+        if ((y / b.band_rows) % b.nranks == b.rank) {
+            if (rows) rows[n] = uint32_t(y);
+            n++;
+        }
+    *count = n;
+    return VXRT_OK;
+}
+
+int vxrt_get_stats(vxrt_ctx* c, vxrt_stats* out) {
+    if (!valid_ctx(c) || !out) { set_error("null argument"); return VXRT_E_INVALID; }
+    if (int rc = vxrt_sync(c)) return rc;
+    unsigned long long rays = 0;
+    HIP_TRY(hipMemcpy(&rays, c->d_rays, sizeof rays, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof *out);
+    out->frames = c->frames;
+    out->rays = rays;
+    out->pixels = c->pixels;
+    out->trace_ms = c->ms[0];
+    out->temporal_ms = c->ms[1];
+    out->denoise_ms = c->ms[2];
+    out->timed_frames = c->timed_frames;
+    out->scene_bytes = c->svo_count * sizeof(SvoRecord) + c->leaf_count * sizeof(int32_t);
+    out->noise_bytes = kNoiseCount * sizeof(float);
+    out->local_rows = uint32_t(c->band.local_rows);
+    out->octree_depth = c->depth;
+    out->octree_nodes = c->svo_count;
+    return VXRT_OK;
+}
+
+int vxrt_reset_stats(vxrt_ctx* c) {
+    if (!valid_ctx(c)) return VXRT_E_INVALID;
+    if (int rc = vxrt_sync(c)) return rc;
+    HIP_TRY(hipMemset(c->d_rays, 0, sizeof(unsigned long long)));
+    c->frames = c->pixels = c->timed_frames = 0;
+    c->ms[0] = c->ms[1] = c->ms[2] = 0.0;
+    return VXRT_OK;
+}
+
+// ---- denoise halo ---------------------------------------------------------------------------------
+// Message to a neighbour: for each of ITS local bands j (up to max_bands), r rows x 3 images x width
+// float4.  A band's "above" rows come from the previous rank, its "below" rows from the next rank.
+static int max_bands(const BandMap& b) {
+    int bands = (b.height + b.band_rows - 1) / b.band_rows;
+    return (bands + b.nranks - 1) / b.nranks;
+}
+
+int vxrt_halo_bytes(vxrt_ctx* c, size_t* bytes) {
+    if (!valid_ctx(c) || !bytes) { set_error("null argument"); return VXRT_E_INVALID; }
+    *bytes = size_t(max_bands(c->band)) * c->denoise.radius * 3 * c->band.width * sizeof(float4);
+    return VXRT_OK;
+}
+
+int vxrt_halo_export(vxrt_ctx* c, void* dev_to_prev, void* dev_to_next) {
+    if (!valid_ctx(c)) return VXRT_E_INVALID;
+    const BandMap& b = c->band;
+    const int r = int(c->denoise.radius);
+    if (b.nranks < 2 || r == 0) return VXRT_OK;
+    if (!dev_to_prev || !dev_to_next) { set_error("null halo buffer"); return VXRT_E_INVALID; }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const float4* imgs[3] = {c->accum_is_sampled ? c->sampled_color : c->accum[c->last], c->nd[c->last], c->albedo};
+    const size_t row_bytes = size_t(b.width) * sizeof(float4);
+    const int nlb = local_band_count(b);
+    for (int lb = 0; lb < nlb; lb++) {
+        const int gb = lb * b.nranks + b.rank;
+        const int y0 = gb * b.band_rows;
+        const int rows = (y0 + b.band_rows <= b.height) ? b.band_rows : b.height - y0;
+        // my top rows are the "below" rows of band gb-1 (previous rank, its local band (gb-1)/nranks)
+        if (gb >= 1) {
+            const int j = (gb - 1) / b.nranks;
+            for (int k = 0; k < r && k < rows; k++)
+                for (int im = 0; im < 3; im++) {
+                    float4* dst = static_cast<float4*>(dev_to_prev) + (size_t(j * r + k) * 3 + im) * b.width;
+                    HIP_TRY(hipMemcpyAsync(dst, imgs[im] + size_t(lb * b.band_rows + k) * b.width, row_bytes, hipMemcpyDeviceToDevice, c->stream));
+                }
+        }
+        // my bottom rows are the "above" rows of band gb+1 (next rank, its local band (gb+1)/nranks)
+        if (rows == b.band_rows && (gb + 1) * b.band_rows < b.height) {
+            const int j = (gb + 1) / b.nranks;
+            for (int k = 0; k < r; k++)
+                for (int im = 0; im < 3; im++) {
+                    float4* dst = static_cast<float4*>(dev_to_next) + (size_t(j * r + k) * 3 + im) * b.width;
+                    HIP_TRY(hipMemcpyAsync(dst, imgs[im] + size_t(lb * b.band_rows + (b.band_rows - r) + k) * b.width, row_bytes, hipMemcpyDeviceToDevice, c->stream));
+                }
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VXRT_OK;
+}
+
+int vxrt_halo_import(vxrt_ctx* c, const void* dev_from_prev, const void* dev_from_next) {
+    if (!valid_ctx(c)) return VXRT_E_INVALID;
+    const BandMap& b = c->band;
+    const int r = int(c->denoise.radius);
+    if (b.nranks < 2 || r == 0) return VXRT_OK;
+    if (!dev_from_prev || !dev_from_next) { set_error("null halo buffer"); return VXRT_E_INVALID; }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const int nlb = local_band_count(b);
+    const size_t per_side = size_t(r) * 3 * b.width;  // float4 per (band, side)
+    if (c->halo == nullptr || c->halo_radius != uint32_t(r)) {
+        if (c->halo) (void)hipFree(c->halo);
+        c->halo = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->halo), size_t(nlb > 0 ? nlb : 1) * 2 * per_side * sizeof(float4)));
+    }
+    for (int lb = 0; lb < nlb; lb++) {
+        // side 0 ("above") was sent by the previous rank as its to_next message slot lb, side 1 by the next rank
+        HIP_TRY(hipMemcpyAsync(c->halo + size_t(lb * 2 + 0) * per_side, static_cast<const float4*>(dev_from_prev) + size_t(lb) * per_side,
+                               per_side * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->halo + size_t(lb * 2 + 1) * per_side, static_cast<const float4*>(dev_from_next) + size_t(lb) * per_side,
+                               per_side * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+    }
+    c->halo_radius = uint32_t(r);
+    c->halo_valid = true;
+    return VXRT_OK;
+}
+
+// ---- host-only helpers -------------------------------------------------------------------------------
+int vxrt_vox_to_voxels(const uint8_t* bytes, size_t len, int16_t (*pos)[3], uint8_t (*mrgb)[4], size_t cap, size_t* n,
+                       uint32_t size_xyz[3]) {
+    if (!bytes || !n) { set_error("null argument"); return VXRT_E_INVALID; }
+    VoxScene scene;
+    if (int rc = decode_vox(bytes, len, &scene)) return rc;
+    *n = scene.voxels.size();
+    if (size_xyz) memcpy(size_xyz, scene.size, sizeof scene.size);
+    for (size_t i = 0; i < scene.voxels.size() && i < cap; i++) {
+        const Voxel& v = scene.voxels[i];
+        if (pos) { pos[i][0] = v.x; pos[i][1] = v.y; pos[i][2] = v.z; }
+        if (mrgb) { mrgb[i][0] = v.m; mrgb[i][1] = v.r; mrgb[i][2] = v.g; mrgb[i][3] = v.b; }
+    }
+    return VXRT_OK;
+}
+
+int vxrt_build_octree(const int16_t (*pos)[3], const uint8_t (*mrgb)[4], size_t n, int32_t* words, size_t cap, size_t* n_words,
+                      uint32_t* depth) {
+    if (!n_words || (n != 0 && (!pos || !mrgb))) { set_error("null argument"); return VXRT_E_INVALID; }
+    std::vector<Voxel> v(n);
+    for (size_t i = 0; i < n; i++) {
+        v[i].x = pos[i][0]; v[i].y = pos[i][1]; v[i].z = pos[i][2];
+        v[i].m = mrgb[i][0]; v[i].r = mrgb[i][1]; v[i].g = mrgb[i][2]; v[i].b = mrgb[i][3];
+    }
+    Octree tree;
+    if (int rc = build_octree(v.data(), n, &tree)) return rc;
+    *n_words = tree.words.size();
+    if (depth) *depth = tree.depth;
+    if (words && cap >= tree.words.size()) memcpy(words, tree.words.data(), tree.words.size() * sizeof(int32_t));
+    return VXRT_OK;
+}
+
+int vxrt_camera_axis_scaled(const float position[3], const float direction[3], float fov, uint32_t width, uint32_t height,
+                            float right[3], float up[3], float forward_ray[3]) {
+    (void)position;
+    if (!direction || !right || !up || !forward_ray) { set_error("null argument"); return VXRT_E_INVALID; }
+    CameraBasis b = camera_axis_scaled(direction, fov, width, height);
+    memcpy(right, b.right, sizeof b.right);
+    memcpy(up, b.up, sizeof b.up);
+    memcpy(forward_ray, b.forward_ray, sizeof b.forward_ray);
+    return VXRT_OK;
+}
+
+int vxrt_noise_table(uint32_t seed, float* out, size_t n) {
+    if (!out) { set_error("null argument"); return VXRT_E_INVALID; }
+    for (size_t i = 0; i < n; i++) out[i] = noise_value(seed, uint32_t(i));
+    return VXRT_OK;
+}
+
+int vxrt_menger_voxels(uint32_t level, const uint8_t mrgb[4], int16_t (*pos)[3], uint8_t (*out_mrgb)[4], size_t cap, size_t* n) {
+    if (!n || !mrgb || level > 9) { set_error("bad argument"); return VXRT_E_INVALID; }
+    uint32_t side = 1;
+    for (uint32_t l = 0; l < level; l++) side *= 3;
+    if (side > 32767) { set_error("menger side exceeds i16"); return VXRT_E_INVALID; }
+    size_t count = 0;
+    for (uint32_t x = 0; x < side; x++)
+        for (uint32_t y = 0; y < side; y++)
+            for (uint32_t z = 0; z < side; z++)
+                if (menger_solid(level, x, y, z)) {
+                    if (count < cap) {
+                        if (pos) { pos[count][0] = int16_t(x); pos[count][1] = int16_t(y); pos[count][2] = int16_t(z); }
+                        if (out_mrgb) memcpy(out_mrgb[count], mrgb, 4);
+                    }
+                    count++;
+                }
+    *n = count;
+    return VXRT_OK;
+}
+
+// device-vs-host bit equality probe of include/vxrt_detmath.h (test hook; host arrays in and out)
+int vxrt_detmath_probe(int32_t device, int32_t fn, const float* x, const float* y, float* out, size_t n) {
+    if (!x || !y || !out) { set_error("null argument"); return VXRT_E_INVALID; }
+    HIP_TRY(hipSetDevice(device));
+    float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dx), n * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dy), n * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dout), n * 4));
+    HIP_TRY(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(launch_detmath_probe(fn, dx, dy, dout, n, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
+    return VXRT_OK;
+}
+
+}  // extern "C"

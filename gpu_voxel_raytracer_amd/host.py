@@ -1,0 +1,332 @@
+"""Host-side mirror of the reference's render-loop interface, over the C ABI of libvxrt.so.
+
+The reference is a Rust binary whose host code (src/main.rs, src/context.rs, src/camera.rs, src/vox.rs)
+drives the GPU through wgpu.  Rust is not available in this image, so the host side above the C ABI is
+this thin ctypes layer; it keeps the reference's names and argument meaning:
+
+    Camera{position, direction, fov}                      src/camera.rs:5-9
+    Uniforms / TemporalUniforms / DenoiseUniforms         src/context.rs:425-525, 304-325
+    Context.recreate_octree(voxels) / load_vox(path)      src/context.rs:799-810, 1817-1821
+    Context.render()                                      src/context.rs:2004-2075
+    Context.resize(w, h)                                  src/context.rs:1430-1461
+
+There is NO CPU fallback: if libvxrt.so is missing or no HIP device is present, construction raises.
+Nothing here imports the test oracle.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+_LIB = None
+
+
+class VxrtError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        super().__init__(f"{where}: status {status} ({detail})")
+
+
+# vxrt_status (include/vxrt.h)
+OK, E_INVALID, E_DEVICE = 0, -1, -2
+E_VOX_MAGIC, E_VOX_VERSION, E_VOX_NOMAIN, E_VOX_EOF, E_VOX_CHUNK = -10, -11, -12, -13, -14
+E_VOX_MATERIAL, E_VOX_NOMATL, E_VOX_NOMODEL, E_IO, E_SCENE, E_NOSCENE = -15, -16, -17, -18, -20, -21
+
+# vxrt_image
+SAMPLED_COLOR, NORMAL_DEPTH, ALBEDO_NODE, ACCUM_COLOR, DENOISED = range(5)
+# render flags
+TRACE, TEMPORAL, DENOISE, ALL, TIMED = 1, 2, 4, 7, 8
+
+NOISE_LEN = 512 * 128 * 128
+DEFAULT_NOISE_SEED = 0x5EED0001
+
+
+class Uniforms(C.Structure):
+    """vxrt_uniforms == Uniforms, src/context.rs:425-469 (148 bytes)."""
+    _fields_ = [
+        ("camera_origin", C.c_float * 4), ("camera_right", C.c_float * 4), ("camera_up", C.c_float * 4),
+        ("camera_forward", C.c_float * 4), ("light", C.c_float * 4), ("global_time", C.c_float),
+        ("still_sample", C.c_uint32), ("frame_number", C.c_uint32), ("emit_strength", C.c_float),
+        ("sun_strength", C.c_float), ("sun_size", C.c_float), ("sun_yaw", C.c_float), ("sun_pitch", C.c_float),
+        ("sun_color", C.c_float * 4), ("sky_color", C.c_float * 4), ("specularity", C.c_float),
+    ]
+
+    @classmethod
+    def default(cls):
+        u = cls()
+        lib().vxrt_default_uniforms(C.byref(u))
+        return u
+
+
+class TemporalUniforms(C.Structure):
+    """vxrt_temporal == TemporalUniforms, src/context.rs:502-515."""
+    _fields_ = [("sample_blending", C.c_float), ("maximum_blending", C.c_float),
+                ("blending_distance_cutoff", C.c_float)]
+
+    @classmethod
+    def default(cls):
+        t = cls()
+        lib().vxrt_default_temporal(C.byref(t))
+        return t
+
+
+class DenoiseUniforms(C.Structure):
+    """vxrt_denoise == DenoiseUniforms, src/context.rs:304-314."""
+    _fields_ = [("radius", C.c_uint32), ("sigma_distance", C.c_float), ("sigma_range", C.c_float),
+                ("albedo_factor", C.c_float)]
+
+    @classmethod
+    def default(cls):
+        d = cls()
+        lib().vxrt_default_denoise(C.byref(d))
+        return d
+
+
+class Config(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("device", C.c_int32), ("max_bounces", C.c_uint32),
+                ("noise_seed", C.c_uint32), ("noise", C.c_void_p), ("rank", C.c_uint32), ("nranks", C.c_uint32),
+                ("band_rows", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("frames", C.c_uint64), ("rays", C.c_uint64), ("pixels", C.c_uint64), ("trace_ms", C.c_double),
+                ("temporal_ms", C.c_double), ("denoise_ms", C.c_double), ("timed_frames", C.c_uint64),
+                ("scene_bytes", C.c_uint64), ("noise_bytes", C.c_uint64), ("local_rows", C.c_uint32),
+                ("octree_depth", C.c_uint32), ("octree_nodes", C.c_uint64)]
+
+
+class Camera:
+    """Camera, src/camera.rs:5-9.  Default = the reference's start camera, src/context.rs:618-622."""
+
+    def __init__(self, position=(0.0, 0.0, -2.0), direction=(0.0, 0.0, 1.0),
+                 fov=float(np.float32(70.0) * (np.float32(np.pi) / np.float32(180.0)))):
+        self.position = np.asarray(position, np.float32)
+        self.direction = np.asarray(direction, np.float32)
+        self.fov = float(np.float32(fov))
+
+    def axis_scaled(self, width, height):
+        """Camera::axis_scaled (src/camera.rs:19-28), evaluated by the library's host code."""
+        r, u, f = (np.zeros(3, np.float32) for _ in range(3))
+        _check(lib().vxrt_camera_axis_scaled(_p(self.position), _p(self.direction), C.c_float(self.fov),
+                                             C.c_uint32(width), C.c_uint32(height), _p(r), _p(u), _p(f)),
+               "vxrt_camera_axis_scaled")
+        return r, u, f
+
+
+def lib():
+    """Load libvxrt.so (building it with hipcc first if it is stale or missing)."""
+    global _LIB
+    if _LIB is None:
+        path = _build.LIB
+        if not os.path.exists(path):
+            path = _build.build()
+        L = C.CDLL(path)
+        L.vxrt_last_error.restype = C.c_char_p
+        L.vxrt_status_string.restype = C.c_char_p
+        L.vxrt_abi_version.restype = C.c_uint32
+        L.vxrt_status_string.argtypes = [C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _check(status, where):
+    if status != 0:
+        raise VxrtError(status, where, (lib().vxrt_last_error() or b"").decode(errors="replace"))
+
+
+# ---- host-only helpers (no GPU needed) -------------------------------------------------------------------
+def vox_to_voxels(data: bytes):
+    """vox::parse + Context::voxels_from_vox -> (pos int16[n,3], mrgb uint8[n,4], (sx,sy,sz))."""
+    buf = np.frombuffer(data, np.uint8)
+    n = C.c_size_t(0)
+    size = np.zeros(3, np.uint32)
+    _check(lib().vxrt_vox_to_voxels(_p(buf), C.c_size_t(len(data)), None, None, C.c_size_t(0), C.byref(n), _p(size)),
+           "vxrt_vox_to_voxels")
+    pos = np.zeros((n.value, 3), np.int16)
+    mrgb = np.zeros((n.value, 4), np.uint8)
+    _check(lib().vxrt_vox_to_voxels(_p(buf), C.c_size_t(len(data)), _p(pos), _p(mrgb), C.c_size_t(n.value),
+                                    C.byref(n), _p(size)), "vxrt_vox_to_voxels")
+    return pos, mrgb, tuple(int(s) for s in size)
+
+
+def build_octree(pos, mrgb):
+    """Context::create_octree -> (int32 words, depth)."""
+    pos = np.ascontiguousarray(pos, np.int16)
+    mrgb = np.ascontiguousarray(mrgb, np.uint8)
+    n = C.c_size_t(0)
+    depth = C.c_uint32(0)
+    _check(lib().vxrt_build_octree(_p(pos), _p(mrgb), C.c_size_t(len(pos)), None, C.c_size_t(0), C.byref(n),
+                                   C.byref(depth)), "vxrt_build_octree")
+    words = np.zeros(n.value, np.int32)
+    _check(lib().vxrt_build_octree(_p(pos), _p(mrgb), C.c_size_t(len(pos)), _p(words), C.c_size_t(n.value),
+                                   C.byref(n), C.byref(depth)), "vxrt_build_octree")
+    return words, int(depth.value)
+
+
+def noise_table(seed=DEFAULT_NOISE_SEED, n=NOISE_LEN):
+    out = np.zeros(n, np.float32)
+    _check(lib().vxrt_noise_table(C.c_uint32(seed), _p(out), C.c_size_t(n)), "vxrt_noise_table")
+    return out
+
+
+def menger_voxels(level, mrgb=(0, 0xb0, 0xd0, 0x60)):
+    m = np.asarray(mrgb, np.uint8)
+    n = C.c_size_t(0)
+    _check(lib().vxrt_menger_voxels(C.c_uint32(level), _p(m), None, None, C.c_size_t(0), C.byref(n)),
+           "vxrt_menger_voxels")
+    pos = np.zeros((n.value, 3), np.int16)
+    out = np.zeros((n.value, 4), np.uint8)
+    _check(lib().vxrt_menger_voxels(C.c_uint32(level), _p(m), _p(pos), _p(out), C.c_size_t(n.value), C.byref(n)),
+           "vxrt_menger_voxels")
+    return pos, out
+
+
+def detmath_probe(fn, x, y=None, device=0):
+    names = {"sin": 0, "cos": 1, "exp": 2, "log": 3, "pow": 4, "sqrt": 5, "div": 6, "tan": 7, "chain": 8}
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), np.float32)
+    out = np.zeros_like(x)
+    _check(lib().vxrt_detmath_probe(C.c_int32(device), C.c_int32(names[fn]), _p(x), _p(y), _p(out),
+                                    C.c_size_t(x.size)), "vxrt_detmath_probe")
+    return out
+
+
+class Context:
+    """The render context: what `Context` is in the reference (src/context.rs:198-268), minus the window.
+
+    One context = one GPU.  `rank`/`nranks` make it render only its interleaved row bands of the frame.
+    """
+
+    def __init__(self, width, height, device=0, max_bounces=3, noise=None, noise_seed=DEFAULT_NOISE_SEED, rank=0,
+                 nranks=1, band_rows=16):
+        self._h = C.c_void_p()
+        self.width, self.height = int(width), int(height)
+        self.camera = Camera()
+        cfg = Config(self.width, self.height, int(device), int(max_bounces), int(noise_seed), None, int(rank),
+                     int(nranks), int(band_rows))
+        keep = None
+        if noise is not None:
+            keep = np.ascontiguousarray(noise, np.float32)
+            if keep.size != NOISE_LEN:
+                raise ValueError("noise table must hold 512*128*128 floats")
+            cfg.noise = keep.ctypes.data
+        _check(lib().vxrt_create(C.byref(cfg), C.byref(self._h)), "vxrt_create")
+        self.uniforms = Uniforms.default()
+        self.temporal_uniforms = TemporalUniforms.default()
+        self.denoise_uniforms = DenoiseUniforms.default()
+
+    # -- lifetime ------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().vxrt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- scene ---------------------------------------------------------------------------------------
+    def recreate_octree(self, pos, mrgb):
+        """Context::recreate_octree(voxels): voxels as (position [i16;3], [material, r, g, b])."""
+        pos = np.ascontiguousarray(pos, np.int16)
+        mrgb = np.ascontiguousarray(mrgb, np.uint8)
+        if pos.shape != (len(pos), 3) or mrgb.shape != (len(pos), 4):
+            raise ValueError("pos must be [n,3] int16 and mrgb [n,4] uint8")
+        _check(lib().vxrt_set_voxels(self._h, _p(pos), _p(mrgb), C.c_size_t(len(pos))), "vxrt_set_voxels")
+
+    def load_vox(self, path):
+        _check(lib().vxrt_load_vox(self._h, os.fsencode(path)), "vxrt_load_vox")
+
+    def load_vox_bytes(self, data: bytes):
+        buf = np.frombuffer(data, np.uint8)
+        _check(lib().vxrt_load_vox_memory(self._h, _p(buf), C.c_size_t(len(data))), "vxrt_load_vox_memory")
+
+    # -- frame ---------------------------------------------------------------------------------------
+    def resize(self, width, height):
+        _check(lib().vxrt_resize(self._h, C.c_uint32(width), C.c_uint32(height)), "vxrt_resize")
+        self.width, self.height = int(width), int(height)
+
+    def update_bindings(self):
+        """Push camera + parameter blocks (Context::update_bindings, src/context.rs:2136-2162)."""
+        cam = self.camera
+        _check(lib().vxrt_set_camera(self._h, _p(np.asarray(cam.position, np.float32)),
+                                     _p(np.asarray(cam.direction, np.float32)), C.c_float(cam.fov)), "vxrt_set_camera")
+        _check(lib().vxrt_set_scene_params(self._h, C.byref(self.uniforms)), "vxrt_set_scene_params")
+        _check(lib().vxrt_set_temporal(self._h, C.byref(self.temporal_uniforms)), "vxrt_set_temporal")
+        _check(lib().vxrt_set_denoise(self._h, C.byref(self.denoise_uniforms)), "vxrt_set_denoise")
+
+    def render(self, flags=ALL):
+        """Context::render(): frame_number += 1, voxels -> temporal -> denoise, history hand-over."""
+        self.update_bindings()
+        _check(lib().vxrt_render(self._h, C.c_uint32(flags)), "vxrt_render")
+
+    def render_stage(self, flags):
+        """vxrt_render without re-pushing parameters (multi-GPU: DENOISE after the halo exchange)."""
+        _check(lib().vxrt_render(self._h, C.c_uint32(flags)), "vxrt_render")
+
+    def sync(self):
+        _check(lib().vxrt_sync(self._h), "vxrt_sync")
+
+    def reset_history(self):
+        _check(lib().vxrt_reset_history(self._h), "vxrt_reset_history")
+
+    def set_frame_number(self, n):
+        _check(lib().vxrt_set_frame_number(self._h, C.c_uint32(n)), "vxrt_set_frame_number")
+
+    # -- outputs -------------------------------------------------------------------------------------
+    def local_rows(self):
+        n = C.c_uint32(0)
+        _check(lib().vxrt_local_rows(self._h, C.byref(n), None), "vxrt_local_rows")
+        rows = np.zeros(n.value, np.uint32)
+        if n.value:
+            _check(lib().vxrt_local_rows(self._h, C.byref(n), _p(rows)), "vxrt_local_rows")
+        return rows
+
+    def read(self, which):
+        """-> float32[local_rows, width, 4] (whole frame for a single-GPU context)."""
+        n = C.c_uint32(0)
+        _check(lib().vxrt_local_rows(self._h, C.byref(n), None), "vxrt_local_rows")
+        out = np.zeros((n.value, self.width, 4), np.float32)
+        _check(lib().vxrt_read(self._h, C.c_int(which), _p(out), C.c_size_t(out.nbytes)), "vxrt_read")
+        return out
+
+    def device_image(self, which):
+        ptr = C.c_void_p()
+        nbytes = C.c_size_t(0)
+        _check(lib().vxrt_device_image(self._h, C.c_int(which), C.byref(ptr), C.byref(nbytes)), "vxrt_device_image")
+        return ptr.value, nbytes.value
+
+    def stats(self):
+        s = Stats()
+        _check(lib().vxrt_get_stats(self._h, C.byref(s)), "vxrt_get_stats")
+        return s
+
+    def reset_stats(self):
+        _check(lib().vxrt_reset_stats(self._h), "vxrt_reset_stats")
+
+    # -- multi-GPU denoise halo ------------------------------------------------------------------------
+    def halo_bytes(self):
+        n = C.c_size_t(0)
+        _check(lib().vxrt_halo_bytes(self._h, C.byref(n)), "vxrt_halo_bytes")
+        return n.value
+
+    def halo_export(self, dev_to_prev, dev_to_next):
+        _check(lib().vxrt_halo_export(self._h, C.c_void_p(dev_to_prev), C.c_void_p(dev_to_next)), "vxrt_halo_export")
+
+    def halo_import(self, dev_from_prev, dev_from_next):
+        _check(lib().vxrt_halo_import(self._h, C.c_void_p(dev_from_prev), C.c_void_p(dev_from_next)),
+               "vxrt_halo_import")

@@ -1,0 +1,209 @@
+/*
+ * vxrt.h — C ABI of the MI355X-native voxel path tracer (libvxrt.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of nolanderc/gpu-voxel-raytracer:
+ *   shaders/voxels.comp -> shaders/temporal.comp -> shaders/denoise.comp,
+ * plus the scene/camera preparation that feeds them.  The reference has no FFI for this path; its
+ * boundary is the set of wgpu calls `Context` makes (src/context.rs).  Each entry point below names
+ * the reference call site it replaces, so that a host (the reference's Rust `Context`, or any other)
+ * can bind it one-for-one — see INTEGRATION.md for the `extern "C"` block a Rust maintainer would add.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 (VXRT_OK) or a negative
+ * vxrt_status; nothing throws or aborts across the boundary; host pointers are borrowed for the
+ * duration of the call only; a context owns all of its device memory.  A context is bound to one GPU
+ * and is not thread-safe; distinct contexts are independent (the reference renders from a single
+ * thread, src/main.rs:34-38).  Multi-GPU = one process and one context per GPU, each rendering its
+ * share of the frame's rows (vxrt_config.rank / nranks / band_rows).
+ */
+#ifndef VXRT_H
+#define VXRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vxrt_ctx vxrt_ctx;
+
+typedef enum vxrt_status {
+    VXRT_OK = 0,
+    VXRT_E_INVALID = -1,      /* bad argument (null pointer, zero size, bad enum, size mismatch)      */
+    VXRT_E_DEVICE = -2,       /* HIP runtime error (no device, allocation, launch); see vxrt_last_error */
+    VXRT_E_VOX_MAGIC = -10,   /* "invalid magic number"               src/vox.rs:12-14                */
+    VXRT_E_VOX_VERSION = -11, /* "unsupported VOX-format: version N"  src/vox.rs:17-19                */
+    VXRT_E_VOX_NOMAIN = -12,  /* "missing MAIN chunk"                 src/vox.rs:21                   */
+    VXRT_E_VOX_EOF = -13,     /* "unexpected end of file"             src/vox.rs:262-283              */
+    VXRT_E_VOX_CHUNK = -14,   /* "expected chunk X, found chunk Y"    src/vox.rs:230-241              */
+    VXRT_E_VOX_MATERIAL = -15,/* unsupported _type / unparsable _flux src/vox.rs:82-96                */
+    VXRT_E_VOX_NOMATL = -16,  /* colour index without a MATL entry (the reference panics) src/context.rs:919 */
+    VXRT_E_VOX_NOMODEL = -17, /* file holds no model                  src/context.rs:916              */
+    VXRT_E_IO = -18,          /* "failed to read file"                src/vox.rs:7                    */
+    VXRT_E_SCENE = -20,       /* voxel list cannot be represented (leaf split, src/context.rs:746; depth > 15;
+                                 too many nodes)                                                       */
+    VXRT_E_NOSCENE = -21      /* render called before any scene was set                               */
+} vxrt_status;
+
+/* Uniforms — src/context.rs:425-469, std140 layout of shaders/voxels.comp:28-49 (148 bytes, same
+ * offsets: a Rust `Uniforms` can be passed as is).  Fields the kernels never read (light,
+ * global_time, still_sample) are carried for layout compatibility only.  The camera_* fields and
+ * frame_number are overwritten by the library (vxrt_set_camera / vxrt_render), exactly as
+ * Context::update_bindings does (src/context.rs:2145-2154). */
+typedef struct vxrt_uniforms {
+    float camera_origin[4];
+    float camera_right[4];
+    float camera_up[4];
+    float camera_forward[4];
+    float light[4];
+    float global_time;
+    uint32_t still_sample;
+    uint32_t frame_number;
+    float emit_strength;
+    float sun_strength;
+    float sun_size;
+    float sun_yaw;
+    float sun_pitch;
+    float sun_color[4];
+    float sky_color[4];
+    float specularity;
+} vxrt_uniforms;
+
+/* TemporalUniforms — src/context.rs:502-515.  Defaults {0.5, 0.98, 1e-2} (:517-525). */
+typedef struct vxrt_temporal {
+    float sample_blending;
+    float maximum_blending;
+    float blending_distance_cutoff;
+} vxrt_temporal;
+
+/* DenoiseUniforms — src/context.rs:304-314.  Defaults {0, 2.0, 1.5, 1.0} (:316-325); radius 0..8
+ * (GUI range, src/context.rs:1791). */
+typedef struct vxrt_denoise {
+    uint32_t radius;
+    float sigma_distance;
+    float sigma_range;
+    float albedo_factor;
+} vxrt_denoise;
+
+typedef struct vxrt_config {
+    uint32_t width, height;   /* full frame size in pixels                                              */
+    int32_t device;           /* HIP device ordinal                                                     */
+    uint32_t max_bounces;     /* MAX_BOUNCES of shaders/voxels.comp:4 (reference: 3); 1..16             */
+    uint32_t noise_seed;      /* seed of the generated noise table when `noise` is NULL                 */
+    const float* noise;       /* optional 512*128*128 floats in [0,1) (layout of shaders/voxels.comp:65-71) */
+    uint32_t rank, nranks;    /* this context renders the row bands b with b % nranks == rank ...       */
+    uint32_t band_rows;       /* ... where band b = rows [b*band_rows, (b+1)*band_rows); 0 -> 16.       */
+                              /* nranks = 0 or 1 -> the whole frame                                     */
+} vxrt_config;
+
+typedef enum vxrt_image {
+    VXRT_SAMPLED_COLOR = 0,   /* voxels.comp binding 0: (rgb, 1)                                        */
+    VXRT_NORMAL_DEPTH = 1,    /* voxels.comp binding 1: (normal, t); miss = (2^30,2^30,2^30,-1)         */
+    VXRT_ALBEDO_NODE = 2,     /* voxels.comp binding 2: (albedo, bits(leaf word))                       */
+    VXRT_ACCUM_COLOR = 3,     /* temporal.comp binding 3: (blended rgb, next blending)                  */
+    VXRT_DENOISED = 4         /* denoise.comp binding 0: (rgb, 1) — what the reference displays         */
+} vxrt_image;
+
+enum {                        /* vxrt_render flags: which of the three dispatches of                    */
+    VXRT_TRACE = 1,           /* Context::render (src/context.rs:2024-2037) to run                      */
+    VXRT_TEMPORAL = 2,
+    VXRT_DENOISE = 4,
+    VXRT_ALL = 7,
+    VXRT_TIMED = 8            /* bracket every kernel with HIP events (read back through vxrt_get_stats) */
+};
+
+typedef struct vxrt_stats {
+    uint64_t frames;          /* frames rendered since create / reset                                   */
+    uint64_t rays;            /* cast_bounded_ray invocations (primary + bounce + sun) in those frames  */
+    uint64_t pixels;          /* pixels traced (this context's rows) in those frames                    */
+    double trace_ms;          /* summed kernel time of VXRT_TIMED frames, per stage                     */
+    double temporal_ms;
+    double denoise_ms;
+    uint64_t timed_frames;
+    uint64_t scene_bytes;     /* device bytes of the scene (octree) and of the noise table              */
+    uint64_t noise_bytes;
+    uint32_t local_rows;      /* rows owned by this context                                             */
+    uint32_t octree_depth;
+    uint64_t octree_nodes;
+} vxrt_stats;
+
+/* ---- context: replaces Context::new / create_bindings / resize (src/context.rs:595-660, 936-1016,
+ *      1430-1461).  resize drops the temporal history like the reference (:1440-1448). -------------- */
+int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out);
+int vxrt_destroy(vxrt_ctx* ctx);
+int vxrt_resize(vxrt_ctx* ctx, uint32_t width, uint32_t height);
+
+/* ---- scene: replaces Context::recreate_octree (src/context.rs:799-810); input is the reference's
+ *      Vec<([i16;3],[u8;4])> (position, [material, r, g, b]).  Resets the temporal history. -------- */
+int vxrt_set_voxels(vxrt_ctx* ctx, const int16_t (*pos)[3], const uint8_t (*mrgb)[4], size_t n);
+/* vox::load + Context::voxels_from_vox + recreate_octree (src/context.rs:1817-1821). */
+int vxrt_load_vox(vxrt_ctx* ctx, const char* path);
+int vxrt_load_vox_memory(vxrt_ctx* ctx, const uint8_t* bytes, size_t len);
+
+/* ---- per-frame parameters: replaces Context::update_bindings (src/context.rs:2136-2162). ---------- */
+/* Camera{position, direction, fov} (src/camera.rs:5-9); the library applies Camera::axis_scaled. */
+int vxrt_set_camera(vxrt_ctx* ctx, const float position[3], const float direction[3], float fov);
+int vxrt_set_scene_params(vxrt_ctx* ctx, const vxrt_uniforms* u);
+int vxrt_set_temporal(vxrt_ctx* ctx, const vxrt_temporal* t);
+int vxrt_set_denoise(vxrt_ctx* ctx, const vxrt_denoise* d);
+void vxrt_default_uniforms(vxrt_uniforms* u);   /* Uniforms::default(),          src/context.rs:471-498 */
+void vxrt_default_temporal(vxrt_temporal* t);   /* TemporalUniforms::default(),  src/context.rs:517-525 */
+void vxrt_default_denoise(vxrt_denoise* d);     /* DenoiseUniforms::default(),   src/context.rs:316-325 */
+
+/* ---- frame: replaces Context::render (src/context.rs:2004-2075).  frame_number is incremented
+ *      first (:2152), the selected stages run in the reference's order, then the G-buffer history
+ *      is handed over (ping-pong instead of the copy at :2041-2043).  Asynchronous. ---------------- */
+int vxrt_render(vxrt_ctx* ctx, uint32_t flags);
+int vxrt_sync(vxrt_ctx* ctx);
+int vxrt_reset_history(vxrt_ctx* ctx);          /* still_sample = 0 path, src/context.rs:1424 */
+int vxrt_set_frame_number(vxrt_ctx* ctx, uint32_t frame_number); /* next render uses frame_number+1 */
+
+/* ---- outputs.  The reference only blits denoised_color (src/context.rs:1131-1136); every image is
+ *      readable here.  dst receives this context's rows in ascending frame-row order, rgba32f,
+ *      local_rows*width*16 bytes (vxrt_local_rows; = height for a single-GPU context). ------------ */
+int vxrt_read(vxrt_ctx* ctx, vxrt_image which, float* dst, size_t bytes);
+int vxrt_local_rows(const vxrt_ctx* ctx, uint32_t* count, uint32_t* rows /* optional: count entries */);
+/* Device pointer of an image (local rows, rgba32f) for zero-copy consumers on the same GPU. */
+int vxrt_device_image(vxrt_ctx* ctx, vxrt_image which, void** device_ptr, size_t* bytes);
+int vxrt_get_stats(vxrt_ctx* ctx, vxrt_stats* out);
+int vxrt_reset_stats(vxrt_ctx* ctx);
+
+/* ---- denoise halo for multi-GPU: the (2r+1)^2 window of denoise.comp:51-57 reaches
+ *      r rows into the neighbouring bands, which live on other GPUs.  export packs, for every band
+ *      edge of this context, the r boundary rows of (accumulated colour, normal/depth, albedo/node);
+ *      import takes the rows that lie just outside this context's bands.  Buffers are DEVICE memory
+ *      (the caller moves them with RCCL send/recv).  Layout: see DESIGN.md "halo". ------------------ */
+int vxrt_halo_bytes(vxrt_ctx* ctx, size_t* bytes_per_neighbour);
+int vxrt_halo_export(vxrt_ctx* ctx, void* dev_to_prev, void* dev_to_next);
+int vxrt_halo_import(vxrt_ctx* ctx, const void* dev_from_prev, const void* dev_from_next);
+
+/* ---- host-side scene preparation, callable without a GPU (src/vox.rs, src/context.rs:710-834,
+ *      913-933, src/camera.rs).  Counts are returned through *n; nothing is written past cap. ------ */
+int vxrt_vox_to_voxels(const uint8_t* bytes, size_t len, int16_t (*pos)[3], uint8_t (*mrgb)[4], size_t cap,
+                       size_t* n, uint32_t size_xyz[3]);
+int vxrt_build_octree(const int16_t (*pos)[3], const uint8_t (*mrgb)[4], size_t n, int32_t* words, size_t cap,
+                      size_t* n_words, uint32_t* depth);
+int vxrt_camera_axis_scaled(const float position[3], const float direction[3], float fov, uint32_t width,
+                            uint32_t height, float right[3], float up[3], float forward_ray[3]);
+/* Stand-in for the blue-noise table the reference does not ship (resources/blue-noise-128.zip,
+ * .MISSING_LARGE_BLOBS): value i of seed s is  z = i*0x9E3779B9 + s;  z ^= z>>16; z *= 0x85EBCA6B;
+ * z ^= z>>13; z *= 0xC2B2AE35; z ^= z>>16;  (z >> 8) * 2^-24. */
+int vxrt_noise_table(uint32_t seed, float* out, size_t n);
+/* Procedural level-`level` Menger sponge, side 3^level voxels at the origin (config 5 generator;
+ * level 4 reproduces the voxel set of vox/menger.vox). */
+int vxrt_menger_voxels(uint32_t level, const uint8_t mrgb[4], int16_t (*pos)[3], uint8_t (*out_mrgb)[4], size_t cap,
+                       size_t* n);
+
+/* Test hook: evaluates function `fn` of include/vxrt_detmath.h on the device for host arrays x, y
+ * (0 sin, 1 cos, 2 exp, 3 log, 4 pow, 5 sqrt, 6 div, 7 tan, 8 normalize/cross/dot chain) so that the
+ * host-vs-device bit equality the numeric contract promises can be checked. */
+int vxrt_detmath_probe(int32_t device, int32_t fn, const float* x, const float* y, float* out, size_t n);
+
+const char* vxrt_status_string(int status);
+const char* vxrt_last_error(void);               /* thread-local detail of the last failing call */
+uint32_t vxrt_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VXRT_H */

@@ -1,0 +1,54 @@
+// ORACLE — test infrastructure only.  Nothing in the product path may include, link or call this.
+//
+// CPU restatement of the hot path of nolanderc/gpu-voxel-raytracer (scene prep + the three compute
+// shaders + the dead src/cpu.rs ray caster).  Parity status: UNPINNED — the reference ships no
+// tests, golden vectors or runnable build for this path; the restatement is pinned
+// by review, by the Appendix-C node-count table and by an independent dense-grid DDA (odda.cpp).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+#include "ovec.h"
+
+enum {
+    ORC_E_MAGIC = -1,     // "invalid magic number"            src/vox.rs:12-14
+    ORC_E_VERSION = -2,   // "unsupported VOX-format"          src/vox.rs:17-19
+    ORC_E_NOMAIN = -3,    // "missing MAIN chunk"              src/vox.rs:21
+    ORC_E_EOF = -4,       // "unexpected end of file"          src/vox.rs:262-283
+    ORC_E_CHUNK = -5,     // "expected chunk X, found chunk Y" src/vox.rs:230-241
+    ORC_E_MATERIAL = -6,  // unsupported material / bad _flux  src/vox.rs:82-96
+    ORC_E_NOMATL = -7,    // voxels_from_vox .unwrap() panic   src/context.rs:919
+    ORC_E_NOMODEL = -8,   // models[0] out of bounds           src/context.rs:916
+    ORC_E_SPLITLEAF = -9, // todo!("split leaf ...")           src/context.rs:746
+};
+
+// Uniforms (src/context.rs:425-469), std140 offsets as in shaders/voxels.comp:28-49 — 148 bytes.
+struct OrcUniforms {
+    float camera_origin[4];
+    float camera_right[4];
+    float camera_up[4];
+    float camera_forward[4];
+    float light[4];
+    float global_time;
+    uint32_t still_sample;
+    uint32_t frame_number;
+    float emit_strength;
+    float sun_strength;
+    float sun_size;
+    float sun_yaw;
+    float sun_pitch;
+    float sun_color[4];
+    float sky_color[4];
+    float specularity;
+};
+static_assert(sizeof(OrcUniforms) == 148, "Uniforms must be 148 bytes");
+
+// TemporalUniforms (src/context.rs:502-515), DenoiseUniforms (src/context.rs:304-314).
+struct OrcTemporal { float sample_blending, maximum_blending, blending_distance_cutoff; };
+struct OrcDenoise { uint32_t radius; float sigma_distance, sigma_range, albedo_factor; };
+
+namespace orc {
+struct Hit { float time; int32_t node; V3 normal; int iterations; };
+// cast_bounded_ray (shaders/voxels.comp:134-247) on a reference-layout octree buffer.
+bool cast_bounded_ray(const int32_t* octree, V3 origin, V3 dir, float max_distance, Hit* hit);
+}  // namespace orc

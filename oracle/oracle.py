@@ -1,0 +1,241 @@
+"""ORACLE — test infrastructure only.
+
+ctypes front end of oracle/_build/liboracle.so, the CPU restatement of the reference's hot path
+(see oracle.h).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the product package never does.  Parity status: UNPINNED by the reference.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+_lib = None
+
+NOISE_LEN = 512 * 128 * 128
+NOISE_SEED = 0x5EED0001
+
+
+def build(force=False):
+    """Compile the oracle with g++ (make).  Building the checker is not using it."""
+    subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+class Uniforms(C.Structure):
+    """Uniforms, src/context.rs:425-469 (148 bytes, std140 offsets of shaders/voxels.comp:28-49)."""
+    _fields_ = [
+        ("camera_origin", C.c_float * 4), ("camera_right", C.c_float * 4), ("camera_up", C.c_float * 4),
+        ("camera_forward", C.c_float * 4), ("light", C.c_float * 4), ("global_time", C.c_float),
+        ("still_sample", C.c_uint32), ("frame_number", C.c_uint32), ("emit_strength", C.c_float),
+        ("sun_strength", C.c_float), ("sun_size", C.c_float), ("sun_yaw", C.c_float), ("sun_pitch", C.c_float),
+        ("sun_color", C.c_float * 4), ("sky_color", C.c_float * 4), ("specularity", C.c_float),
+    ]
+
+    @classmethod
+    def default(cls):
+        """Uniforms::default(), src/context.rs:471-498."""
+        u = cls()
+        u.emit_strength, u.sun_strength, u.sun_size = 4.0, 4.0, 0.05
+        u.sun_yaw, u.sun_pitch = 1.32, 1.0
+        u.sun_color[:] = [1.0, 1.0, 1.0, 0.0]
+        u.sky_color[:] = [0.45, 0.6, 0.65, 0.0]
+        u.specularity = 0.0
+        return u
+
+    def set_camera(self, position, basis9):
+        self.camera_origin[:] = [float(v) for v in position] + [0.0]
+        self.camera_right[:] = [float(v) for v in basis9[0:3]] + [0.0]
+        self.camera_up[:] = [float(v) for v in basis9[3:6]] + [0.0]
+        self.camera_forward[:] = [float(v) for v in basis9[6:9]] + [0.0]
+
+    def camera16(self):
+        return np.array(list(self.camera_origin) + list(self.camera_right) + list(self.camera_up)
+                        + list(self.camera_forward), dtype=np.float32)
+
+
+assert C.sizeof(Uniforms) == 148
+
+
+class Temporal(C.Structure):
+    """TemporalUniforms, src/context.rs:502-525."""
+    _fields_ = [("sample_blending", C.c_float), ("maximum_blending", C.c_float),
+                ("blending_distance_cutoff", C.c_float)]
+
+    @classmethod
+    def default(cls):
+        return cls(0.5, 0.98, 1e-2)
+
+
+class Denoise(C.Structure):
+    """DenoiseUniforms, src/context.rs:304-325."""
+    _fields_ = [("radius", C.c_uint32), ("sigma_distance", C.c_float), ("sigma_range", C.c_float),
+                ("albedo_factor", C.c_float)]
+
+    @classmethod
+    def default(cls):
+        return cls(0, 2.0, 1.5, 1.0)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_voxels_from_vox.restype = C.c_long
+        _lib.orc_create_octree.restype = C.c_long
+        _lib.orc_trace.restype = C.c_longlong
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class OracleError(RuntimeError):
+    def __init__(self, code):
+        super().__init__(f"oracle error {code}")
+        self.code = code
+
+
+def voxels_from_vox(data: bytes):
+    """vox::parse + Context::voxels_from_vox -> (pos int16[n,3], mrgb uint8[n,4], size(x,y,z))."""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    size = np.zeros(3, np.uint32)
+    n = lib().orc_voxels_from_vox(_p(buf), C.c_size_t(len(data)), None, None, C.c_size_t(0), _p(size))
+    if n < 0:
+        raise OracleError(n)
+    pos = np.zeros((n, 3), np.int16)
+    mrgb = np.zeros((n, 4), np.uint8)
+    lib().orc_voxels_from_vox(_p(buf), C.c_size_t(len(data)), _p(pos), _p(mrgb), C.c_size_t(n), _p(size))
+    return pos, mrgb, tuple(int(s) for s in size)
+
+
+def default_palette():
+    out = np.zeros(256, np.uint32)
+    lib().orc_default_palette(_p(out))
+    return out
+
+
+def voxel_depth(pos):
+    pos = np.ascontiguousarray(pos, np.int16)
+    return lib().orc_voxel_depth(_p(pos), C.c_size_t(len(pos)))
+
+
+def create_octree(pos, mrgb):
+    """Context::create_octree -> int32 buffer (5-word header + 8 words per node)."""
+    pos = np.ascontiguousarray(pos, np.int16)
+    mrgb = np.ascontiguousarray(mrgb, np.uint8)
+    n = lib().orc_create_octree(_p(pos), _p(mrgb), C.c_size_t(len(pos)), None, C.c_size_t(0))
+    if n < 0:
+        raise OracleError(n)
+    out = np.zeros(n, np.int32)
+    lib().orc_create_octree(_p(pos), _p(mrgb), C.c_size_t(len(pos)), _p(out), C.c_size_t(n))
+    return out
+
+
+def camera_axis_scaled(position, direction, fov, width, height):
+    """Camera::axis_scaled -> float32[9] = right, up, forward_ray."""
+    out = np.zeros(9, np.float32)
+    pos = np.asarray(position, np.float32)
+    d = np.asarray(direction, np.float32)
+    lib().orc_camera_axis_scaled(_p(pos), _p(d), C.c_float(fov), C.c_uint32(width), C.c_uint32(height), _p(out))
+    return out
+
+
+def noise_table(seed=NOISE_SEED, n=NOISE_LEN):
+    out = np.zeros(n, np.float32)
+    lib().orc_noise_table(C.c_uint32(seed), _p(out), C.c_size_t(n))
+    return out
+
+
+def trace(octree, noise, uniforms, width, height, max_bounces=3, crop=None, nthreads=None):
+    """voxels.comp over crop=(x0,y0,x1,y1) of a width x height frame.
+    Returns (color, normal_depth, albedo) float32[h,w,4] and the ray count."""
+    del width, height  # pixel coordinates are frame-absolute; the frame size only enters via the camera basis
+    x0, y0, x1, y1 = crop
+    h, w = y1 - y0, x1 - x0
+    color = np.zeros((h, w, 4), np.float32)
+    nd = np.zeros((h, w, 4), np.float32)
+    alb = np.zeros((h, w, 4), np.float32)
+    nthreads = nthreads or os.cpu_count() or 1
+    rays = lib().orc_trace(_p(octree), _p(noise), C.byref(uniforms), C.c_int(max_bounces), C.c_int(x0), C.c_int(y0),
+                           C.c_int(x1), C.c_int(y1), _p(color), _p(nd), _p(alb), C.c_int(nthreads))
+    return color, nd, alb, int(rays)
+
+
+def cast_rays(octree, origins, dirs, max_distance=float(1 << 30)):
+    origins = np.ascontiguousarray(origins, np.float32)
+    dirs = np.ascontiguousarray(dirs, np.float32)
+    n = len(origins)
+    hit = np.zeros(n, np.uint8)
+    time = np.zeros(n, np.float32)
+    node = np.zeros(n, np.int32)
+    normal = np.zeros((n, 3), np.float32)
+    iters = np.zeros(n, np.int32)
+    lib().orc_cast_rays(_p(octree), _p(origins), _p(dirs), C.c_size_t(n), C.c_float(max_distance), _p(hit), _p(time),
+                        _p(node), _p(normal), _p(iters))
+    return hit.astype(bool), time, node, normal, iters
+
+
+def temporal(sampled_color, new_nd, old_color, old_nd, cam16, old_cam16, tu, has_history, nthreads=None):
+    h, w = sampled_color.shape[:2]
+    out = np.zeros((h, w, 4), np.float32)
+    nthreads = nthreads or os.cpu_count() or 1
+    args = [np.ascontiguousarray(a, np.float32) for a in (sampled_color, new_nd, old_color, old_nd, cam16, old_cam16)]
+    lib().orc_temporal(*[_p(a) for a in args], C.byref(tu), C.c_int(int(has_history)), C.c_int(w), C.c_int(h),
+                       _p(out), C.c_int(nthreads))
+    return out
+
+
+def denoise(colors, normals_depths, albedo, cam16, du, nthreads=None):
+    h, w = colors.shape[:2]
+    out = np.zeros((h, w, 4), np.float32)
+    nthreads = nthreads or os.cpu_count() or 1
+    args = [np.ascontiguousarray(a, np.float32) for a in (colors, normals_depths, albedo, cam16)]
+    lib().orc_denoise(*[_p(a) for a in args], C.byref(du), C.c_int(w), C.c_int(h), _p(out), C.c_int(nthreads))
+    return out
+
+
+def dda_cast(grid, base, origins, dirs):
+    """Independent dense-grid DDA (odda.cpp). grid uint8[nx,ny,nz], base int[3] (integer cell of grid[0,0,0])."""
+    grid = np.ascontiguousarray(grid, np.uint8)
+    dims = np.array(grid.shape, np.int32)
+    base = np.asarray(base, np.int32)
+    origins = np.ascontiguousarray(origins, np.float32)
+    dirs = np.ascontiguousarray(dirs, np.float32)
+    n = len(origins)
+    hit = np.zeros(n, np.uint8)
+    time = np.zeros(n, np.float64)
+    axis = np.zeros(n, np.int32)
+    cell = np.zeros((n, 3), np.int32)
+    lib().orc_dda_cast(_p(grid), _p(dims), _p(base), _p(origins), _p(dirs), C.c_size_t(n), _p(hit), _p(time), _p(axis),
+                       _p(cell))
+    return hit.astype(bool), time, axis, cell
+
+
+def cpu_rs_render(coords_u16, rgb_u8, cam_pos, basis9, width, height, time=0.0):
+    """CpuBackend::render (src/cpu.rs:32-72) -> (pixels u8[h,w,3], hit_time, hit_normal, hit_value)."""
+    coords = np.ascontiguousarray(coords_u16, np.uint16)
+    rgb = np.ascontiguousarray(rgb_u8, np.uint8)
+    pixels = np.zeros((height, width, 3), np.uint8)
+    ht = np.zeros((height, width), np.float32)
+    hn = np.zeros((height, width, 3), np.float32)
+    hv = np.zeros((height, width), np.int32)
+    pos = np.asarray(cam_pos, np.float32)
+    b9 = np.asarray(basis9, np.float32)
+    lib().orc_cpu_rs_render(_p(coords), _p(rgb), C.c_size_t(len(coords)), _p(pos), _p(b9), C.c_int(width),
+                            C.c_int(height), C.c_float(time), _p(pixels), _p(ht), _p(hn), _p(hv))
+    return pixels, ht, hn, hv
+
+
+def detmath(fn, x, y=None):
+    names = {"sin": 0, "cos": 1, "exp": 2, "log": 3, "pow": 4, "sqrt": 5, "div": 6, "tan": 7}
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), np.float32)
+    out = np.zeros_like(x)
+    lib().orc_detmath(C.c_int(names[fn]), _p(x), _p(y), _p(out), C.c_size_t(x.size))
+    return out

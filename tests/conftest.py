@@ -1,0 +1,66 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+REFERENCE = "/root/reference"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def O():
+    """The CPU oracle (test infrastructure).  Built on demand with g++."""
+    from oracle import oracle
+    oracle.build()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def H():
+    """The product's host layer (ctypes over libvxrt.so)."""
+    from gpu_voxel_raytracer_amd import host
+    host.lib()
+    return host
+
+
+@pytest.fixture(scope="session")
+def noise(O):
+    return O.noise_table()
+
+
+@pytest.fixture(scope="session")
+def scenes():
+    from gpu_voxel_raytracer_amd import scenes as s
+    return s
+
+
+def have_reference():
+    return os.path.isdir(os.path.join(REFERENCE, "vox"))
+
+
+needs_reference = pytest.mark.skipif(not have_reference(), reason="/root/reference not mounted (GPU box)")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_bits_equal(a, b, what=""):
+    """Bitwise equality of float images, except that +0/-0 and NaN payloads are not distinguished."""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    same = (a == b) | (np.isnan(a) & np.isnan(b))
+    if not same.all():
+        idx = np.argwhere(~same)
+        first = tuple(idx[0])
+        raise AssertionError(f"{what}: {len(idx)} of {a.size} values differ; first at {first}: {a[first]!r} vs {b[first]!r}")
