@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the vxrt hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): vox/menger.vox (81^3 Menger sponge, 160 000
+voxels; voxel-list fixture tests/golden/scenes/menger.npz), 1920x1080, 1 sample per pixel per frame,
+MAX_BOUNCES = 4, path-trace stage only (no temporal / denoise), fixed camera, Uniforms::default().
+A "step" is one frame (frame_number advances every step, so every step draws different noise).
+
+Metric: Mrays/s, where a ray is one cast_bounded_ray invocation (primary, bounce or sun shadow ray),
+counted exactly on the device.  value = rays cast by all ranks / max-over-ranks wall time of the K
+timed steps; everything the timed region touches is resident in HBM before it starts.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU; the frame's rows are dealt to the ranks in interleaved 16-row bands
+(scene and noise table replicated, no data-path collective for this stage), so total work is fixed:
+"scaling": "strong".  torch.distributed (RCCL) carries only the barrier and the time/ray reductions.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT, BOUNCES, SCENE = 1920, 1080, 4, "menger"
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(pixels, bounces, scene_bytes):
+    """48 B/px written (3 x rgba32f) + the scene once + the noise layers one frame touches
+    (8 rand() layers per bounce at most, 64 KiB each)."""
+    return 48 * pixels + scene_bytes + min(8 * bounces, 512) * 128 * 128 * 4
+
+
+def cpu_baseline(pos, mrgb, cam, target_seconds=12.0):
+    """The CPU oracle (restatement of shaders/voxels.comp, oracle/oshaders.cpp) timed on this host's cores on
+    whole frames of the same workload: a reported baseline, not the target."""
+    from oracle import oracle as O
+    O.build()
+    octree = O.create_octree(pos, mrgb)
+    noise = O.noise_table()
+    u = O.Uniforms.default()
+    u.set_camera(cam[0], O.camera_axis_scaled(cam[0], cam[1], cam[2], WIDTH, HEIGHT))
+    threads = os.cpu_count() or 1
+    rays, frames, t0 = 0, 0, time.perf_counter()
+    while True:
+        frames += 1
+        u.frame_number = frames
+        rays += O.trace(octree, noise, u, WIDTH, HEIGHT, BOUNCES, crop=(0, 0, WIDTH, HEIGHT), nthreads=threads)[3]
+        dt = time.perf_counter() - t0
+        if dt >= target_seconds or frames >= 4096:
+            break
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{frames} full {WIDTH}x{HEIGHT} frames of the same workload ({rays} rays) in {dt:.1f} s, "
+                      f"{threads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--view", default="bench", choices=["bench", "close"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from gpu_voxel_raytracer_amd import Camera, Context, TIMED, TRACE, scenes
+
+    pos, mrgb, size = scenes.load_scene(SCENE)
+    cam = scenes.bench_camera(size) if args.view == "bench" else scenes.close_camera(size)
+
+    ctx = Context(WIDTH, HEIGHT, device=local_rank, max_bounces=BOUNCES, rank=rank, nranks=world, band_rows=16)
+    ctx.recreate_octree(pos, mrgb)
+    ctx.camera = Camera(*cam)
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.render(TRACE)
+    barrier()
+    ctx.reset_stats()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.render(TRACE | TIMED)
+    ctx.sync()
+    if dist is not None:
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    st = ctx.stats()
+    rays, kernel_ms, local_px = st.rays, st.trace_ms, st.pixels // max(args.steps, 1)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        r = torch.tensor([rays], dtype=torch.int64, device="cuda")
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        rays = int(r.item())
+
+    if rank == 0:
+        launch_ms = kernel_ms / max(st.timed_frames, 1)
+        alg = algorithmic_bytes(local_px, BOUNCES, st.scene_bytes)
+        achieved = alg / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s", "value": round(rays / elapsed / 1e6, 2), "unit": "Mrays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"vox/{SCENE}.vox {WIDTH}x{HEIGHT}, 1 spp, {BOUNCES} bounces, trace stage only "
+                                   f"(BASELINE configs[1]); camera '{args.view}' of SURVEY §8d; Uniforms::default()",
+                       "parallelism": f"screen bands x{world} (16-row interleave, scene replicated)",
+                       "rays_per_frame": rays // args.steps, "rays_per_pixel": round(rays / args.steps / (WIDTH * HEIGHT), 4),
+                       "mpixels_per_s": round(WIDTH * HEIGHT * args.steps / elapsed / 1e6, 1)},
+            "roofline": {"bound": "hbm", "kernel": "trace_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "launch_ms": round(launch_ms, 4), "algorithmic_bytes_per_launch": alg},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pos, mrgb, cam)
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -39,7 +39,7 @@ __device__ __forceinline__ bool sample_bilinear(const float4* img, const BandMap
     float fx = u * float(b.width) - 0.5f, fy = v * float(b.height) - 0.5f;
     float x0f = vx_floor(fx), y0f = vx_floor(fy);
     float ax = vx_floor((fx - x0f) * 256.0f + 0.5f) / 256.0f, ay = vx_floor((fy - y0f) * 256.0f + 0.5f) / 256.0f;
-    int x0 = int(x0f), y0 = int(y0f);
+    int x0 = min(max(vx_f2i(x0f), -2), b.width), y0 = min(max(vx_f2i(y0f), -2), b.height);
     int xa = min(max(x0, 0), b.width - 1), xb = min(max(x0 + 1, 0), b.width - 1);
     int ya = min(max(y0, 0), b.height - 1), yb = min(max(y0 + 1, 0), b.height - 1);
     int la = local_row(b, ya), lb = ay == 0.0f ? la : local_row(b, yb);
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void temporal_kernel(const TemporalArgs a) {
         if (0.0f <= tu && tu <= 1.0f && 0.0f <= tv && tv <= 1.0f) {
             float4 old_nd;
             if (sample_bilinear(a.old_nd, a.band, tu, tv, old_nd)) {
-                f3 old_dir = norm3((float(int(sx + 0.5f)) * ld3(a.old_cam.r) + float(int(sy - 0.5f)) * ld3(a.old_cam.u)) + ld3(a.old_cam.f));
+                f3 old_dir = norm3((float(vx_f2i(sx + 0.5f)) * ld3(a.old_cam.r) + float(vx_f2i(sy - 0.5f)) * ld3(a.old_cam.u)) + ld3(a.old_cam.f));
                 f3 old_position = ld3(a.old_cam.o) + old_nd.w * old_dir;
                 f3 camera_dir = norm3(cam_o - world_pos);
                 float bias = vx_max(0.0f, dot3(camera_dir, normal));

@@ -41,12 +41,20 @@ VX_HD float vx_clamp(float x, float lo, float hi) { return vx_min(vx_max(x, lo),
 /* mix(x,y,a) = x*(1-a) + y*a */
 VX_HD float vx_mix(float x, float y, float a) { return x * (1.0f - a) + y * a; }
 
+/* float -> int with every input defined (C leaves NaN / out-of-range undefined; x86 and gfx950 differ). */
+VX_HD int32_t vx_f2i(float x) {
+    if (!(x == x)) return 0;
+    if (x >= 2147483648.0f) return 2147483647;
+    if (x <= -2147483648.0f) return (-2147483647 - 1);
+    return (int32_t)x;
+}
+
 VX_HD float vx_sqrt(float x) { return __builtin_sqrtf(x); }
 VX_HD float vx_floor(float x) { return __builtin_floorf(x); }
 
 /* ---- sin / cos ----------------------------------------------------------------------------
  * Cody–Waite reduction by pi/2 in three parts, then the classic degree-13/14 minimax
- * polynomials on [-pi/4, pi/4].  Meant for |x| < ~1e3 (the path feeds it sun yaw/pitch and
+ * polynomials on [-pi/4, pi/4].  Domain |x| <= 32768 (NaN outside); meant for |x| < ~1e3 (the path feeds it sun yaw/pitch and
  * phi = 2*pi*u, u in [0,1)).  Max error ~1 ulp on that range. */
 VX_HD float vx_ksin(float r) {
     float z = r * r;
@@ -67,6 +75,10 @@ VX_HD float vx_kcos(float r) {
     return (1.0f - 0.5f * z) + (z * z) * p;
 }
 VX_HD float vx_reduce_pio2(float x, int *quadrant) {
+    if (!(vx_abs(x) <= 32768.0f)) {  /* outside the supported domain (also inf, NaN): NaN, deterministically */
+        *quadrant = 0;
+        return vx_u2f(0x7fc00000u);
+    }
     float kf = vx_floor(x * 0.63661977236758134f + 0.5f);
     /* pi/2 = P1 + P2 + P3, P1 and P2 with trailing zero bits so k*P1, k*P2 are exact for |k| < 2^7 */
     float r = x - kf * 1.5707855225e+00f;     /* 0x3fc90f80 */

@@ -326,8 +326,11 @@ struct Tex {  // rgba32f image + the Linear/ClampToEdge sampler of src/context.r
         float x0 = vx_floor(fx), y0 = vx_floor(fy);
         float ax = vx_floor((fx - x0) * 256.0f + 0.5f) / 256.0f, ay = vx_floor((fy - y0) * 256.0f + 0.5f) / 256.0f;
         float t00[4], t10[4], t01[4], t11[4];
-        fetch((int)x0, (int)y0, t00); fetch((int)x0 + 1, (int)y0, t10);
-        fetch((int)x0, (int)y0 + 1, t01); fetch((int)x0 + 1, (int)y0 + 1, t11);
+        int ix0 = vx_f2i(x0), iy0 = vx_f2i(y0);
+        ix0 = ix0 > w ? w : (ix0 < -2 ? -2 : ix0);
+        iy0 = iy0 > h ? h : (iy0 < -2 ? -2 : iy0);
+        fetch(ix0, iy0, t00); fetch(ix0 + 1, iy0, t10);
+        fetch(ix0, iy0 + 1, t01); fetch(ix0 + 1, iy0 + 1, t11);
         for (int k = 0; k < 4; k++) {
             // a zero weight must not let a NaN/inf neighbour (sky normals are 2^30) through
             float top = ax == 0.0f ? t00[k] : (t00[k] * (1.0f - ax) + t10[k] * ax);
@@ -411,7 +414,7 @@ void orc_temporal(const float* sampled_color, const float* new_nd, const float* 
                     tex_nd.sample(tu_, tv_, ond);
                     float old_depth = ond[3];
                     // int(old_screen.x + 0.5), int(old_screen.y - 0.5): truncation   temporal.comp:99-103
-                    V3 old_ray_dir = normalize(((float)(int)(sx + 0.5f) * ocr + (float)(int)(sy - 0.5f) * ocu) + ocf);
+                    V3 old_ray_dir = normalize(((float)vx_f2i(sx + 0.5f) * ocr + (float)vx_f2i(sy - 0.5f) * ocu) + ocf);
                     V3 old_position = oco + old_depth * old_ray_dir;
                     V3 camera_dir = normalize(cam_o - world_pos);
                     float bias = vx_max(0.0f, dot(camera_dir, normal));
