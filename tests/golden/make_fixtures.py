@@ -12,6 +12,7 @@ What it writes and where each comes from:
   octree_kat.json      known answers for the octree builder: depth, nodes per level, total nodes, byte
                        size, emissive voxel count, sha256 of the int32 buffer.  The per-level counts
                        reproduce SURVEY.md Appendix C (computed there by an unrelated throw-away parser).
+  config1_3x3x3_256.npz  the restated src/cpu.rs image (u8) + primary-hit colours for BASELINE config 1.
   frames_<scene>.npz   small full-pipeline frames rendered BY THE ORACLE (trace -> temporal -> denoise
                        for frames 1..N): self-goldens that pin the oracle against silent change.  The
                        reference ships no golden images and cannot be executed here (no Rust / Vulkan /
@@ -105,6 +106,13 @@ def main():
         g = golden_frames(name, **kw)
         np.savez_compressed(os.path.join(OUT, f"frames_{name}.npz"), **g)
         print("frames", name, "rays/frame", g["rays"].tolist())
+
+    # BASELINE config 1: vox/3x3x3.vox, 256x256, restated src/cpu.rs at time 0 (voxel units = 2 x world units)
+    pos, mrgb, size = scenes.load_scene("3x3x3")
+    cam_pos, cam_dir, fov = scenes.bench_camera(size)
+    basis = O.camera_axis_scaled(cam_pos, cam_dir, fov, 256, 256)
+    pixels, _, _, hv = O.cpu_rs_render(pos.astype(np.uint16), mrgb[:, 1:], cam_pos * 2, basis, 256, 256, time=0.0)
+    np.savez_compressed(os.path.join(OUT, "config1_3x3x3_256.npz"), pixels=pixels, hit_value=hv)
 
 
 if __name__ == "__main__":

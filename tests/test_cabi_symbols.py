@@ -1,0 +1,57 @@
+"""CPU: libvxrt.so loads without a GPU and exports every function include/vxrt.h declares (and the
+product never links the oracle)."""
+import ctypes
+import os
+import re
+import subprocess
+
+from conftest import ROOT
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "vxrt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vxrt_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(H):
+    names = declared_functions()
+    assert len(names) >= 30 and "vxrt_render" in names and "vxrt_create" in names
+    lib = H.lib()
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert lib.vxrt_abi_version() == 1
+    assert lib.vxrt_status_string(-13) == b"unexpected end of file"
+
+
+def test_no_torch_types_and_c_linkage():
+    from gpu_voxel_raytracer_amd import _build
+    out = subprocess.run(["nm", "-D", "--defined-only", _build.LIB], capture_output=True, text=True).stdout
+    exported = [l.split()[-1] for l in out.splitlines() if " T " in l]
+    for n in declared_functions():
+        assert n in exported, n                       # unmangled => extern "C"
+    assert not any("torch" in s or "at::" in s or "c10" in s for s in exported)
+
+
+def test_product_does_not_touch_the_oracle():
+    pkg = os.path.join(ROOT, "gpu_voxel_raytracer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "liboracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+                assert not re.search(r'#include\s+"[^"]*oracle/', text), f
+    from gpu_voxel_raytracer_amd import _build
+    ldd = subprocess.run(["ldd", _build.LIB], capture_output=True, text=True).stdout
+    assert "liboracle" not in ldd
+
+
+def test_null_and_invalid_arguments_return_errors(H):
+    lib = H.lib()
+    assert lib.vxrt_create(None, None) == H.E_INVALID
+    assert lib.vxrt_render(None, 1) == H.E_INVALID
+    assert lib.vxrt_read(None, 0, None, 0) == H.E_INVALID
+    assert lib.vxrt_destroy(None) == 0
+    n = ctypes.c_size_t(0)
+    assert lib.vxrt_vox_to_voxels(None, 0, None, None, 0, ctypes.byref(n), None) == H.E_INVALID
+    assert lib.vxrt_menger_voxels(12, None, None, None, 0, ctypes.byref(n)) == H.E_INVALID

@@ -1,0 +1,92 @@
+"""GPU: the multi-GPU decomposition exercised inside ONE process on ONE device — N contexts
+with rank = 0..N-1 render their interleaved 16-row bands; stitched together they must equal the
+single-context frame bit for bit, including the denoise stage fed through the halo export/import path
+(the buffers RCCL would carry between GPUs are handed over directly here)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def hip():
+    lib = C.CDLL("libamdhip64.so")
+    lib.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    lib.hipFree.argtypes = [C.c_void_p]
+    lib.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    return lib
+
+
+@pytest.mark.parametrize("nranks,w,h,radius", [(2, 128, 80, 3), (3, 96, 100, 8), (4, 160, 72, 1), (8, 64, 200, 8), (5, 80, 40, 2)])
+def test_bands_and_halo_equal_single_context(H, scenes, noise, nranks, w, h, radius):
+    from gpu_voxel_raytracer_amd import ALL, DENOISE, TEMPORAL, TRACE, Camera, Context
+    pos, mrgb, size = scenes.load_scene("castle")
+    cam = Camera(*scenes.close_camera(size))
+    rt = hip()
+
+    def setup(ctx):
+        ctx.recreate_octree(pos, mrgb)
+        ctx.camera = cam
+        ctx.denoise_uniforms.radius = radius
+
+    with Context(w, h, max_bounces=3, noise=noise) as single:
+        setup(single)
+        ctxs = [Context(w, h, max_bounces=3, noise=noise, rank=r, nranks=nranks, band_rows=16) for r in range(nranks)]
+        try:
+            for c in ctxs:
+                setup(c)
+            rows = [c.local_rows() for c in ctxs]
+            assert sorted(np.concatenate(rows).tolist()) == list(range(h))          # a partition of the frame
+            for frame in range(3):
+                single.render(ALL)
+                for c in ctxs:
+                    c.render(TRACE | TEMPORAL)
+                # halo exchange: rank r sends its band edges to r-1 and r+1 (mod N)
+                nbytes = ctxs[0].halo_bytes()
+                bufs = {}
+                for r, c in enumerate(ctxs):
+                    p, n = C.c_void_p(), C.c_void_p()
+                    assert rt.hipMalloc(C.byref(p), nbytes) == 0 and rt.hipMalloc(C.byref(n), nbytes) == 0
+                    rt.hipMemset(p, 0xff, nbytes); rt.hipMemset(n, 0xff, nbytes)
+                    c.halo_export(p.value, n.value)
+                    bufs[r] = (p, n)
+                for r, c in enumerate(ctxs):
+                    from_prev = bufs[(r - 1) % nranks][1]      # what the previous rank addressed to its next
+                    from_next = bufs[(r + 1) % nranks][0]      # what the next rank addressed to its prev
+                    c.halo_import(from_prev.value, from_next.value)
+                    c.render_stage(DENOISE)
+                for c in ctxs:
+                    c.sync()
+                for p, n in bufs.values():
+                    rt.hipFree(p); rt.hipFree(n)
+                for img in range(5):
+                    want = single.read(img)
+                    got = np.zeros_like(want)
+                    for c, rr in zip(ctxs, rows):
+                        if len(rr):
+                            got[rr] = c.read(img)
+                    assert_bits_equal(got, want, f"image {img} frame {frame + 1} nranks {nranks}")
+            total = sum(c.stats().rays for c in ctxs)
+            assert total == single.stats().rays
+        finally:
+            for c in ctxs:
+                c.close()
+
+
+def test_multirank_denoise_without_halo_is_refused(H, scenes, noise):
+    from gpu_voxel_raytracer_amd import ALL, Camera, Context, VxrtError
+    pos, mrgb, size = scenes.load_scene("8x8x8")
+    with Context(64, 64, rank=1, nranks=2, noise=noise) as ctx:
+        ctx.recreate_octree(pos, mrgb)
+        ctx.denoise_uniforms.radius = 2
+        with pytest.raises(VxrtError):
+            ctx.render(ALL)
+        ctx.denoise_uniforms.radius = 0
+        ctx.render(ALL)                                   # radius 0 needs no neighbours
+    with pytest.raises(VxrtError):
+        Context(64, 64, rank=2, nranks=2)
+    with pytest.raises(VxrtError):
+        Context(64, 64, rank=0, nranks=2, band_rows=8)

@@ -1,0 +1,138 @@
+"""CPU: the product's host-side scene preparation (libvxrt.so, no GPU needed) against the oracle and the
+fixtures: .vox decoding + adapter (src/vox.rs, src/context.rs:913-933), octree builder
+(src/context.rs:710-834), camera basis (src/camera.rs), noise table, procedural Menger, error codes."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import REFERENCE, needs_reference
+from test_oracle_scene import KAT, chunk, make_vox, matl
+
+
+@pytest.mark.parametrize("name", sorted(KAT))
+def test_octree_builder_equals_oracle(O, H, scenes, name):
+    pos, mrgb, _ = scenes.load_scene(name)
+    words, depth = H.build_octree(pos, mrgb)
+    assert depth == KAT[name]["depth"]
+    assert np.array_equal(words, O.create_octree(pos, mrgb))       # word for word, header included
+
+
+def test_octree_builder_random_negative_coordinates(O, H):
+    rng = np.random.default_rng(5)
+    for n, lo, hi in ((1, 0, 1), (50, -8, 8), (2000, -100, 60), (500, -512, 511), (10, 0, 30000)):
+        pos = rng.integers(lo, hi, (n, 3)).astype(np.int16)
+        mrgb = rng.integers(0, 256, (n, 4)).astype(np.uint8)
+        words, depth = H.build_octree(pos, mrgb)
+        assert depth == O.voxel_depth(pos) and np.array_equal(words, O.create_octree(pos, mrgb))
+    words, depth = H.build_octree(np.zeros((0, 3), np.int16), np.zeros((0, 4), np.uint8))
+    assert depth == 0 and len(words) == 13
+
+
+def test_vox_decoder_equals_oracle_on_synthetic_files(O, H):
+    files = [make_vox(), make_vox(voxels=((1, 2, 3, 5), (7, 8, 9, 6)), matls=(5, 6), emit=(6,)),
+             make_vox(voxels=((0, 0, 0, 1), (0, 0, 1, 2), (0, 0, 2, 255)), rgba=False, matls=(1, 2, 255)),
+             make_vox(pack=2, extra=chunk(b"nTRN", b"\x01\x02\x03") + chunk(b"LAYR", b"", b"zz")),
+             make_vox(voxels=())]
+    for data in files:
+        p1, m1, s1 = H.vox_to_voxels(data)
+        p2, m2, s2 = O.voxels_from_vox(data)
+        assert s1 == s2 and np.array_equal(p1, p2) and np.array_equal(m1, m2)
+
+
+def test_vox_decoder_error_codes(H):
+    good = make_vox()
+
+    def code(data):
+        with pytest.raises(H.VxrtError) as e:
+            H.vox_to_voxels(data)
+        return e.value.status
+
+    hdr = b"VOX " + struct.pack("<i", 150)
+    empty_model = chunk(b"SIZE", struct.pack("<III", 1, 1, 1)) + chunk(b"XYZI", struct.pack("<I", 0))
+    assert code(b"VOXX" + good[4:]) == H.E_VOX_MAGIC
+    assert code(make_vox(version=200)) == H.E_VOX_VERSION
+    assert code(hdr + chunk(b"PACK")) == H.E_VOX_NOMAIN
+    assert code(good[:30]) == H.E_VOX_EOF and code(good[:-3]) == H.E_VOX_EOF
+    assert code(hdr + chunk(b"MAIN", b"", chunk(b"XYZI", struct.pack("<I", 0)))) == H.E_VOX_CHUNK
+    assert code(hdr + chunk(b"MAIN", b"", empty_model + matl(1, _type="_glass"))) == H.E_VOX_MATERIAL
+    assert code(hdr + chunk(b"MAIN", b"", empty_model + matl(1, _flux="abc"))) == H.E_VOX_MATERIAL
+    assert code(make_vox(matls=())) == H.E_VOX_NOMATL
+    assert b"MATL" in H.lib().vxrt_last_error() or b"material" in H.lib().vxrt_last_error().lower()
+    # a chunk whose two u32 sizes overflow when added is rejected, not wrapped
+    evil = hdr + b"MAIN" + struct.pack("<II", 0xfffffff0, 0x20) + b"\0" * 64
+    assert code(evil) == H.E_VOX_EOF
+
+
+@needs_reference
+def test_vox_decoder_equals_oracle_on_every_reference_scene(O, H):
+    for f in sorted(os.listdir(os.path.join(REFERENCE, "vox"))):
+        data = open(os.path.join(REFERENCE, "vox", f), "rb").read()
+        p1, m1, s1 = H.vox_to_voxels(data)
+        p2, m2, s2 = O.voxels_from_vox(data)
+        assert s1 == s2 and np.array_equal(p1, p2) and np.array_equal(m1, m2), f
+
+
+def test_camera_basis_equals_oracle(O, H):
+    from gpu_voxel_raytracer_amd import Camera
+    rng = np.random.default_rng(11)
+    for _ in range(200):
+        pos = rng.normal(size=3).astype(np.float32) * 30
+        d = rng.normal(size=3).astype(np.float32)
+        fov = float(np.float32(rng.uniform(0.3, 2.5)))
+        w, h = int(rng.integers(16, 4000)), int(rng.integers(16, 2200))
+        r, u, f = Camera(pos, d, fov).axis_scaled(w, h)
+        assert np.array_equal(np.concatenate([r, u, f]), O.camera_axis_scaled(pos, d, fov, w, h))
+
+
+def test_noise_table_spec(O, H):
+    a = H.noise_table(0x5EED0001, 1 << 16)
+    assert np.array_equal(a, O.noise_table(0x5EED0001, 1 << 16))
+    # the documented generator (include/vxrt.h), third implementation in numpy
+    i = np.arange(1 << 16, dtype=np.uint32)
+    z = i * np.uint32(0x9E3779B9) + np.uint32(0x5EED0001)
+    z ^= z >> np.uint32(16); z *= np.uint32(0x85EBCA6B); z ^= z >> np.uint32(13); z *= np.uint32(0xC2B2AE35); z ^= z >> np.uint32(16)
+    assert np.array_equal(a, (z >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24))
+    full = H.noise_table()
+    assert full.size == 512 * 128 * 128 and full.min() >= 0 and full.max() < 1 and abs(full.mean() - 0.5) < 1e-3
+    assert not np.array_equal(H.noise_table(1, 64), H.noise_table(2, 64))
+
+
+def test_menger_generator(H, scenes):
+    pos, mrgb, _ = scenes.load_scene("menger")
+    gp, gm = H.menger_voxels(4, mrgb[0])
+    assert len(gp) == 20 ** 4 == len(pos)
+    assert set(map(tuple, gp.tolist())) == set(map(tuple, pos.tolist()))   # same voxel set as vox/menger.vox
+    assert (gm == mrgb[0]).all()
+    for level, n in ((0, 1), (1, 20), (2, 400), (3, 8000)):
+        assert len(H.menger_voxels(level)[0]) == n
+
+
+def test_defaults_match_reference_values(H):
+    u, t, d = H.Uniforms.default(), H.TemporalUniforms.default(), H.DenoiseUniforms.default()
+    f = np.float32
+    assert (u.emit_strength, u.sun_strength, f(u.sun_size), f(u.sun_yaw), u.sun_pitch) == (4.0, 4.0, f(0.05), f(1.32), 1.0)
+    assert list(u.sun_color)[:3] == [1, 1, 1] and [f(v) for v in list(u.sky_color)[:3]] == [f(0.45), f(0.6), f(0.65)]
+    assert u.specularity == 0 and u.frame_number == 0
+    assert (f(t.sample_blending), f(t.maximum_blending), f(t.blending_distance_cutoff)) == (f(0.5), f(0.98), f(1e-2))
+    assert (d.radius, d.sigma_distance, d.sigma_range, d.albedo_factor) == (0, 2.0, 1.5, 1.0)
+    import ctypes
+    assert ctypes.sizeof(H.Uniforms) == 148 and H.Uniforms.specularity.offset == 144 and H.Uniforms.sun_color.offset == 112
+
+
+def test_product_fails_loudly_without_gpu(H):
+    """No CPU fallback: without a HIP device the context cannot be created."""
+    import ctypes
+    n = ctypes.c_int(0)
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        have_gpu = hip.hipGetDeviceCount(ctypes.byref(n)) == 0 and n.value > 0
+    except OSError:
+        have_gpu = False
+    if have_gpu:
+        pytest.skip("a GPU is present")
+    from gpu_voxel_raytracer_amd import Context, VxrtError
+    with pytest.raises(VxrtError) as e:
+        Context(64, 64)
+    assert e.value.status == H.E_DEVICE
