@@ -42,16 +42,17 @@ __device__ __forceinline__ bool sample_bilinear(const float4* img, const BandMap
     int x0 = min(max(vx_f2i(x0f), -2), b.width), y0 = min(max(vx_f2i(y0f), -2), b.height);
     int xa = min(max(x0, 0), b.width - 1), xb = min(max(x0 + 1, 0), b.width - 1);
     int ya = min(max(y0, 0), b.height - 1), yb = min(max(y0 + 1, 0), b.height - 1);
-    int la = local_row(b, ya), lb = ay == 0.0f ? la : local_row(b, yb);
+    // a texel whose quantised weight is 0 is not read: only rows with a non-zero weight must be local
+    int la = ay == 1.0f ? 0 : local_row(b, ya), lb = ay == 0.0f ? 0 : local_row(b, yb);
     if (la < 0 || lb < 0) return false;
     float4 t00 = img[size_t(la) * b.width + xa], t10 = img[size_t(la) * b.width + xb];
     float4 t01 = img[size_t(lb) * b.width + xa], t11 = img[size_t(lb) * b.width + xb];
     const float* p00 = &t00.x; const float* p10 = &t10.x; const float* p01 = &t01.x; const float* p11 = &t11.x;
     float* o = &out.x;
     for (int k = 0; k < 4; k++) {
-        float top = ax == 0.0f ? p00[k] : (p00[k] * (1.0f - ax) + p10[k] * ax);
-        float bot = ax == 0.0f ? p01[k] : (p01[k] * (1.0f - ax) + p11[k] * ax);
-        o[k] = ay == 0.0f ? top : (top * (1.0f - ay) + bot * ay);
+        float top = ax == 0.0f ? p00[k] : (ax == 1.0f ? p10[k] : (p00[k] * (1.0f - ax) + p10[k] * ax));
+        float bot = ax == 0.0f ? p01[k] : (ax == 1.0f ? p11[k] : (p01[k] * (1.0f - ax) + p11[k] * ax));
+        o[k] = ay == 0.0f ? top : (ay == 1.0f ? bot : (top * (1.0f - ay) + bot * ay));
     }
     return true;
 }

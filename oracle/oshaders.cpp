@@ -17,7 +17,7 @@
 //       and every comparison false (temporal.comp:82-92) -> "no history => blending = 1".
 //   U4  texture() with the Linear sampler (src/context.rs:980-989): ideal bilinear with weights
 //       quantised to 8 fractional bits (Vulkan subTexelPrecisionBits on the hardware the reference
-//       ran on), clamp-to-edge.
+//       ran on), clamp-to-edge; a texel whose quantised weight is 0 is not read.
 //   U5  inverse(mat4) (temporal.comp:82): affine inverse by adjugate/determinant in binary64,
 //       rounded once to binary32, hoisted out of the pixel loop (the matrix is per-frame).
 #include <atomic>
@@ -332,10 +332,10 @@ struct Tex {  // rgba32f image + the Linear/ClampToEdge sampler of src/context.r
         fetch(ix0, iy0, t00); fetch(ix0 + 1, iy0, t10);
         fetch(ix0, iy0 + 1, t01); fetch(ix0 + 1, iy0 + 1, t11);
         for (int k = 0; k < 4; k++) {
-            // a zero weight must not let a NaN/inf neighbour (sky normals are 2^30) through
-            float top = ax == 0.0f ? t00[k] : (t00[k] * (1.0f - ax) + t10[k] * ax);
-            float bot = ax == 0.0f ? t01[k] : (t01[k] * (1.0f - ax) + t11[k] * ax);
-            o[k] = ay == 0.0f ? top : (top * (1.0f - ay) + bot * ay);
+            // a texel whose quantised weight is 0 is not read at all (so a NaN/inf neighbour cannot leak in)
+            float top = ax == 0.0f ? t00[k] : (ax == 1.0f ? t10[k] : (t00[k] * (1.0f - ax) + t10[k] * ax));
+            float bot = ax == 0.0f ? t01[k] : (ax == 1.0f ? t11[k] : (t01[k] * (1.0f - ax) + t11[k] * ax));
+            o[k] = ay == 0.0f ? top : (ay == 1.0f ? bot : (top * (1.0f - ay) + bot * ay));
         }
     }
 };
