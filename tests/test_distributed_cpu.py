@@ -1,0 +1,149 @@
+"""CPU, world_size 2 over gloo: rehearses the N > 1 path of gpu_voxel_raytracer_amd/distributed.py — band
+ownership, the halo message layout and its routing (who sends which rows to whom, which received buffer
+feeds which side) — with the ORACLE standing in for the GPU kernels (the product itself has no CPU path).
+Two spawned processes each render their bands, swap halos through torch.distributed, denoise, and rank 0
+checks the stitched frame against the single-process oracle frame, bit for bit."""
+import ctypes
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+class OracleBandContext:
+    """Stand-in with host.Context's halo/render interface; mirrors vxrt_halo_export/import (vxrt_api.hip)."""
+
+    def __init__(self, O, layout, rank, radius, full_accum, full_nd, full_alb, cam16):
+        self.O, self.layout, self.rank, self.r = O, layout, rank, radius
+        self.rows = layout.rows(rank)
+        self.imgs = [a[self.rows].copy() for a in (full_accum, full_nd, full_alb)]   # only OUR rows are known
+        self.cam16 = cam16
+        self.halo = None
+
+    def halo_bytes(self):
+        return self.layout.halo_floats(self.r) * 4
+
+    def _view(self, ptr):
+        n = self.layout.halo_floats(self.r)
+        return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_float)), (n,)).reshape(
+            self.layout.max_bands(), self.r, 3, self.layout.width, 4)
+
+    def halo_export(self, to_prev, to_next):
+        L, r = self.layout, self.r
+        vp, vn = self._view(to_prev), self._view(to_next)
+        for lb, gb in enumerate(L.local_bands(self.rank)):
+            y0 = gb * L.band_rows
+            nrows = min(L.band_rows, L.height - y0)
+            if gb >= 1:
+                for k in range(min(r, nrows)):
+                    for im in range(3):
+                        vp[(gb - 1) // L.nranks, k, im] = self.imgs[im][lb * L.band_rows + k]
+            if nrows == L.band_rows and (gb + 1) * L.band_rows < L.height:
+                for k in range(r):
+                    for im in range(3):
+                        vn[(gb + 1) // L.nranks, k, im] = self.imgs[im][lb * L.band_rows + L.band_rows - r + k]
+
+    def halo_import(self, from_prev, from_next):
+        self.halo = (self._view(from_prev).copy(), self._view(from_next).copy())
+
+    def render_stage(self, flags):
+        # rebuild, for each of our bands, the band + its halo rows, denoise that strip with the oracle
+        L, r, O = self.layout, self.r, self.O
+        out = np.zeros_like(self.imgs[0])
+        du = O.Denoise.default()
+        du.radius = r
+        for lb, gb in enumerate(L.local_bands(self.rank)):
+            y0 = gb * L.band_rows
+            nrows = min(L.band_rows, L.height - y0)
+            top, bot = max(y0 - r, 0), min(y0 + nrows + r, L.height)
+            strip = [np.zeros((L.height, L.width, 4), np.float32) for _ in range(3)]   # full-frame canvas
+            for im in range(3):
+                strip[im][y0:y0 + nrows] = self.imgs[im][lb * L.band_rows: lb * L.band_rows + nrows]
+                for y in range(top, y0):
+                    strip[im][y] = self.halo[0][lb, y - (y0 - r), im]
+                for y in range(y0 + nrows, bot):
+                    strip[im][y] = self.halo[1][lb, y - (y0 + L.band_rows), im]
+            den = O.denoise(strip[0], strip[1], strip[2], self.cam16, du, nthreads=2)
+            out[lb * L.band_rows: lb * L.band_rows + nrows] = den[y0:y0 + nrows]
+        self.denoised = out
+
+
+def _worker(rank, world, port, w, h, radius, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from gpu_voxel_raytracer_amd import distributed as D
+    from gpu_voxel_raytracer_amd import scenes
+    from oracle import oracle as O
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pos, mrgb, size = scenes.load_scene("castle")
+        cam = scenes.close_camera(size)
+        octree = O.create_octree(pos, mrgb)
+        noise = O.noise_table()
+        u = O.Uniforms.default()
+        u.set_camera(cam[0], O.camera_axis_scaled(cam[0], cam[1], cam[2], w, h))
+        u.frame_number = 1
+        cam16 = u.camera16()
+        layout = D.BandLayout(w, h, world, 16)
+        # each rank traces ONLY its rows (pixel coordinates are frame-absolute)
+        mine = layout.rows(rank)
+        color = np.zeros((h, w, 4), np.float32); nd = np.zeros_like(color); alb = np.zeros_like(color)
+        for gb in layout.local_bands(rank):
+            y0, y1 = gb * 16, min(gb * 16 + 16, h)
+            c, n_, a, _ = O.trace(octree, noise, u, w, h, 3, crop=(0, y0, w, y1), nthreads=2)
+            color[y0:y1], nd[y0:y1], alb[y0:y1] = c, n_, a
+        accum = O.temporal(color, nd, np.zeros_like(color), np.zeros_like(nd), cam16, cam16, O.Temporal.default(), False, nthreads=2)
+        ctx = OracleBandContext(O, layout, rank, radius, accum, nd, alb, cam16)
+        D.exchange_halo(ctx, dist, rank, world, "cpu", torch)
+        ctx.render_stage(D.DENOISE)
+        full = D.gather_image(ctx.denoised, layout, rank, dist, torch, "cpu")
+        if rank == 0:
+            # single-process reference
+            c, n_, a, _ = O.trace(octree, noise, u, w, h, 3, crop=(0, 0, w, h), nthreads=2)
+            acc = O.temporal(c, n_, np.zeros_like(c), np.zeros_like(n_), cam16, cam16, O.Temporal.default(), False, nthreads=2)
+            du = O.Denoise.default(); du.radius = radius
+            want = O.denoise(acc, n_, a, cam16, du, nthreads=2)
+            same = (full == want) | (np.isnan(full) & np.isnan(want))
+            q.put(("ok", bool(same.all()), int((~same).sum())))
+    except Exception as e:  # pragma: no cover
+        q.put(("error", repr(e), rank))
+        raise
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("w,h,radius", [(96, 72, 3), (64, 50, 8)])
+def test_two_rank_gloo_halo_exchange(O, w, h, radius):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    procs = [mpctx.Process(target=_worker, args=(r, 2, port, w, h, radius, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0] == "ok" and res[1], res
+
+
+def test_band_layout_matches_library(H):
+    from gpu_voxel_raytracer_amd import distributed as D
+    for (w, h, n) in ((64, 200, 8), (1920, 1080, 8), (1920, 1080, 3), (100, 16, 4), (80, 40, 5)):
+        L = D.BandLayout(w, h, n, 16)
+        allrows = np.concatenate([L.rows(r) for r in range(n)])
+        assert sorted(allrows.tolist()) == list(range(h))
+        assert all(L.owner(y) == r for r in range(n) for y in L.rows(r))
+        assert max(len(L.local_bands(r)) for r in range(n)) == L.max_bands()
+    L = D.BandLayout(1920, 1080, 8)
+    sizes = [len(L.rows(r)) for r in range(8)]
+    assert sum(sizes) == 1080 and max(sizes) - min(sizes) <= 16            # interleaving balances the ranks
