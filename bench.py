@@ -62,13 +62,16 @@ def cpu_baseline(pos, mrgb, cam, target_seconds=12.0):
 
 
 def main():
+    global BOUNCES
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--view", default="bench", choices=["bench", "close"])
+    ap.add_argument("--bounces", type=int, default=BOUNCES, help="diagnostic only; the benchmark is 4")
     args = ap.parse_args()
+    BOUNCES = args.bounces
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -27,7 +27,8 @@ def build(force=False, verbose=False, extra_flags=()):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + list(extra_flags) + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    extra_flags = list(extra_flags) + os.environ.get("VXRT_HIPCC_FLAGS", "").split()
+    cmd = [hipcc] + FLAGS + extra_flags + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -18,6 +18,8 @@ struct SvoRecord {
     uint32_t base;
 };
 
+constexpr unsigned kRaySlots = 2048;  // ray counters, one per 64-byte line (TraceArgs::ray_counter)
+
 struct Cam {  // first 64 bytes of Uniforms, without padding
     float o[3], r[3], u[3], f[3];
 };
@@ -33,12 +35,15 @@ struct TraceArgs {
     float4* out_color;
     float4* out_nd;
     float4* out_albedo;
-    unsigned long long* ray_counter;
+    unsigned long long* ray_counter;  // kRaySlots counters, 8 words apart
+    const uint32_t* tile_order;       // monolithic kernel: block b renders 16x16 tile tile_order[b] (null: b)
+    uint32_t* tile_cost;              // ... and records how long the tile took (shader clocks, max over its waves)
     float root_center[3];
     float root_size;
     BandMap band;
     int max_bounces;
     uint32_t frame_number;
+    uint32_t launch_index;  // counts trace launches of the context (persistent kernel: which tile counter to use)
     int stack_levels;  // LDS stack entries per thread (= octree depth, >= 1)
     Cam cam;
     // per-frame constants hoisted from voxels.comp main() (identical for every pixel)
@@ -78,7 +83,19 @@ struct DenoiseArgs {
     float sigma_distance_2, sigma_range_2, albedo_factor;
 };
 
-hipError_t launch_trace(const TraceArgs& a, hipStream_t s);
+// Queue of live paths between two launches of the wavefront tracer (trace.hip): 64-byte records in 64 shards.
+struct PathQueue {
+    float4* recs;             // [64 shards][shard_capacity][4 float4]
+    unsigned* counts;         // 64 counters, 16 uints (one 64-byte line) apart
+    unsigned shard_capacity;  // records per shard
+};
+
+hipError_t launch_trace(const TraceArgs& a, hipStream_t s);  // monolithic: one pixel per lane, all bounces
+// longest-tile-first schedule for the next launch: order[] = tiles sorted by descending cost; cost[] is cleared
+hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, unsigned tiles, hipStream_t s);
+// wavefront: primary_kernel + max_bounces x bounce_kernel; queues[2] ping-pong, count_sets[3] rotate
+hipError_t launch_trace_wavefront(const TraceArgs& a, const PathQueue queues[2], unsigned* count_sets[3], unsigned* launch_counter,
+                                  int blocks, unsigned split_mask, hipStream_t s);
 hipError_t launch_temporal(const TemporalArgs& a, hipStream_t s);
 hipError_t launch_denoise(const DenoiseArgs& a, hipStream_t s);
 hipError_t launch_noise_fill(float* dst, uint32_t seed, size_t n, hipStream_t s);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iterator>
@@ -80,6 +81,19 @@ struct vxrt_ctx {
 
     // stats
     unsigned long long* d_rays = nullptr;
+    // wavefront tracer: two path queues (ping-pong) and three rotating sets of 64 shard counters
+    float4* d_queue[2] = {nullptr, nullptr};
+    unsigned* d_counts = nullptr;
+    unsigned shard_capacity = 0;
+    unsigned wavefront_launches = 0;
+    int trace_variant = 0;  // 0 = monolithic trace_kernel (all bounces in one launch), 2 = wavefront (slower, kept for A/B)
+    // longest-tile-first scheduling of the monolithic kernel: cost of every 16x16 tile in the last frame -> order
+    uint32_t* d_tile_cost = nullptr;
+    uint32_t* d_tile_order = nullptr;
+    bool tile_order_valid = false;
+    int use_tile_order = 1;
+    int trace_blocks = 2048;
+    unsigned trace_split = 0x1;  // bit k: compact live paths and start a new launch at path segment k
     uint64_t frames = 0, pixels = 0, timed_frames = 0;
     double ms[3] = {0, 0, 0};
     std::vector<EventPair> pending, free_pairs;
@@ -102,11 +116,15 @@ int local_band_count(const BandMap& b) {
 }
 
 void free_images(vxrt_ctx* c) {
-    float4** imgs[] = {&c->sampled_color, &c->albedo, &c->nd[0], &c->nd[1], &c->accum[0], &c->accum[1], &c->denoised, &c->halo};
+    float4** imgs[] = {&c->sampled_color, &c->albedo, &c->nd[0], &c->nd[1], &c->accum[0], &c->accum[1], &c->denoised, &c->halo,
+                       &c->d_queue[0], &c->d_queue[1]};
     for (float4** p : imgs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
+    if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
+    if (c->d_tile_order) (void)hipFree(c->d_tile_order);
+    c->d_tile_cost = c->d_tile_order = nullptr;
 }
 
 int alloc_images(vxrt_ctx* c) {
@@ -118,6 +136,16 @@ int alloc_images(vxrt_ctx* c) {
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), bytes));
         HIP_TRY(hipMemsetAsync(*p, 0, bytes, c->stream));
     }
+    // path queues: every 8x8-pixel wave of the primary launch appends to shard (wave index % 64)
+    const size_t waves = size_t((c->band.width + 15) / 16) * size_t((c->band.local_rows + 15) / 16) * 4;
+    c->shard_capacity = unsigned((waves + 63) / 64 * 64);
+    for (int i = 0; i < 2; i++)
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_queue[i]), (size_t(c->shard_capacity) * 64 + 1) * 64));
+    const size_t tiles = waves / 4;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_tile_cost), (tiles + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_tile_order), (tiles + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(c->d_tile_cost, 0, (tiles + 1) * sizeof(uint32_t), c->stream));
+    c->tile_order_valid = false;
     c->cur = 0;
     c->last = 0;
     c->has_history = false;
@@ -325,8 +353,14 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) {
     } else {
         if (launch_noise_fill(c->d_noise, cfg->noise_seed, kNoiseCount, c->stream) != hipSuccess) return fail(hip_fail(hipGetLastError(), "noise fill"));
     }
-    if (hipMalloc(reinterpret_cast<void**>(&c->d_rays), sizeof(unsigned long long)) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipMalloc counter"));
-    if (hipMemsetAsync(c->d_rays, 0, sizeof(unsigned long long), c->stream) != hipSuccess) return fail(hip_fail(hipGetLastError(), "memset counter"));
+    if (hipMalloc(reinterpret_cast<void**>(&c->d_rays), kRaySlots * 64) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipMalloc counter"));
+    if (hipMemsetAsync(c->d_rays, 0, kRaySlots * 64, c->stream) != hipSuccess) return fail(hip_fail(hipGetLastError(), "memset counter"));
+    if (hipMalloc(reinterpret_cast<void**>(&c->d_counts), 3 * 64 * 64) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipMalloc queue counters"));
+    if (hipMemsetAsync(c->d_counts, 0, 3 * 64 * 64, c->stream) != hipSuccess) return fail(hip_fail(hipGetLastError(), "memset queue counters"));
+    if (const char* v = getenv("VXRT_TRACE_VARIANT")) c->trace_variant = atoi(v);
+    if (const char* v = getenv("VXRT_TRACE_BLOCKS")) c->trace_blocks = atoi(v);
+    if (const char* v = getenv("VXRT_TILE_ORDER")) c->use_tile_order = atoi(v);
+    if (const char* v = getenv("VXRT_TRACE_SPLIT")) c->trace_split = unsigned(strtoul(v, nullptr, 0));
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(hip_fail(hipGetLastError(), "sync"));
     *out = c;
     return VXRT_OK;
@@ -343,6 +377,7 @@ int vxrt_destroy(vxrt_ctx* c) {
     if (c->d_leaves) (void)hipFree(c->d_leaves);
     if (c->d_noise) (void)hipFree(c->d_noise);
     if (c->d_rays) (void)hipFree(c->d_rays);
+    if (c->d_counts) (void)hipFree(c->d_counts);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return VXRT_OK;
@@ -465,11 +500,14 @@ int vxrt_render(vxrt_ctx* c, uint32_t flags) {
         a.svo = c->d_svo; a.leaves = c->d_leaves; a.noise = c->d_noise;
         a.out_color = c->sampled_color; a.out_nd = c->nd[c->cur]; a.out_albedo = c->albedo;
         a.ray_counter = c->d_rays;
+        a.tile_order = (c->use_tile_order && c->tile_order_valid) ? c->d_tile_order : nullptr;
+        a.tile_cost = c->use_tile_order ? c->d_tile_cost : nullptr;
         memcpy(a.root_center, c->root_center, sizeof a.root_center);
         a.root_size = c->root_size;
         a.band = c->band;
         a.max_bounces = int(c->cfg.max_bounces);
         a.frame_number = u.frame_number;
+        a.launch_index = 0;
         a.stack_levels = c->depth < 1 ? 1 : int(c->depth);
         a.cam = c->cam;
         // voxels.comp:296 and the other per-frame constants, evaluated once with the same operations
@@ -486,8 +524,23 @@ int vxrt_render(vxrt_ctx* c, uint32_t flags) {
         if (c->band.local_rows > 0) {
             EventPair p;
             if (timed) { p = take_pair(c, 0); HIP_TRY(hipEventRecord(p.a, c->stream)); }
-            HIP_TRY(launch_trace(a, c->stream));
-            if (timed) { HIP_TRY(hipEventRecord(p.b, c->stream)); c->pending.push_back(p); }
+            if (c->trace_variant == 0) {
+                HIP_TRY(launch_trace(a, c->stream));
+                if (c->use_tile_order) {  // schedule for the next frame (outside the timed kernel, ~4 us)
+                    const unsigned tiles = unsigned((c->band.width + 15) / 16) * unsigned((c->band.local_rows + 15) / 16);
+                    if (timed) { HIP_TRY(hipEventRecord(p.b, c->stream)); }
+                    HIP_TRY(launch_tile_order(c->d_tile_cost, c->d_tile_order, tiles, c->stream));
+                    c->tile_order_valid = true;
+                }
+            } else {
+                PathQueue queues[2] = {{c->d_queue[0], nullptr, c->shard_capacity}, {c->d_queue[1], nullptr, c->shard_capacity}};
+                unsigned* sets[3] = {c->d_counts, c->d_counts + 64 * 16, c->d_counts + 2 * 64 * 16};
+                HIP_TRY(launch_trace_wavefront(a, queues, sets, &c->wavefront_launches, c->trace_blocks, c->trace_split, c->stream));
+            }
+            if (timed) {
+                if (!(c->trace_variant == 0 && c->use_tile_order)) HIP_TRY(hipEventRecord(p.b, c->stream));
+                c->pending.push_back(p);
+            }
         }
         c->frames += 1;
         c->pixels += uint64_t(c->band.local_rows) * c->band.width;
@@ -601,8 +654,10 @@ int vxrt_local_rows(const vxrt_ctx* c, uint32_t* count, uint32_t* rows) {
 int vxrt_get_stats(vxrt_ctx* c, vxrt_stats* out) {
     if (!valid_ctx(c) || !out) { set_error("null argument"); return VXRT_E_INVALID; }
     if (int rc = vxrt_sync(c)) return rc;
+    std::vector<unsigned long long> slots(size_t(kRaySlots) * 8);
+    HIP_TRY(hipMemcpy(slots.data(), c->d_rays, slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     unsigned long long rays = 0;
-    HIP_TRY(hipMemcpy(&rays, c->d_rays, sizeof rays, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < slots.size(); i += 8) rays += slots[i];
     memset(out, 0, sizeof *out);
     out->frames = c->frames;
     out->rays = rays;
@@ -622,7 +677,7 @@ int vxrt_get_stats(vxrt_ctx* c, vxrt_stats* out) {
 int vxrt_reset_stats(vxrt_ctx* c) {
     if (!valid_ctx(c)) return VXRT_E_INVALID;
     if (int rc = vxrt_sync(c)) return rc;
-    HIP_TRY(hipMemset(c->d_rays, 0, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->d_rays, 0, kRaySlots * 64));
     c->frames = c->pixels = c->timed_frames = 0;
     c->ms[0] = c->ms[1] = c->ms[2] = 0.0;
     return VXRT_OK;

@@ -62,6 +62,8 @@ static uint32_t current_octant(V3 position, V3 center) {
     return dx + dy + dz;
 }
 
+thread_local long long g_iterations = 0;  // diagnostic: octree steps taken by this thread
+
 // voxels.comp:134-247
 bool cast_bounded_ray(const int32_t* octree, V3 ray_origin, V3 ray_dir, float max_distance, Hit* out) {
     float hdr[5];
@@ -94,6 +96,7 @@ bool cast_bounded_ray(const int32_t* octree, V3 ray_origin, V3 ray_dir, float ma
     int iterations = 0;
     for (;;) {
         iterations++;
+        g_iterations++;
         out->iterations = iterations;
         out->time = time;
         if (iterations >= 2048) {
@@ -362,6 +365,22 @@ long long orc_trace(const int32_t* octree, const float* noise, const OrcUniforms
         rays += r;
     });
     return rays.load();
+}
+
+// Diagnostic: octree steps per pixel (summed over all of the pixel's rays) for a crop — used to reason about
+// the GPU kernels' critical path, not by any parity test.
+void orc_trace_steps(const int32_t* octree, const float* noise, const OrcUniforms* u, int max_bounces, int x0, int y0,
+                     int x1, int y1, int32_t* steps, int nthreads) {
+    int cw = x1 - x0;
+    std::vector<float> scratch((size_t)12);
+    parallel_rows(y0, y1, nthreads, [&](int y) {
+        float c[4], n[4], a[4];
+        for (int x = x0; x < x1; x++) {
+            long long before = g_iterations;
+            trace_pixel(octree, noise, *u, max_bounces, x, y, c, n, a);
+            steps[(size_t)(y - y0) * cw + (x - x0)] = (int32_t)(g_iterations - before);
+        }
+    });
 }
 
 // Batch of single rays through cast_bounded_ray — for traversal unit tests and the DDA cross-check.
