@@ -38,6 +38,16 @@ def algorithmic_bytes(pixels, bounces, scene_bytes):
     return 48 * pixels + scene_bytes + min(8 * bounces, 512) * 128 * 128 * 4
 
 
+def measured_traffic():
+    """HBM bytes per trace_kernel launch from the rocprofv3 PMC passes recorded in profiles/ (FETCH_SIZE and
+    WRITE_SIZE need separate passes and cannot be collected from inside this process); None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01", "trace_traffic_pmc.json")
+    try:
+        return float(json.load(open(path))["hbm_bytes_per_launch_corrected"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(pos, mrgb, cam, target_seconds=12.0):
     """The CPU oracle (restatement of shaders/voxels.comp, oracle/oshaders.cpp) timed on this host's cores on
     whole frames of the same workload: a reported baseline, not the target."""
@@ -140,7 +150,8 @@ def main():
                        "rays_per_frame": rays // args.steps, "rays_per_pixel": round(rays / args.steps / (WIDTH * HEIGHT), 4),
                        "mpixels_per_s": round(WIDTH * HEIGHT * args.steps / elapsed / 1e6, 1)},
             "roofline": {"bound": "hbm", "kernel": "trace_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": measured_traffic() if (world == 1 and args.view == "bench" and BOUNCES == 4) else None,
                          "launch_ms": round(launch_ms, 4), "algorithmic_bytes_per_launch": alg},
         }
         if world == 1 and not args.no_cpu_baseline:

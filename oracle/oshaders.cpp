@@ -63,6 +63,8 @@ static uint32_t current_octant(V3 position, V3 center) {
 }
 
 thread_local long long g_iterations = 0;  // diagnostic: octree steps taken by this thread
+thread_local int* g_phase_steps = nullptr;  // diagnostic: steps of each successive ray of the current pixel
+thread_local int g_phase = 0;
 
 // voxels.comp:134-247
 bool cast_bounded_ray(const int32_t* octree, V3 ray_origin, V3 ray_dir, float max_distance, Hit* out) {
@@ -234,7 +236,9 @@ static int trace_pixel(const int32_t* octree, const float* noise, const OrcUnifo
     for (int bounce = 0; bounce < max_bounces; bounce++) {
         Hit h;
         rays++;
-        if (cast_bounded_ray(octree, ray_origin, ray_dir, ALMOST_INFINITY, &h)) {
+        bool primary_hit = cast_bounded_ray(octree, ray_origin, ray_dir, ALMOST_INFINITY, &h);
+        if (g_phase_steps && g_phase < 32) g_phase_steps[g_phase++] = h.iterations;
+        if (primary_hit) {
             V3 normal = h.normal;
             V3 hit_pos = ray_origin + ray_dir * h.time;
             V3 color = bounce == 0 ? v3s(1.0f) : node_color(h.node);
@@ -262,6 +266,7 @@ static int trace_pixel(const int32_t* octree, const float* noise, const OrcUnifo
                     Hit sh;
                     rays++;
                     bool sun_obstructed = cast_bounded_ray(octree, hit_pos + 1e-5f * normal, normalize(-light_dir), ALMOST_INFINITY, &sh);
+                    if (g_phase_steps && g_phase < 32) g_phase_steps[g_phase++] = sh.iterations;
                     ambient_rays++;
                     if (!sun_obstructed) {
                         sample_color = sample_color + ((sun_color * color) * blending_factor) * vx_max(0.0f, dot(normal, normalize(-light_dir)));
@@ -367,7 +372,7 @@ long long orc_trace(const int32_t* octree, const float* noise, const OrcUniforms
     return rays.load();
 }
 
-// Diagnostic: octree steps per pixel (summed over all of the pixel's rays) for a crop — used to reason about
+// Diagnostic: per pixel 17 ints = total octree steps, then the steps of each successive ray (<= 16) — for a crop — used to reason about
 // the GPU kernels' critical path, not by any parity test.
 void orc_trace_steps(const int32_t* octree, const float* noise, const OrcUniforms* u, int max_bounces, int x0, int y0,
                      int x1, int y1, int32_t* steps, int nthreads) {
@@ -377,8 +382,13 @@ void orc_trace_steps(const int32_t* octree, const float* noise, const OrcUniform
         float c[4], n[4], a[4];
         for (int x = x0; x < x1; x++) {
             long long before = g_iterations;
+            int32_t* row = steps + ((size_t)(y - y0) * cw + (x - x0)) * 17;
+            for (int k = 0; k < 17; k++) row[k] = 0;
+            g_phase_steps = row + 1;
+            g_phase = 0;
             trace_pixel(octree, noise, *u, max_bounces, x, y, c, n, a);
-            steps[(size_t)(y - y0) * cw + (x - x0)] = (int32_t)(g_iterations - before);
+            g_phase_steps = nullptr;
+            row[0] = (int32_t)(g_iterations - before);
         }
     });
 }
