@@ -92,7 +92,7 @@ struct PathQueue {
 
 hipError_t launch_trace(const TraceArgs& a, hipStream_t s);  // monolithic: one pixel per lane, all bounces
 // longest-tile-first schedule for the next launch: order[] = tiles sorted by descending cost; cost[] is cleared
-hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, unsigned tiles, hipStream_t s);
+hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t* last_cost, unsigned tiles, hipStream_t s);
 // wavefront: primary_kernel + max_bounces x bounce_kernel; queues[2] ping-pong, count_sets[3] rotate
 hipError_t launch_trace_wavefront(const TraceArgs& a, const PathQueue queues[2], unsigned* count_sets[3], unsigned* launch_counter,
                                   int blocks, unsigned split_mask, hipStream_t s);

@@ -345,7 +345,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs a) {
 }
 
 // Counting sort of the tiles by descending cost (key = log2 of the cost with two mantissa bits), one block.
-__global__ __launch_bounds__(1024) void tile_order_kernel(uint32_t* cost, uint32_t* order, unsigned tiles) {
+__global__ __launch_bounds__(1024) void tile_order_kernel(uint32_t* cost, uint32_t* order, uint32_t* last_cost, unsigned tiles) {
     __shared__ unsigned hist[128], offs[128];
     const unsigned tid = threadIdx.x;
     if (tid < 128) hist[tid] = 0;
@@ -367,7 +367,10 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(uint32_t* cost, uint32
         order[pos] = t;
     }
     __syncthreads();
-    for (unsigned t = tid; t < tiles; t += blockDim.x) cost[t] = 0u;
+    for (unsigned t = tid; t < tiles; t += blockDim.x) {
+        last_cost[t] = cost[t];
+        cost[t] = 0u;
+    }
 }
 
 
@@ -616,8 +619,8 @@ hipError_t launch_trace(const TraceArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, unsigned tiles, hipStream_t s) {
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, cost, order, tiles);
+hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t* last_cost, unsigned tiles, hipStream_t s) {
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, cost, order, last_cost, tiles);
     return hipGetLastError();
 }
 

@@ -90,6 +90,7 @@ struct vxrt_ctx {
     // longest-tile-first scheduling of the monolithic kernel: cost of every 16x16 tile in the last frame -> order
     uint32_t* d_tile_cost = nullptr;
     uint32_t* d_tile_order = nullptr;
+    uint32_t* d_tile_last_cost = nullptr;  // copy of the last frame's tile costs (diagnostics: vxrt_debug_tile_costs)
     bool tile_order_valid = false;
     int use_tile_order = 1;
     int trace_blocks = 2048;
@@ -124,7 +125,8 @@ void free_images(vxrt_ctx* c) {
     }
     if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
     if (c->d_tile_order) (void)hipFree(c->d_tile_order);
-    c->d_tile_cost = c->d_tile_order = nullptr;
+    if (c->d_tile_last_cost) (void)hipFree(c->d_tile_last_cost);
+    c->d_tile_cost = c->d_tile_order = c->d_tile_last_cost = nullptr;
 }
 
 int alloc_images(vxrt_ctx* c) {
@@ -144,6 +146,7 @@ int alloc_images(vxrt_ctx* c) {
     const size_t tiles = waves / 4;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_tile_cost), (tiles + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_tile_order), (tiles + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_tile_last_cost), (tiles + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMemsetAsync(c->d_tile_cost, 0, (tiles + 1) * sizeof(uint32_t), c->stream));
     c->tile_order_valid = false;
     c->cur = 0;
@@ -529,7 +532,7 @@ int vxrt_render(vxrt_ctx* c, uint32_t flags) {
                 if (c->use_tile_order) {  // schedule for the next frame (outside the timed kernel, ~4 us)
                     const unsigned tiles = unsigned((c->band.width + 15) / 16) * unsigned((c->band.local_rows + 15) / 16);
                     if (timed) { HIP_TRY(hipEventRecord(p.b, c->stream)); }
-                    HIP_TRY(launch_tile_order(c->d_tile_cost, c->d_tile_order, tiles, c->stream));
+                    HIP_TRY(launch_tile_order(c->d_tile_cost, c->d_tile_order, c->d_tile_last_cost, tiles, c->stream));
                     c->tile_order_valid = true;
                 }
             } else {
@@ -680,6 +683,17 @@ int vxrt_reset_stats(vxrt_ctx* c) {
     HIP_TRY(hipMemset(c->d_rays, 0, kRaySlots * 64));
     c->frames = c->pixels = c->timed_frames = 0;
     c->ms[0] = c->ms[1] = c->ms[2] = 0.0;
+    return VXRT_OK;
+}
+
+// Diagnostics: shader-clock duration of every 16x16 tile in the last traced frame (monolithic kernel).
+int vxrt_debug_tile_costs(vxrt_ctx* c, uint32_t* out, size_t n) {
+    if (!valid_ctx(c) || !out) { set_error("null argument"); return VXRT_E_INVALID; }
+    const size_t tiles = size_t((c->band.width + 15) / 16) * size_t((c->band.local_rows + 15) / 16);
+    if (n != tiles || !c->d_tile_last_cost) { set_error("tile count mismatch"); return VXRT_E_INVALID; }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, c->d_tile_last_cost, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return VXRT_OK;
 }
 

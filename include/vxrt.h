@@ -199,6 +199,10 @@ int vxrt_menger_voxels(uint32_t level, const uint8_t mrgb[4], int16_t (*pos)[3],
  * host-vs-device bit equality the numeric contract promises can be checked. */
 int vxrt_detmath_probe(int32_t device, int32_t fn, const float* x, const float* y, float* out, size_t n);
 
+/* Diagnostics: duration (shader clocks) of each 16x16 tile of the last traced frame, row-major over
+ * ceil(width/16) x ceil(local_rows/16) tiles — the data the longest-tile-first scheduler works from. */
+int vxrt_debug_tile_costs(vxrt_ctx* ctx, uint32_t* out, size_t n);
+
 const char* vxrt_status_string(int status);
 const char* vxrt_last_error(void);               /* thread-local detail of the last failing call */
 uint32_t vxrt_abi_version(void);

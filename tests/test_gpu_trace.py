@@ -130,3 +130,42 @@ def test_full_size_bench_config_crops(O, H, scenes, noise):
     nrm = nd[hit][:, :3]
     assert np.isin(nrm, (-1.0, 0.0, 1.0)).all() and (np.abs(nrm).sum(1) >= 1).all()
     assert W * Hh <= st.rays <= 2 * B * W * Hh and st.pixels == W * Hh
+
+
+@pytest.mark.parametrize("env", [
+    {"VXRT_TRACE_VARIANT": "0", "VXRT_TILE_ORDER": "0"},      # monolithic kernel, tiles in raster order
+    {"VXRT_TRACE_VARIANT": "0", "VXRT_TILE_ORDER": "1"},      # ... longest-tile-first (default)
+    {"VXRT_TRACE_VARIANT": "2", "VXRT_TRACE_SPLIT": "0x1"},   # wavefront: primary launch + one launch for all segments
+    {"VXRT_TRACE_VARIANT": "2", "VXRT_TRACE_SPLIT": "0x5"},   # wavefront: queues compacted before segments 0 and 2
+    {"VXRT_TRACE_VARIANT": "2", "VXRT_TRACE_SPLIT": "0xff", "VXRT_TRACE_BLOCKS": "64"},  # every segment its own launch; few waves loop over many chunks
+])
+def test_every_trace_variant_is_bit_exact(O, H, scenes, noise, monkeypatch, env):
+    """The scheduling variants of the tracer (read from the environment when a context is created) change
+    which lane / launch executes a path segment, never a result."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for name, w, h, b, cam in (("castle", 200, 120, 5, "close"), ("room", 136, 104, 3, "close"), ("menger", 256, 144, 4, "bench")):
+        for (g, rays, ref) in render_both(O, H, scenes, noise, name, w, h, b, frames=(1, 2, 3), camera=cam, specularity=0.1):
+            assert_bits_equal(g[0], ref[0], f"colour {name} {env}")
+            assert_bits_equal(g[1], ref[1], f"nd {name} {env}")
+            assert_bits_equal(g[2], ref[2], f"albedo {name} {env}")
+            assert rays == ref[3]
+
+
+def test_tile_cost_feedback(H, scenes, noise):
+    """The longest-tile-first scheduler's input: per-tile durations of the last frame (vxrt_debug_tile_costs)."""
+    import ctypes as C
+    from gpu_voxel_raytracer_amd import Context, Camera, TRACE
+    pos, mrgb, size = scenes.load_scene("castle")
+    w, h = 320, 192
+    with Context(w, h, max_bounces=3, noise=noise) as ctx:
+        ctx.recreate_octree(pos, mrgb)
+        ctx.camera = Camera(*scenes.bench_camera(size))
+        ctx.render(TRACE)
+        ctx.render(TRACE)
+        n = (w // 16) * (h // 16)
+        cost = np.zeros(n, np.uint32)
+        H._check(H.lib().vxrt_debug_tile_costs(ctx._h, cost.ctypes.data_as(C.c_void_p), C.c_size_t(n)), "vxrt_debug_tile_costs")
+        hit = (ctx.read(1)[..., 3] >= 0).reshape(h // 16, 16, w // 16, 16).any(axis=(1, 3)).ravel()
+        assert (cost > 0).all() and hit.any() and (~hit).any()
+        assert np.median(cost[hit]) > 2 * np.median(cost[~hit])     # tiles that see geometry take longer than sky tiles
