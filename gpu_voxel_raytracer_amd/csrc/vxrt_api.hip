@@ -57,19 +57,33 @@ struct vxrt_ctx {
     uint32_t depth = 0;
     float* d_noise = nullptr;
 
-    // images (local rows x width, rgba32f)
-    float4* sampled_color = nullptr;
-    float4* albedo = nullptr;
-    float4* nd[2] = {nullptr, nullptr};
+    // Images (local rows x width, rgba32f).  The trace outputs live in a ring of frame slots so that the
+    // trace stage of up to `inflight` consecutive frames can be on the GPU together (one stream each) while
+    // the temporal/denoise stages run in frame order on `stream`.  A slot is not re-used while it still is
+    // the temporal history or while a stage that reads it is in flight (slot.last_use).
+    struct Slot {
+        float4* sampled_color = nullptr;
+        float4* albedo = nullptr;
+        float4* nd = nullptr;
+        hipEvent_t trace_done = nullptr;  // recorded on the slot's trace stream
+        hipEvent_t last_use = nullptr;    // recorded after the last stage that touched the slot
+        bool last_use_recorded = false;
+    };
+    std::vector<Slot> ring;
+    int inflight = 1;
+    std::vector<hipStream_t> trace_streams;   // inflight entries; entry 0 is `stream` when inflight == 1
+    int slot = 0;        // slot of the most recently traced frame
+    int hist_slot = -1;  // slot whose normal/depth pairs with accum[hist] as the temporal history
     float4* accum[2] = {nullptr, nullptr};
     float4* denoised = nullptr;
     float4* halo = nullptr;  // rows of neighbouring ranks for the denoise window
     uint32_t halo_radius = 0;
     bool halo_valid = false;
-    int cur = 0;             // nd[cur]/accum[cur] are written this frame, [cur^1] hold the history
+    int cur = 0;             // accum[cur] is written by the next temporal stage, accum[cur^1] is the history
     bool has_history = false;
     bool accum_is_sampled = true;  // the latest "accumulated" image is sampled_color (temporal never ran)
-    int last = 0;                   // index of the most recently completed nd/accum pair
+    int last = 0;                   // index of the most recently written accum image
+    uint64_t traced = 0;            // frames traced so far (selects the trace stream)
 
     // parameters
     vxrt_uniforms uniforms{};
@@ -88,10 +102,14 @@ struct vxrt_ctx {
     unsigned wavefront_launches = 0;
     int trace_variant = 0;  // 0 = monolithic trace_kernel (all bounces in one launch), 2 = wavefront (slower, kept for A/B)
     // longest-tile-first scheduling of the monolithic kernel: cost of every 16x16 tile in the last frame -> order
-    uint32_t* d_tile_cost = nullptr;
-    uint32_t* d_tile_order = nullptr;
-    uint32_t* d_tile_last_cost = nullptr;  // copy of the last frame's tile costs (diagnostics: vxrt_debug_tile_costs)
-    bool tile_order_valid = false;
+    struct TileSchedule {  // one per trace stream: costs of the frame it traced last, and the order made from them
+        uint32_t* cost = nullptr;
+        uint32_t* order = nullptr;
+        uint32_t* last_cost = nullptr;  // copy for diagnostics (vxrt_debug_tile_costs)
+        bool valid = false;
+    };
+    std::vector<TileSchedule> schedules;
+    int last_schedule = 0;
     int use_tile_order = 1;
     int trace_blocks = 2048;
     unsigned trace_split = 0x1;  // bit k: compact live paths and start a new launch at path segment k
@@ -117,23 +135,38 @@ int local_band_count(const BandMap& b) {
 }
 
 void free_images(vxrt_ctx* c) {
-    float4** imgs[] = {&c->sampled_color, &c->albedo, &c->nd[0], &c->nd[1], &c->accum[0], &c->accum[1], &c->denoised, &c->halo,
-                       &c->d_queue[0], &c->d_queue[1]};
+    for (vxrt_ctx::Slot& sl : c->ring) {
+        for (float4** p : {&sl.sampled_color, &sl.albedo, &sl.nd}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        if (sl.trace_done) (void)hipEventDestroy(sl.trace_done);
+        if (sl.last_use) (void)hipEventDestroy(sl.last_use);
+    }
+    c->ring.clear();
+    float4** imgs[] = {&c->accum[0], &c->accum[1], &c->denoised, &c->halo, &c->d_queue[0], &c->d_queue[1]};
     for (float4** p : imgs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
-    if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
-    if (c->d_tile_order) (void)hipFree(c->d_tile_order);
-    if (c->d_tile_last_cost) (void)hipFree(c->d_tile_last_cost);
-    c->d_tile_cost = c->d_tile_order = c->d_tile_last_cost = nullptr;
+    for (vxrt_ctx::TileSchedule& t : c->schedules)
+        for (uint32_t** p : {&t.cost, &t.order, &t.last_cost}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    c->schedules.clear();
 }
 
 int alloc_images(vxrt_ctx* c) {
     free_images(c);
     size_t bytes = image_bytes(c);
     if (bytes == 0) bytes = sizeof(float4);
-    float4** imgs[] = {&c->sampled_color, &c->albedo, &c->nd[0], &c->nd[1], &c->accum[0], &c->accum[1], &c->denoised};
+    // inflight frames being traced + the frame in the post stages + the temporal history
+    c->ring.resize(size_t(c->inflight) + 2);
+    for (vxrt_ctx::Slot& sl : c->ring) {
+        for (float4** p : {&sl.sampled_color, &sl.albedo, &sl.nd}) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), bytes));
+            HIP_TRY(hipMemsetAsync(*p, 0, bytes, c->stream));
+        }
+        HIP_TRY(hipEventCreateWithFlags(&sl.trace_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl.last_use, hipEventDisableTiming));
+        sl.last_use_recorded = false;
+    }
+    float4** imgs[] = {&c->accum[0], &c->accum[1], &c->denoised};
     for (float4** p : imgs) {
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), bytes));
         HIP_TRY(hipMemsetAsync(*p, 0, bytes, c->stream));
@@ -144,17 +177,29 @@ int alloc_images(vxrt_ctx* c) {
     for (int i = 0; i < 2; i++)
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_queue[i]), (size_t(c->shard_capacity) * 64 + 1) * 64));
     const size_t tiles = waves / 4;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_tile_cost), (tiles + 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_tile_order), (tiles + 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_tile_last_cost), (tiles + 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMemsetAsync(c->d_tile_cost, 0, (tiles + 1) * sizeof(uint32_t), c->stream));
-    c->tile_order_valid = false;
+    c->schedules.resize(size_t(c->inflight));
+    for (vxrt_ctx::TileSchedule& t : c->schedules) {
+        for (uint32_t** p : {&t.cost, &t.order, &t.last_cost}) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), (tiles + 1) * sizeof(uint32_t)));
+            HIP_TRY(hipMemsetAsync(*p, 0, (tiles + 1) * sizeof(uint32_t), c->stream));
+        }
+        t.valid = false;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->slot = 0;
+    c->hist_slot = -1;
     c->cur = 0;
     c->last = 0;
     c->has_history = false;
     c->accum_is_sampled = true;
     c->halo_valid = false;
     c->halo_radius = 0;
+    return VXRT_OK;
+}
+
+int sync_all(vxrt_ctx* c) {
+    for (hipStream_t t : c->trace_streams) HIP_TRY(hipStreamSynchronize(t));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return VXRT_OK;
 }
 
@@ -256,7 +301,7 @@ int upload_scene(vxrt_ctx* c, const Voxel* voxels, size_t n) {
     if (leaves.empty()) leaves.push_back(0);
 
     HIP_TRY(hipSetDevice(c->cfg.device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc = sync_all(c)) return rc;
     if (c->d_svo) (void)hipFree(c->d_svo);
     if (c->d_leaves) (void)hipFree(c->d_leaves);
     c->d_svo = nullptr;
@@ -348,6 +393,18 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) {
     int rc = VXRT_OK;
     auto fail = [&](int code) { vxrt_destroy(c); return code; };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipStreamCreate"));
+    c->inflight = cfg->frames_in_flight == 0 ? 1 : int(cfg->frames_in_flight);
+    if (const char* v = getenv("VXRT_INFLIGHT")) c->inflight = atoi(v);
+    if (const char* v = getenv("VXRT_TRACE_VARIANT")) c->trace_variant = atoi(v);
+    if (c->inflight < 1 || c->inflight > 8) { set_error("frames_in_flight must be 1..8"); return fail(VXRT_E_INVALID); }
+    if (c->trace_variant != 0) c->inflight = 1;  // the wavefront variant shares its queues between frames
+    c->trace_streams.assign(size_t(c->inflight), nullptr);
+    if (c->inflight == 1) {
+        c->trace_streams[0] = c->stream;
+    } else {
+        for (hipStream_t& t : c->trace_streams)
+            if (hipStreamCreateWithFlags(&t, hipStreamNonBlocking) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipStreamCreate"));
+    }
     set_band(c, cfg->width, cfg->height);
     if ((rc = alloc_images(c)) != VXRT_OK) return fail(rc);
     if (hipMalloc(reinterpret_cast<void**>(&c->d_noise), kNoiseCount * sizeof(float)) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipMalloc noise"));
@@ -360,7 +417,6 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) {
     if (hipMemsetAsync(c->d_rays, 0, kRaySlots * 64, c->stream) != hipSuccess) return fail(hip_fail(hipGetLastError(), "memset counter"));
     if (hipMalloc(reinterpret_cast<void**>(&c->d_counts), 3 * 64 * 64) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipMalloc queue counters"));
     if (hipMemsetAsync(c->d_counts, 0, 3 * 64 * 64, c->stream) != hipSuccess) return fail(hip_fail(hipGetLastError(), "memset queue counters"));
-    if (const char* v = getenv("VXRT_TRACE_VARIANT")) c->trace_variant = atoi(v);
     if (const char* v = getenv("VXRT_TRACE_BLOCKS")) c->trace_blocks = atoi(v);
     if (const char* v = getenv("VXRT_TILE_ORDER")) c->use_tile_order = atoi(v);
     if (const char* v = getenv("VXRT_TRACE_SPLIT")) c->trace_split = unsigned(strtoul(v, nullptr, 0));
@@ -372,6 +428,7 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) {
 int vxrt_destroy(vxrt_ctx* c) {
     if (!c) return VXRT_OK;
     (void)hipSetDevice(c->cfg.device);
+    for (hipStream_t t : c->trace_streams) if (t) (void)hipStreamSynchronize(t);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto* v : {&c->pending, &c->free_pairs})
         for (EventPair& p : *v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -381,6 +438,7 @@ int vxrt_destroy(vxrt_ctx* c) {
     if (c->d_noise) (void)hipFree(c->d_noise);
     if (c->d_rays) (void)hipFree(c->d_rays);
     if (c->d_counts) (void)hipFree(c->d_counts);
+    for (hipStream_t t : c->trace_streams) if (t && t != c->stream) (void)hipStreamDestroy(t);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return VXRT_OK;
@@ -390,7 +448,7 @@ int vxrt_resize(vxrt_ctx* c, uint32_t width, uint32_t height) {
     if (!valid_ctx(c)) return VXRT_E_INVALID;
     if (width == 0 || height == 0 || width > 65536 || height > 65536) { set_error("bad frame size"); return VXRT_E_INVALID; }
     HIP_TRY(hipSetDevice(c->cfg.device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc = sync_all(c)) return rc;
     c->cfg.width = width;
     c->cfg.height = height;
     set_band(c, width, height);
@@ -499,12 +557,21 @@ int vxrt_render(vxrt_ctx* c, uint32_t flags) {
 
     if (flags & VXRT_TRACE) {
         const vxrt_uniforms& u = c->uniforms;
+        // next frame slot (never the temporal history) and the trace stream of this frame
+        int s = (c->slot + 1) % int(c->ring.size());
+        if (c->has_history && s == c->hist_slot) s = (s + 1) % int(c->ring.size());
+        const size_t lane = size_t(c->traced % uint64_t(c->inflight));
+        hipStream_t ts = c->trace_streams[lane];
+        vxrt_ctx::TileSchedule& sched = c->schedules[lane];
+        vxrt_ctx::Slot& slot = c->ring[size_t(s)];
+        if (slot.last_use_recorded) HIP_TRY(hipStreamWaitEvent(ts, slot.last_use, 0));
+
         TraceArgs a;
         a.svo = c->d_svo; a.leaves = c->d_leaves; a.noise = c->d_noise;
-        a.out_color = c->sampled_color; a.out_nd = c->nd[c->cur]; a.out_albedo = c->albedo;
+        a.out_color = slot.sampled_color; a.out_nd = slot.nd; a.out_albedo = slot.albedo;
         a.ray_counter = c->d_rays;
-        a.tile_order = (c->use_tile_order && c->tile_order_valid) ? c->d_tile_order : nullptr;
-        a.tile_cost = c->use_tile_order ? c->d_tile_cost : nullptr;
+        a.tile_order = (c->use_tile_order && sched.valid) ? sched.order : nullptr;
+        a.tile_cost = c->use_tile_order ? sched.cost : nullptr;
         memcpy(a.root_center, c->root_center, sizeof a.root_center);
         a.root_size = c->root_size;
         a.band = c->band;
@@ -526,42 +593,50 @@ int vxrt_render(vxrt_ctx* c, uint32_t flags) {
         a.sun_size = u.sun_size; a.sun_strength = u.sun_strength; a.emit_strength = u.emit_strength; a.specularity = u.specularity;
         if (c->band.local_rows > 0) {
             EventPair p;
-            if (timed) { p = take_pair(c, 0); HIP_TRY(hipEventRecord(p.a, c->stream)); }
+            if (timed) { p = take_pair(c, 0); HIP_TRY(hipEventRecord(p.a, ts)); }
             if (c->trace_variant == 0) {
-                HIP_TRY(launch_trace(a, c->stream));
-                if (c->use_tile_order) {  // schedule for the next frame (outside the timed kernel, ~4 us)
+                HIP_TRY(launch_trace(a, ts));
+                if (timed) HIP_TRY(hipEventRecord(p.b, ts));
+                if (c->use_tile_order) {  // schedule for this stream's next frame (after the timed kernel, ~7 us)
                     const unsigned tiles = unsigned((c->band.width + 15) / 16) * unsigned((c->band.local_rows + 15) / 16);
-                    if (timed) { HIP_TRY(hipEventRecord(p.b, c->stream)); }
-                    HIP_TRY(launch_tile_order(c->d_tile_cost, c->d_tile_order, c->d_tile_last_cost, tiles, c->stream));
-                    c->tile_order_valid = true;
+                    HIP_TRY(launch_tile_order(sched.cost, sched.order, sched.last_cost, tiles, ts));
+                    sched.valid = true;
                 }
             } else {
                 PathQueue queues[2] = {{c->d_queue[0], nullptr, c->shard_capacity}, {c->d_queue[1], nullptr, c->shard_capacity}};
                 unsigned* sets[3] = {c->d_counts, c->d_counts + 64 * 16, c->d_counts + 2 * 64 * 16};
-                HIP_TRY(launch_trace_wavefront(a, queues, sets, &c->wavefront_launches, c->trace_blocks, c->trace_split, c->stream));
+                HIP_TRY(launch_trace_wavefront(a, queues, sets, &c->wavefront_launches, c->trace_blocks, c->trace_split, ts));
+                if (timed) HIP_TRY(hipEventRecord(p.b, ts));
             }
-            if (timed) {
-                if (!(c->trace_variant == 0 && c->use_tile_order)) HIP_TRY(hipEventRecord(p.b, c->stream));
-                c->pending.push_back(p);
-            }
+            if (timed) c->pending.push_back(p);
         }
+        HIP_TRY(hipEventRecord(slot.trace_done, ts));
+        HIP_TRY(hipEventRecord(slot.last_use, ts));  // until a later stage reads the slot, the trace is its last use
+        slot.last_use_recorded = true;
+        c->slot = s;
+        c->last_schedule = int(lane);
+        c->traced += 1;
         c->frames += 1;
         c->pixels += uint64_t(c->band.local_rows) * c->band.width;
         if (timed) c->timed_frames += 1;
         c->accum_is_sampled = true;
-        c->last = c->cur;
         c->halo_valid = false;
     }
 
+    vxrt_ctx::Slot& cur = c->ring[size_t(c->slot)];
+    const bool post = (flags & (VXRT_TEMPORAL | VXRT_DENOISE)) != 0;
+    if (post && c->traced > 0) HIP_TRY(hipStreamWaitEvent(c->stream, cur.trace_done, 0));
+
     if (flags & VXRT_TEMPORAL) {
+        vxrt_ctx::Slot& hist = c->ring[size_t(c->hist_slot >= 0 ? c->hist_slot : c->slot)];
         TemporalArgs a;
-        a.sampled_color = c->sampled_color; a.new_nd = c->nd[c->cur];
-        a.old_color = c->accum[c->cur ^ 1]; a.old_nd = c->nd[c->cur ^ 1];
+        a.sampled_color = cur.sampled_color; a.new_nd = cur.nd;
+        a.old_color = c->accum[c->cur ^ 1]; a.old_nd = hist.nd;
         a.new_color = c->accum[c->cur];
         a.band = c->band;
         a.cam = c->cam;
         a.old_cam = c->old_cam;
-        a.has_history = (c->has_history && c->old_cam_valid) ? 1 : 0;
+        a.has_history = (c->has_history && c->old_cam_valid && c->hist_slot >= 0) ? 1 : 0;
         memset(a.inv, 0, sizeof a.inv);
         if (a.has_history) affine_inverse(c->old_cam, a.inv);
         a.sample_blending = c->temporal.sample_blending;
@@ -573,18 +648,23 @@ int vxrt_render(vxrt_ctx* c, uint32_t flags) {
             HIP_TRY(launch_temporal(a, c->stream));
             if (timed) { HIP_TRY(hipEventRecord(p.b, c->stream)); c->pending.push_back(p); }
         }
+        if (c->hist_slot >= 0 && c->hist_slot != c->slot) {  // the old history slot may be traced into again after this
+            HIP_TRY(hipEventRecord(hist.last_use, c->stream));
+            hist.last_use_recorded = true;
+        }
         c->accum_is_sampled = false;
         c->last = c->cur;
         c->cur ^= 1;  // hand the G-buffer over: what was written becomes the history (src/context.rs:2041-2043)
+        c->hist_slot = c->slot;
         c->has_history = true;
     }
     if (flags & VXRT_TRACE) c->old_cam_valid = true;  // the next frame's "old" camera is this frame's
 
     if (flags & VXRT_DENOISE) {
         DenoiseArgs a;
-        a.colors = c->accum_is_sampled ? c->sampled_color : c->accum[c->last];
-        a.nd = c->nd[c->last];
-        a.albedo = c->albedo;
+        a.colors = c->accum_is_sampled ? cur.sampled_color : c->accum[c->last];
+        a.nd = cur.nd;
+        a.albedo = cur.albedo;
         a.output = c->denoised;
         a.halo = (multi && c->denoise.radius > 0) ? c->halo : nullptr;
         a.band = c->band;
@@ -600,22 +680,26 @@ int vxrt_render(vxrt_ctx* c, uint32_t flags) {
             if (timed) { HIP_TRY(hipEventRecord(p.b, c->stream)); c->pending.push_back(p); }
         }
     }
+    if (post) {
+        HIP_TRY(hipEventRecord(cur.last_use, c->stream));
+        cur.last_use_recorded = true;
+    }
     return VXRT_OK;
 }
 
 int vxrt_sync(vxrt_ctx* c) {
     if (!valid_ctx(c)) return VXRT_E_INVALID;
     HIP_TRY(hipSetDevice(c->cfg.device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc = sync_all(c)) return rc;
     return resolve_events(c);
 }
 
 static float4* image_ptr(vxrt_ctx* c, vxrt_image which) {
     switch (which) {
-        case VXRT_SAMPLED_COLOR: return c->sampled_color;
-        case VXRT_NORMAL_DEPTH: return c->nd[c->last];
-        case VXRT_ALBEDO_NODE: return c->albedo;
-        case VXRT_ACCUM_COLOR: return c->accum_is_sampled ? c->sampled_color : c->accum[c->last];
+        case VXRT_SAMPLED_COLOR: return c->ring[size_t(c->slot)].sampled_color;
+        case VXRT_NORMAL_DEPTH: return c->ring[size_t(c->slot)].nd;
+        case VXRT_ALBEDO_NODE: return c->ring[size_t(c->slot)].albedo;
+        case VXRT_ACCUM_COLOR: return c->accum_is_sampled ? c->ring[size_t(c->slot)].sampled_color : c->accum[c->last];
         case VXRT_DENOISED: return c->denoised;
         default: return nullptr;
     }
@@ -627,7 +711,7 @@ int vxrt_read(vxrt_ctx* c, vxrt_image which, float* dst, size_t bytes) {
     if (!src || !dst) { set_error("bad image or null destination"); return VXRT_E_INVALID; }
     if (bytes != image_bytes(c)) { set_error("vxrt_read: bytes must equal local_rows*width*16"); return VXRT_E_INVALID; }
     HIP_TRY(hipSetDevice(c->cfg.device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc = sync_all(c)) return rc;
     if (bytes) HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return VXRT_OK;
 }
@@ -690,10 +774,10 @@ int vxrt_reset_stats(vxrt_ctx* c) {
 int vxrt_debug_tile_costs(vxrt_ctx* c, uint32_t* out, size_t n) {
     if (!valid_ctx(c) || !out) { set_error("null argument"); return VXRT_E_INVALID; }
     const size_t tiles = size_t((c->band.width + 15) / 16) * size_t((c->band.local_rows + 15) / 16);
-    if (n != tiles || !c->d_tile_last_cost) { set_error("tile count mismatch"); return VXRT_E_INVALID; }
+    if (n != tiles || c->schedules.empty()) { set_error("tile count mismatch"); return VXRT_E_INVALID; }
     HIP_TRY(hipSetDevice(c->cfg.device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(out, c->d_tile_last_cost, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (int rc = sync_all(c)) return rc;
+    HIP_TRY(hipMemcpy(out, c->schedules[size_t(c->last_schedule)].last_cost, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return VXRT_OK;
 }
 
@@ -718,7 +802,9 @@ int vxrt_halo_export(vxrt_ctx* c, void* dev_to_prev, void* dev_to_next) {
     if (b.nranks < 2 || r == 0) return VXRT_OK;
     if (!dev_to_prev || !dev_to_next) { set_error("null halo buffer"); return VXRT_E_INVALID; }
     HIP_TRY(hipSetDevice(c->cfg.device));
-    const float4* imgs[3] = {c->accum_is_sampled ? c->sampled_color : c->accum[c->last], c->nd[c->last], c->albedo};
+    const vxrt_ctx::Slot& cur = c->ring[size_t(c->slot)];
+    if (c->traced > 0) HIP_TRY(hipStreamWaitEvent(c->stream, cur.trace_done, 0));
+    const float4* imgs[3] = {c->accum_is_sampled ? cur.sampled_color : c->accum[c->last], cur.nd, cur.albedo};
     const size_t row_bytes = size_t(b.width) * sizeof(float4);
     const int nlb = local_band_count(b);
     for (int lb = 0; lb < nlb; lb++) {

@@ -94,6 +94,10 @@ typedef struct vxrt_config {
     uint32_t rank, nranks;    /* this context renders the row bands b with b % nranks == rank ...       */
     uint32_t band_rows;       /* ... where band b = rows [b*band_rows, (b+1)*band_rows); 0 -> 16.       */
                               /* nranks = 0 or 1 -> the whole frame                                     */
+    uint32_t frames_in_flight;/* 0/1: every stage of a frame runs in submission order on one stream (the
+                                 reference's single queue).  F = 2..8: the TRACE stage of up to F consecutive
+                                 frames may run concurrently (one HIP stream each, ring of F+2 G-buffer slots);
+                                 temporal/denoise still run in frame order.  Results are identical.       */
 } vxrt_config;
 
 typedef enum vxrt_image {

@@ -160,3 +160,36 @@ def test_errors_through_the_abi(H, scenes):
         Context(0, 10)
     with pytest.raises(VxrtError):
         Context(64, 64, max_bounces=0)
+
+
+@pytest.mark.parametrize("inflight", [2, 3, 4])
+def test_frames_in_flight_give_identical_frames(O, H, scenes, noise, inflight):
+    """frames_in_flight > 1 lets the trace stage of consecutive frames overlap on separate streams (ring of
+    G-buffer slots, temporal/denoise still in frame order): every frame must equal the serial pipeline's."""
+    from gpu_voxel_raytracer_amd import ALL, TRACE, Camera, Context
+    w, h, bounces, radius = 144, 96, 4, 2
+    ref = OraclePipeline(O, scenes, noise, "castle", w, h, bounces, radius)
+    pos, mrgb, size = scenes.load_scene("castle")
+    p0, d0, fov = scenes.close_camera(size)
+    with Context(w, h, max_bounces=bounces, noise=noise, frames_in_flight=inflight) as ctx:
+        ctx.recreate_octree(pos, mrgb)
+        ctx.denoise_uniforms.radius = radius
+        # several frames are submitted before anything is read back, so they really are in flight together
+        cams = [(p0 + np.float32(0.02 * f) * np.array([1, 0, 0.3], np.float32), d0, fov) for f in range(7)]
+        want = [ref.render(cam) for cam in cams]
+        for f, cam in enumerate(cams):
+            ctx.camera = Camera(*cam)
+            ctx.render(ALL)
+            if f in (2, 5, 6):     # read-back points
+                for img, wimg, label in zip(range(5), want[f], ("colour", "nd", "albedo", "accum", "denoised")):
+                    assert_bits_equal(ctx.read(img), wimg, f"{label} frame {f + 1} inflight {inflight}")
+        # trace-only frames must not disturb the temporal history: 5 of them wrap the slot ring completely
+        hist = ctx.read(3)
+        for _ in range(5):
+            ctx.render(TRACE)
+            ref.frame += 1
+        ctx.render(ALL)
+        wanted = ref.render(cams[-1])
+        assert_bits_equal(ctx.read(3), wanted[3], "accum after trace-only frames")
+        assert_bits_equal(ctx.read(4), wanted[4], "denoised after trace-only frames")
+        assert not np.array_equal(hist, ctx.read(3))
