@@ -27,6 +27,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Frames in flight run on separate HIP streams; the ROCm runtime maps streams onto 4 hardware queues unless told
+# otherwise, which would cap the overlap at 4 kernels.  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 WIDTH, HEIGHT, BOUNCES, SCENE = 1920, 1080, 4, "menger"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -80,7 +83,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--view", default="bench", choices=["bench", "close"])
     ap.add_argument("--bounces", type=int, default=BOUNCES, help="diagnostic only; the benchmark is 4")
-    ap.add_argument("--inflight", type=int, default=3, help="frames whose trace stage may be on the GPU together")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="frames whose trace stage may be on the GPU together (default: 4 on one GPU, 8 per rank otherwise)")
     args = ap.parse_args()
     BOUNCES = args.bounces
 
@@ -106,6 +110,9 @@ def main():
             dist.init_process_group(backend)
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
+    if args.inflight <= 0:
+        # a rank that owns 1/N of the rows has 1/N of the work per frame but the same longest tile: more frames in flight
+        args.inflight = 4 if world == 1 else 8
     from gpu_voxel_raytracer_amd import Camera, Context, TIMED, TRACE, scenes
 
     pos, mrgb, size = scenes.load_scene(SCENE)
@@ -122,14 +129,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        ctx.render(TRACE)
+    ctx.render_frames(TRACE, args.warmup)
     barrier()
     ctx.reset_stats()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ctx.render(TRACE | TIMED)
+    ctx.render_frames(TRACE | TIMED, args.steps)   # K steps = K frames, submitted back to back
     ctx.sync()
     if dist is not None:
         torch.cuda.synchronize()

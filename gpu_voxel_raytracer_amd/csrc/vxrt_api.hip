@@ -107,6 +107,7 @@ struct vxrt_ctx {
         uint32_t* order = nullptr;
         uint32_t* last_cost = nullptr;  // copy for diagnostics (vxrt_debug_tile_costs)
         bool valid = false;
+        int age = 0;  // frames traced since the last sort
     };
     std::vector<TileSchedule> schedules;
     int last_schedule = 0;
@@ -396,7 +397,7 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) {
     c->inflight = cfg->frames_in_flight == 0 ? 1 : int(cfg->frames_in_flight);
     if (const char* v = getenv("VXRT_INFLIGHT")) c->inflight = atoi(v);
     if (const char* v = getenv("VXRT_TRACE_VARIANT")) c->trace_variant = atoi(v);
-    if (c->inflight < 1 || c->inflight > 8) { set_error("frames_in_flight must be 1..8"); return fail(VXRT_E_INVALID); }
+    if (c->inflight < 1 || c->inflight > 16) { set_error("frames_in_flight must be 1..16"); return fail(VXRT_E_INVALID); }
     if (c->trace_variant != 0) c->inflight = 1;  // the wavefront variant shares its queues between frames
     c->trace_streams.assign(size_t(c->inflight), nullptr);
     if (c->inflight == 1) {
@@ -597,11 +598,15 @@ int vxrt_render(vxrt_ctx* c, uint32_t flags) {
             if (c->trace_variant == 0) {
                 HIP_TRY(launch_trace(a, ts));
                 if (timed) HIP_TRY(hipEventRecord(p.b, ts));
-                if (c->use_tile_order) {  // schedule for this stream's next frame (after the timed kernel, ~7 us)
+                // Re-sort the tiles for this stream's coming frames from the costs just measured: after its first
+                // frame, then every 8th (costs keep accumulating as a running maximum in between; ~7 us per sort).
+                if (c->use_tile_order && (!sched.valid || sched.age >= 8)) {
                     const unsigned tiles = unsigned((c->band.width + 15) / 16) * unsigned((c->band.local_rows + 15) / 16);
                     HIP_TRY(launch_tile_order(sched.cost, sched.order, sched.last_cost, tiles, ts));
                     sched.valid = true;
+                    sched.age = 0;
                 }
+                sched.age++;
             } else {
                 PathQueue queues[2] = {{c->d_queue[0], nullptr, c->shard_capacity}, {c->d_queue[1], nullptr, c->shard_capacity}};
                 unsigned* sets[3] = {c->d_counts, c->d_counts + 64 * 16, c->d_counts + 2 * 64 * 16};
@@ -684,6 +689,12 @@ int vxrt_render(vxrt_ctx* c, uint32_t flags) {
         HIP_TRY(hipEventRecord(cur.last_use, c->stream));
         cur.last_use_recorded = true;
     }
+    return VXRT_OK;
+}
+
+int vxrt_render_frames(vxrt_ctx* c, uint32_t flags, uint32_t count) {
+    for (uint32_t i = 0; i < count; i++)
+        if (int rc = vxrt_render(c, flags)) return rc;
     return VXRT_OK;
 }
 

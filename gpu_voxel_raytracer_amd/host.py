@@ -274,6 +274,11 @@ class Context:
         self.update_bindings()
         _check(lib().vxrt_render(self._h, C.c_uint32(flags)), "vxrt_render")
 
+    def render_frames(self, flags, count):
+        """`count` frames with the current camera and parameters in one call (vxrt_render_frames)."""
+        self.update_bindings()
+        _check(lib().vxrt_render_frames(self._h, C.c_uint32(flags), C.c_uint32(count)), "vxrt_render_frames")
+
     def render_stage(self, flags):
         """vxrt_render without re-pushing parameters (multi-GPU: DENOISE after the halo exchange)."""
         _check(lib().vxrt_render(self._h, C.c_uint32(flags)), "vxrt_render")

@@ -158,6 +158,8 @@ void vxrt_default_denoise(vxrt_denoise* d);     /* DenoiseUniforms::default(),  
  *      first (:2152), the selected stages run in the reference's order, then the G-buffer history
  *      is handed over (ping-pong instead of the copy at :2041-2043).  Asynchronous. ---------------- */
 int vxrt_render(vxrt_ctx* ctx, uint32_t flags);
+/* `count` consecutive frames with the parameters currently set (camera at rest): count x vxrt_render. */
+int vxrt_render_frames(vxrt_ctx* ctx, uint32_t flags, uint32_t count);
 int vxrt_sync(vxrt_ctx* ctx);
 int vxrt_reset_history(vxrt_ctx* ctx);          /* still_sample = 0 path, src/context.rs:1424 */
 int vxrt_set_frame_number(vxrt_ctx* ctx, uint32_t frame_number); /* next render uses frame_number+1 */

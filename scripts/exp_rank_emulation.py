@@ -1,0 +1,19 @@
+"""Predict the N-GPU trace-stage frame time on one GPU: run each rank's band set alone and take the slowest."""
+import sys, time
+sys.path.insert(0, '.')
+from gpu_voxel_raytracer_amd import Context, Camera, TRACE, scenes
+W, H = 1920, 1080
+pos, mrgb, size = scenes.load_scene("menger")
+cam = scenes.bench_camera(size)
+import os
+for nranks in [int(v) for v in os.environ.get('RANKS', '1,2,4,8').split(',')]:
+    for infl in [int(v) for v in os.environ.get('INFL', '3,6,8').split(',')]:
+        worst, total_rays = 0.0, 0
+        for rank in range(nranks):
+            with Context(W, H, max_bounces=4, rank=rank, nranks=nranks, frames_in_flight=infl) as ctx:
+                ctx.recreate_octree(pos, mrgb); ctx.camera = Camera(*cam)
+                ctx.render_frames(TRACE, 50); ctx.sync(); ctx.reset_stats()
+                n = 400
+                t0 = time.perf_counter(); ctx.render_frames(TRACE, n); ctx.sync(); dt = (time.perf_counter() - t0) / n
+                worst = max(worst, dt); total_rays += ctx.stats().rays / n
+        print(f"nranks={nranks} inflight={infl}: slowest rank {worst * 1e3:.4f} ms/frame -> {total_rays / worst / 1e9:.1f} Gray/s aggregate")
