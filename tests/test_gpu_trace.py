@@ -169,3 +169,106 @@ def test_tile_cost_feedback(H, scenes, noise):
         hit = (ctx.read(1)[..., 3] >= 0).reshape(h // 16, 16, w // 16, 16).any(axis=(1, 3)).ravel()
         assert (cost > 0).all() and hit.any() and (~hit).any()
         assert np.median(cost[hit]) > 2 * np.median(cost[~hit])     # tiles that see geometry take longer than sky tiles
+
+
+def _render_voxels(O, noise, pos, mrgb, cam, w, h, bounces, frames=(1,)):
+    from gpu_voxel_raytracer_amd import Context, Camera, TRACE
+    octree = O.create_octree(pos, mrgb)
+    u = O.Uniforms.default()
+    u.set_camera(cam[0], O.camera_axis_scaled(cam[0], cam[1], cam[2], w, h))
+    out = []
+    with Context(w, h, max_bounces=bounces, noise=noise) as ctx:
+        ctx.recreate_octree(pos, mrgb)
+        ctx.camera = Camera(*cam)
+        for f in frames:
+            ctx.set_frame_number(f - 1)
+            ctx.reset_stats()
+            ctx.render(TRACE)
+            got = [ctx.read(i) for i in range(3)]
+            u.frame_number = f
+            ref = O.trace(octree, noise, u, w, h, bounces, crop=(0, 0, w, h))
+            out.append((got, ctx.stats().rays, ref))
+    return out
+
+
+def test_empty_scene_and_single_voxel(O, H, noise):
+    """Edge cases of the scene format: no voxels at all (root node of eight empty slots, depth 0) and one voxel."""
+    f32 = np.float32
+    cam = (np.array([3, 2, -4], f32), np.array([-3, -2, 4], f32), 1.0)
+    for pos, mrgb in ((np.zeros((0, 3), np.int16), np.zeros((0, 4), np.uint8)),
+                      (np.array([[0, 0, 0]], np.int16), np.array([[0x40, 200, 100, 50]], np.uint8)),
+                      (np.array([[-1, -1, -1]], np.int16), np.array([[0, 1, 2, 3]], np.uint8))):
+        for (g, rays, ref) in _render_voxels(O, noise, pos, mrgb, cam, 96, 64, 3):
+            for a, b, label in zip(g, ref[:3], ("colour", "nd", "albedo")):
+                assert_bits_equal(a, b, f"{label} n={len(pos)}")
+            assert rays == ref[3]
+            if len(pos) == 0:
+                assert (g[1][..., 3] == -1).all()
+
+
+def test_deep_octree_negative_coordinates_and_depth_limit(O, H, noise):
+    """Random voxels on both sides of the origin (all eight root octants used), a depth-10 tree, and the deepest
+    tree i16 coordinates allow (depth 15)."""
+    rng = np.random.default_rng(42)
+    f32 = np.float32
+    pos = rng.integers(-40, 40, (6000, 3)).astype(np.int16)
+    mrgb = rng.integers(0, 256, (6000, 4)).astype(np.uint8)
+    cam = (np.array([45, 30, -50], f32), np.array([-45, -30, 50], f32), 1.1)
+    for (g, rays, ref) in _render_voxels(O, noise, pos, mrgb, cam, 160, 96, 4, frames=(1, 7)):
+        for a, b, label in zip(g, ref[:3], ("colour", "nd", "albedo")):
+            assert_bits_equal(a, b, label)
+        assert rays == ref[3]
+    # depth 10: a bumpy slab of voxels far from the origin
+    xs, ys = np.meshgrid(np.arange(900, 960), np.arange(900, 960))
+    far = np.stack([xs.ravel(), ys.ravel(), 900 + (xs.ravel() * 7 + ys.ravel() * 3) % 5], 1).astype(np.int16)
+    far_m = np.tile(np.array([[0, 255, 128, 0]], np.uint8), (len(far), 1))
+    assert O.voxel_depth(far) == 10
+    cam = (np.array([462, 470, 438], f32), np.array([0.1, -0.25, 1.0], f32), 1.2)
+    for (g, rays, ref) in _render_voxels(O, noise, far, far_m, cam, 128, 96, 2):
+        assert_bits_equal(g[0], ref[0], "colour depth 10")
+        assert_bits_equal(g[1], ref[1], "nd depth 10")
+        assert (g[1][..., 3] >= 0).any()
+    # the extremes of i16 both give depth 15 = MAX_DEPTH - 1 pushes (voxels.comp:3): the deepest tree there is
+    for extreme in (32767, -32768):
+        p15 = np.array([[extreme, 3, -2], [0, 0, 0]], np.int16)
+        m15 = np.array([[0, 10, 200, 30], [0x40, 255, 255, 255]], np.uint8)
+        assert O.voxel_depth(p15) == 15
+        cam = (np.array([extreme / 2 + (3 if extreme > 0 else -3), 4, -6], f32), np.array([-0.5 if extreme > 0 else 0.5, -0.4, 1.0], f32), 0.9)
+        for (g, rays, ref) in _render_voxels(O, noise, p15, m15, cam, 64, 48, 3):
+            assert_bits_equal(g[0], ref[0], "colour depth 15")
+            assert_bits_equal(g[1], ref[1], "nd depth 15")
+            assert rays == ref[3]
+
+
+def test_zero_times_infinity_rays_through_the_gpu(O, H, scenes, noise):
+    """An axis-aligned camera on integer coordinates sends its centre rays exactly along +z through node mid-planes:
+    (center - origin) * (1/0) = 0 * inf = NaN in the shader (voxels.comp:140,191).  The kernel reproduces the
+    oracle's NaNs and everything around them."""
+    pos, mrgb, size = scenes.load_scene("8x8x8")
+    f32 = np.float32
+    cam = (np.array([1, 1, -5], f32), np.array([0, 0, 1], f32), 1.0)
+    for (g, rays, ref) in _render_voxels(O, noise, pos, mrgb, cam, 64, 64, 3):
+        assert np.isnan(ref[1][..., 3]).any() or np.isnan(ref[0]).any()      # the quirk really is exercised
+        for a, b, label in zip(g, ref[:3], ("colour", "nd", "albedo")):
+            assert_bits_equal(a, b, label)
+        assert rays == ref[3]
+
+
+def test_iteration_cap(O, H, noise):
+    """voxels.comp:166-169: after 2047 loop trips a ray "hits" with node = LEAF_BIT.  A depth-15 scene with a long
+    sparse row of voxels makes grazing rays exceed the cap on both sides identically."""
+    f32 = np.float32
+    n = 1500
+    pos = np.stack([np.arange(n) * 20, np.zeros(n), np.arange(n) % 2], 1).astype(np.int16)   # up to x = 29980: depth 15
+    mrgb = np.tile(np.array([[0, 90, 90, 90]], np.uint8), (n, 1))
+    octree = O.create_octree(pos, mrgb)
+    o = np.array([[-1.0, 0.26, 0.24]], f32)
+    d = np.array([[1.0, 1e-6, 2e-6]], f32); d /= np.linalg.norm(d)
+    hit, t, node, normal, iters = O.cast_rays(octree, o, d)
+    cam = (o[0], d[0], 0.02)
+    for (g, rays, ref) in _render_voxels(O, noise, pos, mrgb, cam, 48, 32, 2):
+        for a, b, label in zip(g, ref[:3], ("colour", "nd", "albedo")):
+            assert_bits_equal(a, b, label)
+        assert rays == ref[3]
+        capped = (ref[2][..., 3].view(np.uint32) == 0x80000000)
+    assert iters[0] < 2048 or node[0] == -2147483648
