@@ -6,9 +6,11 @@
 //                    80 algorithmic bytes per pixel (64 read + 16 written); the per-pixel
 //                    inverse(mat4) of the shader is hoisted to the host (one matrix per frame).
 //  denoise_kernel  : shaders/denoise.comp:24-93 — (2r+1)^2 cross-bilateral window.  A 16x16 block
-//                    stages its (16+2r)^2 apron once in LDS as 8 floats per pixel (rgb, normal,
-//                    log|depth|, material id), so a tap is LDS reads + ~45 flops + one exp instead
-//                    of three 16-byte global loads and two logs.
+//                    stages its (16+2r)^2 apron once in LDS as 8 floats per pixel (rgb, log|depth| ;
+//                    normal, material id), so a tap is two ds_read_b128 + ~45 flops + one exp instead
+//                    of three 16-byte global loads and two logs; the per-offset distance term comes
+//                    from a small LDS table; taps whose weight is exactly zero are skipped.
+//                    radius 0 (the default) is a separate streaming kernel.
 #include "kernels.h"
 #include "vx_vec.h"
 
@@ -102,29 +104,50 @@ __global__ __launch_bounds__(256) void temporal_kernel(const TemporalArgs a) {
     a.new_color[pix] = make_float4(blended.x, blended.y, blended.z, next_blending);
 }
 
-struct Tap {  // one staged pixel of the denoise apron: 32 bytes
-    float r, g, b, nx, ny, nz, logd;
-    int32_t mat;
-};
+// A staged pixel of the denoise apron is two float4 in two LDS arrays (each read is a conflict-free
+// ds_read_b128: consecutive lanes, consecutive 16-byte slots):
+//   A[i] = (r, g, b, log|depth|)      B[i] = (nx, ny, nz, bits(material id | flags))
+constexpr int32_t kTapOutside = 0x7fffffff;   // not a pixel of the frame: denoise.comp:57 skips the tap
+constexpr int32_t kTapNonFinite = 0x40000000; // colour holds an inf/NaN: its zero-weight taps may not be skipped
 
-// One 16x16 output tile per block.  R = max radius the LDS apron is sized for.
+__device__ __forceinline__ bool finite3(float4 c) {
+    return ((__float_as_uint(c.x) & 0x7f800000u) != 0x7f800000u) && ((__float_as_uint(c.y) & 0x7f800000u) != 0x7f800000u) &&
+           ((__float_as_uint(c.z) & 0x7f800000u) != 0x7f800000u);
+}
+
+// radius 0 (the reference's default): out = mix(c, albedo * c, albedo_factor), a pure stream.
+__global__ __launch_bounds__(256) void denoise_passthrough_kernel(const DenoiseArgs a) {
+    const size_t n = size_t(a.band.local_rows) * a.band.width;
+    const size_t pix = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (pix >= n) return;
+    const f3 cc = xyz(a.colors[pix]);
+    const f3 alb = xyz(a.albedo[pix]);
+    const f3 out = mix3(cc, alb * cc, a.albedo_factor);
+    a.output[pix] = make_float4(out.x, out.y, out.z, 1.0f);
+}
+
+// One 16x16 output tile per block, radius 1..8.
 __global__ __launch_bounds__(256) void denoise_kernel(const DenoiseArgs a) {
     extern __shared__ float4 lds_raw[];
-    Tap* tile = reinterpret_cast<Tap*>(lds_raw);
     const int r = int(a.radius);
-    const int tw = 16 + 2 * r;
+    const int tw = 16 + 2 * r, taps = 2 * r + 1;
+    float4* tileA = lds_raw;
+    float4* tileB = lds_raw + tw * tw;
+    float* wdist = reinterpret_cast<float*>(lds_raw + 2 * tw * tw);  // (dx*dx + dy*dy) / sigma_distance_2 per window offset
     const int x0 = blockIdx.x * 16 - r;
     const int lrow0 = blockIdx.y * 16;  // band_rows is a multiple of 16: a tile never straddles two bands
     const int y0 = frame_row(a.band, lrow0) - r;
     const int lband = lrow0 / a.band.band_rows;
     const int band_y0 = (lband * a.band.nranks + a.band.rank) * a.band.band_rows;  // first frame row of the band
 
+    for (int i = threadIdx.x; i < taps * taps; i += 256) {
+        const int dx = i % taps - r, dy = i / taps - r;
+        wdist[i] = float(dx * dx + dy * dy) / a.sigma_distance_2;   // denoise.comp:79
+    }
     for (int i = threadIdx.x; i < tw * tw; i += 256) {
         int tx = i % tw, ty = i / tw;
         int gx = x0 + tx, gy = y0 + ty;
-        Tap t;
-        t.r = t.g = t.b = t.nx = t.ny = t.nz = t.logd = 0.0f;
-        t.mat = int32_t(0x7fffffff);  // marks "outside the frame" (denoise.comp:57 skips the tap)
+        float4 ta = make_float4(0.0f, 0.0f, 0.0f, 0.0f), tb = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(kTapOutside));
         if (gx >= 0 && gx < a.band.width && gy >= 0 && gy < a.band.height) {
             int l = local_row(a.band, gy);
             float4 c, nd, al;
@@ -143,13 +166,14 @@ __global__ __launch_bounds__(256) void denoise_kernel(const DenoiseArgs a) {
                 have = false;
             }
             if (have) {
-                t.r = c.x; t.g = c.y; t.b = c.z;
-                t.nx = nd.x; t.ny = nd.y; t.nz = nd.z;
-                t.logd = vx_log(vx_abs(nd.w));
-                t.mat = __float_as_int(al.w) >> 24;
+                ta = make_float4(c.x, c.y, c.z, vx_log(vx_abs(nd.w)));                         // denoise.comp:66
+                int32_t mat = (__float_as_int(al.w) >> 24) & 0xff;                              // denoise.comp:67
+                if (!finite3(c)) mat |= kTapNonFinite;
+                tb = make_float4(nd.x, nd.y, nd.z, __int_as_float(mat));
             }
         }
-        tile[i] = t;
+        tileA[i] = ta;
+        tileB[i] = tb;
     }
     __syncthreads();
 
@@ -160,32 +184,41 @@ __global__ __launch_bounds__(256) void denoise_kernel(const DenoiseArgs a) {
     if (y >= a.band.height) return;
     const size_t pix = size_t(lrow) * a.band.width + x;
 
-    const Tap ct = tile[(ly + r) * tw + (lx + r)];
-    const f3 cc = mk3(ct.r, ct.g, ct.b), cn = mk3(ct.nx, ct.ny, ct.nz);
+    const float4 ca = tileA[(ly + r) * tw + (lx + r)], cb = tileB[(ly + r) * tw + (lx + r)];
+    const f3 cc = xyz(ca), cn = xyz(cb);
+    const float clogd = ca.w;
+    const int32_t cmat = __float_as_int(cb.w) & 0xff;
     const f3 ray_dir = pixel_dir(a.cam, x, y);
     const float depth_bias = vx_max(0.0f, dot3(cn, -ray_dir));
 
     float normalization = 0.0f;
     f3 sum = splat3(0.0f);
     for (int dy = -r; dy <= r; dy++) {
-        for (int dx = -r; dx <= r; dx++) {
-            const Tap w = tile[(ly + r + dy) * tw + (lx + r + dx)];
-            if (w.mat == int32_t(0x7fffffff)) continue;
-            f3 wc = mk3(w.r, w.g, w.b);
+        const float4* rowA = tileA + (ly + r + dy) * tw + lx;
+        const float4* rowB = tileB + (ly + r + dy) * tw + lx;
+        const float* rowW = wdist + (dy + r) * taps;
+        for (int dx = 0; dx < taps; dx++) {
+            const float4 wa = rowA[dx], wb = rowB[dx];
+            const int32_t wflags = __float_as_int(wb.w);
+            if (wflags == kTapOutside) continue;
+            f3 wc = xyz(wa);
             f3 color_delta = cc - wc;
-            f3 normal_delta = cn - mk3(w.nx, w.ny, w.nz);
-            float depth_delta = ct.logd - w.logd;
-            float material_delta = ct.mat != w.mat ? 1.0f : 0.0f;
+            f3 normal_delta = cn - xyz(wb);
+            float depth_delta = clogd - wa.w;
+            float material_delta = cmat != (wflags & 0xff) ? 1.0f : 0.0f;
             float bd = depth_bias * depth_delta;
             float factor_range = (((dot3(color_delta, color_delta) + 1e4f * dot3(normal_delta, normal_delta)) + 1e4f * (bd * bd)) +
                                   1e4f * material_delta) / a.sigma_range_2;
-            float factor_distance = float(dx * dx + dy * dy) / a.sigma_distance_2;
-            float factor = vx_exp(-factor_range - factor_distance);
+            float arg = -factor_range - rowW[dx];
+            // exp(arg) is exactly +0 below -87.3 (vx_exp): such a tap adds +0 to the weight sum and colour * 0 to the
+            // colour sum — nothing, unless the colour is inf/NaN (then 0 * colour = NaN must still poison the sum)
+            if (arg < -87.3f && !(wflags & kTapNonFinite)) continue;
+            float factor = vx_exp(arg);
             normalization += factor;
             sum = sum + wc * factor;
         }
     }
-    f3 out = a.radius == 0u ? cc : sum / normalization;
+    f3 out = sum / normalization;
     f3 alb = xyz(a.albedo[pix]);
     out = mix3(out, alb * out, a.albedo_factor);
     a.output[pix] = make_float4(out.x, out.y, out.z, 1.0f);
@@ -235,9 +268,14 @@ hipError_t launch_temporal(const TemporalArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_denoise(const DenoiseArgs& a, hipStream_t s) {
+    if (a.radius == 0u) {
+        const size_t n = size_t(a.band.local_rows) * a.band.width;
+        hipLaunchKernelGGL(denoise_passthrough_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     dim3 grid((a.band.width + 15) / 16, (a.band.local_rows + 15) / 16);
-    int tw = 16 + 2 * int(a.radius);
-    size_t lds = size_t(tw) * tw * sizeof(Tap);
+    int tw = 16 + 2 * int(a.radius), taps = 2 * int(a.radius) + 1;
+    size_t lds = size_t(tw) * tw * 32 + size_t(taps * taps + 3) / 4 * 16;
     hipLaunchKernelGGL(denoise_kernel, grid, dim3(256), lds, s, a);
     return hipGetLastError();
 }

@@ -121,7 +121,6 @@ __device__ __forceinline__ bool cast_ray(const SceneView& sc, f3 o, f3 d, float 
                     has_next_mask |= 1u << lvl;
                 }
                 raw = *reinterpret_cast<const uint2*>(sc.svo + (rec.base + __popc(rec.masks & (bit - 1u))));
-                asm volatile("" : "+v"(raw.x), "+v"(raw.y));  // keep this a global_load (no merge with the LDS read into a flat_load)
                 ix = (ix << 1) | ((octant >> 2) & 1u);
                 iy = (iy << 1) | ((octant >> 1) & 1u);
                 iz = (iz << 1) | (octant & 1u);
@@ -134,6 +133,8 @@ __device__ __forceinline__ bool cast_ray(const SceneView& sc, f3 o, f3 d, float 
                 ix >>= up; iy >>= up; iz >>= up;
                 lvl = l;
                 raw = stack[l * kBlock];
+                // consume the LDS read here: left alone, the compiler merges it with the descend branch's global
+                // load into one flat_load (either address space), which is slower and waits on both counters
                 asm volatile("" : "+v"(raw.x), "+v"(raw.y));
             }
             size = __builtin_ldexpf(sc.root_size, -int(lvl));
