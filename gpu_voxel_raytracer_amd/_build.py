@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvxrt.so")
-SOURCES = ["vxrt_api.hip", "trace.hip", "post.hip", "scene_host.cpp"]
+SOURCES = ["vxrt_api.hip", "trace.hip", "post.hip", "scene_host.cpp", "scene_procedural.cpp"]
 HEADERS = ["kernels.h", "scene_host.h", "vx_vec.h", os.path.join("..", "..", "include", "vxrt.h"),
            os.path.join("..", "..", "include", "vxrt_detmath.h")]
 

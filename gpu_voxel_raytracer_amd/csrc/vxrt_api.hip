@@ -18,6 +18,9 @@
 
 namespace vxrt {
 const std::string& last_error();
+int build_menger_svo(uint32_t level, uint32_t clip, const uint8_t mrgb[4], uint32_t emissive_period, std::vector<SvoRecord>* recs,
+                     std::vector<int32_t>* leaves, uint32_t* depth_out);
+int32_t procedural_leaf_word(uint32_t x, uint32_t y, uint32_t z, const uint8_t mrgb[4], uint32_t emissive_period);
 }
 using namespace vxrt;
 
@@ -293,14 +296,8 @@ int flatten_svo(const Octree& tree, std::vector<SvoRecord>* recs, std::vector<in
     return VXRT_OK;
 }
 
-int upload_scene(vxrt_ctx* c, const Voxel* voxels, size_t n) {
-    Octree tree;
-    if (int rc = build_octree(voxels, n, &tree)) return rc;
-    std::vector<SvoRecord> recs;
-    std::vector<int32_t> leaves;
-    if (int rc = flatten_svo(tree, &recs, &leaves)) return rc;
+int upload_svo(vxrt_ctx* c, std::vector<SvoRecord>& recs, std::vector<int32_t>& leaves, uint32_t depth) {
     if (leaves.empty()) leaves.push_back(0);
-
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = sync_all(c)) return rc;
     if (c->d_svo) (void)hipFree(c->d_svo);
@@ -313,13 +310,20 @@ int upload_scene(vxrt_ctx* c, const Voxel* voxels, size_t n) {
     HIP_TRY(hipMemcpy(c->d_leaves, leaves.data(), leaves.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     c->svo_count = recs.size();
     c->leaf_count = leaves.size();
-    float hdr[5];
-    memcpy(hdr, tree.words.data(), sizeof hdr);
-    c->root_center[0] = hdr[0]; c->root_center[1] = hdr[1]; c->root_center[2] = hdr[2];
-    c->root_size = hdr[3];
-    c->depth = tree.depth;
+    c->root_center[0] = c->root_center[1] = c->root_center[2] = 0.0f;  // src/context.rs:782-786
+    c->root_size = float(1u << depth);                                   // src/context.rs:779
+    c->depth = depth;
     c->has_scene = true;
     return VXRT_OK;
+}
+
+int upload_scene(vxrt_ctx* c, const Voxel* voxels, size_t n) {
+    Octree tree;
+    if (int rc = build_octree(voxels, n, &tree)) return rc;
+    std::vector<SvoRecord> recs;
+    std::vector<int32_t> leaves;
+    if (int rc = flatten_svo(tree, &recs, &leaves)) return rc;
+    return upload_svo(c, recs, leaves, tree.depth);
 }
 
 bool valid_ctx(const vxrt_ctx* c) {
@@ -920,10 +924,12 @@ int vxrt_noise_table(uint32_t seed, float* out, size_t n) {
     return VXRT_OK;
 }
 
-int vxrt_menger_voxels(uint32_t level, const uint8_t mrgb[4], int16_t (*pos)[3], uint8_t (*out_mrgb)[4], size_t cap, size_t* n) {
+int vxrt_menger_voxels_ex(uint32_t level, uint32_t clip, const uint8_t mrgb[4], uint32_t emissive_period, int16_t (*pos)[3],
+                          uint8_t (*out_mrgb)[4], size_t cap, size_t* n) {
     if (!n || !mrgb || level > 9) { set_error("bad argument"); return VXRT_E_INVALID; }
     uint32_t side = 1;
     for (uint32_t l = 0; l < level; l++) side *= 3;
+    if (clip != 0 && clip < side) side = clip;
     if (side > 32767) { set_error("menger side exceeds i16"); return VXRT_E_INVALID; }
     size_t count = 0;
     for (uint32_t x = 0; x < side; x++)
@@ -932,12 +938,33 @@ int vxrt_menger_voxels(uint32_t level, const uint8_t mrgb[4], int16_t (*pos)[3],
                 if (menger_solid(level, x, y, z)) {
                     if (count < cap) {
                         if (pos) { pos[count][0] = int16_t(x); pos[count][1] = int16_t(y); pos[count][2] = int16_t(z); }
-                        if (out_mrgb) memcpy(out_mrgb[count], mrgb, 4);
+                        if (out_mrgb) {
+                            const int32_t w = procedural_leaf_word(x, y, z, mrgb, emissive_period);
+                            out_mrgb[count][0] = uint8_t((uint32_t(w) >> 24) & 0x7fu);
+                            out_mrgb[count][1] = mrgb[1]; out_mrgb[count][2] = mrgb[2]; out_mrgb[count][3] = mrgb[3];
+                        }
                     }
                     count++;
                 }
     *n = count;
     return VXRT_OK;
+}
+
+int vxrt_menger_voxels(uint32_t level, const uint8_t mrgb[4], int16_t (*pos)[3], uint8_t (*out_mrgb)[4], size_t cap, size_t* n) {
+    return vxrt_menger_voxels_ex(level, 0, mrgb, 0, pos, out_mrgb, cap, n);
+}
+
+int vxrt_set_menger(vxrt_ctx* c, uint32_t level, uint32_t clip, const uint8_t mrgb[4], uint32_t emissive_period) {
+    if (!valid_ctx(c)) return VXRT_E_INVALID;
+    if (!mrgb) { set_error("null colour"); return VXRT_E_INVALID; }
+    uint32_t side = 1;
+    for (uint32_t l = 0; l < level && l < 10; l++) side *= 3;
+    if (clip == 0 || clip > side) clip = side;
+    std::vector<SvoRecord> recs;
+    std::vector<int32_t> leaves;
+    uint32_t depth = 0;
+    if (int rc = build_menger_svo(level, clip, mrgb, emissive_period, &recs, &leaves, &depth)) return rc;
+    return upload_svo(c, recs, leaves, depth);
 }
 
 // device-vs-host bit equality probe of include/vxrt_detmath.h (test hook; host arrays in and out)

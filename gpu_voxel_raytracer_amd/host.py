@@ -175,15 +175,15 @@ def noise_table(seed=DEFAULT_NOISE_SEED, n=NOISE_LEN):
     return out
 
 
-def menger_voxels(level, mrgb=(0, 0xb0, 0xd0, 0x60)):
+def menger_voxels(level, mrgb=(0, 0xb0, 0xd0, 0x60), clip=0, emissive_period=0):
+    """Voxel list of the (clipped) level-`level` Menger sponge; the list form of Context.set_menger's scene."""
     m = np.asarray(mrgb, np.uint8)
     n = C.c_size_t(0)
-    _check(lib().vxrt_menger_voxels(C.c_uint32(level), _p(m), None, None, C.c_size_t(0), C.byref(n)),
-           "vxrt_menger_voxels")
+    args = (C.c_uint32(level), C.c_uint32(clip), _p(m), C.c_uint32(emissive_period))
+    _check(lib().vxrt_menger_voxels_ex(*args, None, None, C.c_size_t(0), C.byref(n)), "vxrt_menger_voxels_ex")
     pos = np.zeros((n.value, 3), np.int16)
     out = np.zeros((n.value, 4), np.uint8)
-    _check(lib().vxrt_menger_voxels(C.c_uint32(level), _p(m), _p(pos), _p(out), C.c_size_t(n.value), C.byref(n)),
-           "vxrt_menger_voxels")
+    _check(lib().vxrt_menger_voxels_ex(*args, _p(pos), _p(out), C.c_size_t(n.value), C.byref(n)), "vxrt_menger_voxels_ex")
     return pos, out
 
 
@@ -247,6 +247,12 @@ class Context:
         if pos.shape != (len(pos), 3) or mrgb.shape != (len(pos), 4):
             raise ValueError("pos must be [n,3] int16 and mrgb [n,4] uint8")
         _check(lib().vxrt_set_voxels(self._h, _p(pos), _p(mrgb), C.c_size_t(len(pos))), "vxrt_set_voxels")
+
+    def set_menger(self, level, clip=0, mrgb=(0, 0xb0, 0xd0, 0x60), emissive_period=0):
+        """Procedural Menger sponge built straight into the device scene format (BASELINE config 5)."""
+        m = np.asarray(mrgb, np.uint8)
+        _check(lib().vxrt_set_menger(self._h, C.c_uint32(level), C.c_uint32(clip), _p(m), C.c_uint32(emissive_period)),
+               "vxrt_set_menger")
 
     def load_vox(self, path):
         _check(lib().vxrt_load_vox(self._h, os.fsencode(path)), "vxrt_load_vox")

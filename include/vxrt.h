@@ -199,6 +199,14 @@ int vxrt_noise_table(uint32_t seed, float* out, size_t n);
  * level 4 reproduces the voxel set of vox/menger.vox). */
 int vxrt_menger_voxels(uint32_t level, const uint8_t mrgb[4], int16_t (*pos)[3], uint8_t (*out_mrgb)[4], size_t cap,
                        size_t* n);
+/* The same sponge clipped to [0, clip)^3 (0 = no clip) with every voxel whose hash(x,y,z) % emissive_period == 0
+ * marked emissive (0 = none): the voxel-list form of the scene vxrt_set_menger builds procedurally. */
+int vxrt_menger_voxels_ex(uint32_t level, uint32_t clip, const uint8_t mrgb[4], uint32_t emissive_period, int16_t (*pos)[3],
+                          uint8_t (*out_mrgb)[4], size_t cap, size_t* n);
+/* BASELINE config 5: builds that scene straight into the device format without a voxel list
+ * or a reference-layout octree (level 7 clipped to 2048: ~1.05e9 voxels, 1.2 GB of nodes + 4.2 GB of leaf words).
+ * The tree equals the one create_octree (src/context.rs:777-796) would build from the voxel list. */
+int vxrt_set_menger(vxrt_ctx* ctx, uint32_t level, uint32_t clip, const uint8_t mrgb[4], uint32_t emissive_period);
 
 /* Test hook: evaluates function `fn` of include/vxrt_detmath.h on the device for host arrays x, y
  * (0 sin, 1 cos, 2 exp, 3 log, 4 pow, 5 sqrt, 6 div, 7 tan, 8 normalize/cross/dot chain) so that the
