@@ -1,0 +1,98 @@
+"""Headless frame loop: what src/main.rs + Context::update/render do interactively, without
+the window — a camera path, N frames of trace -> temporal -> denoise, and image dumps.
+
+    python -m gpu_voxel_raytracer_amd.frame_loop --scene menger --frames 32 --radius 2 --out gpurun_out/menger
+
+Scenes: a fixture name (tests/golden/scenes/*.npz), a .vox file, or `menger:<level>[:clip[:emissive_period]]`.
+The reference shows `denoised_color` through an sRGB swap chain without tone mapping (shaders/display.frag,
+src/context.rs:1352-1403); the PNGs are written the same way (clamp to [0,1], sRGB encode)."""
+import argparse
+import os
+
+import numpy as np
+
+from . import ALL, DENOISED, Camera, Context, scenes
+
+
+def orbit_camera(size_xyz, t, radius_scale=1.5, height=0.6, fov=scenes.FOV_70):
+    """Camera on a circle around the model centre, t in [0,1) = one revolution (a stand-in for the reference's
+    WASD fly camera, src/context.rs:1959-2001)."""
+    ext = scenes.world_extent(size_xyz)
+    c = ext * np.float32(0.5)
+    e = np.float32(ext.max())
+    a = np.float32(2 * np.pi * t)
+    position = (c + e * np.array([radius_scale * np.cos(a), height, radius_scale * np.sin(a)], np.float32)).astype(np.float32)
+    return position, (c - position).astype(np.float32), fov
+
+
+def srgb8(rgb):
+    """Linear -> 8-bit sRGB, as a Bgra8UnormSrgb swap chain stores it (src/context.rs:696-706)."""
+    x = np.clip(np.nan_to_num(rgb, nan=0.0, posinf=1.0, neginf=0.0), 0.0, 1.0)
+    y = np.where(x <= 0.0031308, 12.92 * x, 1.055 * np.power(x, 1 / 2.4) - 0.055)
+    return (y * 255.0 + 0.5).astype(np.uint8)
+
+
+def load_into(ctx, scene):
+    """Returns the model size (x, y, z in file axes) used for camera placement."""
+    if scene.startswith("menger:"):
+        parts = [int(p) for p in scene.split(":")[1:]] + [0, 0]
+        level, clip, period = parts[0], parts[1], parts[2]
+        ctx.set_menger(level, clip, (0, 0x7b, 0xa2, 0x3f), period)
+        side = min(3 ** level, clip or 3 ** level)
+        return (side, side, side)
+    if os.path.exists(scene):
+        from . import host
+        data = open(scene, "rb").read()
+        pos, mrgb, size = host.vox_to_voxels(data)
+        ctx.recreate_octree(pos, mrgb)
+        return size
+    pos, mrgb, size = scenes.load_scene(scene)
+    ctx.recreate_octree(pos, mrgb)
+    return size
+
+
+def run(scene="menger", width=1280, height=720, frames=16, bounces=3, radius=0, moving=False, out=None, device=0,
+        frames_in_flight=1, dump_every=0):
+    """Renders `frames` frames; returns the last denoised frame (float32 [h, w, 4]) and the context statistics."""
+    with Context(width, height, device=device, max_bounces=bounces, frames_in_flight=frames_in_flight) as ctx:
+        size = load_into(ctx, scene)
+        ctx.denoise_uniforms.radius = radius
+        for f in range(frames):
+            t = (f / max(frames, 1)) * 0.25 if moving else 0.0
+            ctx.camera = Camera(*orbit_camera(size, 0.62 + t))
+            ctx.render(ALL)
+            if out and dump_every and (f + 1) % dump_every == 0:
+                save_png(ctx.read(DENOISED), f"{out}_{f + 1:04d}.png")
+        img = ctx.read(DENOISED)
+        st = ctx.stats()
+    if out:
+        save_png(img, out + ".png")
+    return img, st
+
+
+def save_png(img, path):
+    from PIL import Image
+    os.makedirs(os.path.dirname(os.path.abspath(path)) or ".", exist_ok=True)
+    Image.fromarray(srgb8(img[..., :3])).save(path)
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--scene", default="menger")
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--bounces", type=int, default=3)
+    ap.add_argument("--radius", type=int, default=0)
+    ap.add_argument("--moving", action="store_true", help="orbit the camera (temporal reprojection at work)")
+    ap.add_argument("--dump-every", type=int, default=0)
+    ap.add_argument("--out", default="gpurun_out/frame")
+    args = ap.parse_args()
+    img, st = run(args.scene, args.width, args.height, args.frames, args.bounces, args.radius, args.moving, args.out,
+                  dump_every=args.dump_every)
+    print(f"{args.scene}: {st.frames} frames, {st.rays} rays, image {img.shape[1]}x{img.shape[0]} -> {args.out}.png, "
+          f"mean radiance {float(np.nanmean(img[..., :3])):.4f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,5 +1,5 @@
 import sys, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from gpu_voxel_raytracer_amd import host as H
 from oracle import oracle as O
 rng = np.random.default_rng(1)

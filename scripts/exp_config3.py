@@ -1,6 +1,6 @@
 """BASELINE config 3: vox/monu10.vox at 3840x2160, 8 bounces, temporal + denoise; per-stage kernel times."""
 import sys, os
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 from gpu_voxel_raytracer_amd import Context, Camera, ALL, TIMED, scenes
 W, H, B = 3840, 2160, 8

@@ -1,6 +1,6 @@
 """BASELINE config 5 (scaled to one GPU): procedural level-7 Menger clipped to CLIP^3, 8 bounces; build + trace time."""
 import sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 from gpu_voxel_raytracer_amd import Context, Camera, TRACE, TIMED
 clip = int(sys.argv[1]) if len(sys.argv) > 1 else 2048

@@ -1,5 +1,5 @@
 import sys, time, os
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 from gpu_voxel_raytracer_amd import Context, Camera, TRACE, TIMED, scenes
 W, H = 1920, 1080

@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from gpu_voxel_raytracer_amd import Context, Camera, TRACE, scenes
 pos, mrgb, size = scenes.load_scene("castle")
 for infl in (1, 3):

@@ -1,6 +1,6 @@
 """How much do independent frames gain from being in flight together?  N contexts (own streams) on one GPU."""
 import sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from gpu_voxel_raytracer_amd import Context, Camera, TRACE, scenes
 W, H = 1920, 1080
 pos, mrgb, size = scenes.load_scene("menger")

@@ -1,6 +1,6 @@
 """Predict the N-GPU trace-stage frame time on one GPU: run each rank's band set alone and take the slowest."""
 import sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from gpu_voxel_raytracer_amd import Context, Camera, TRACE, scenes
 W, H = 1920, 1080
 pos, mrgb, size = scenes.load_scene("menger")

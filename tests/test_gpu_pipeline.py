@@ -193,3 +193,21 @@ def test_frames_in_flight_give_identical_frames(O, H, scenes, noise, inflight):
         assert_bits_equal(ctx.read(3), wanted[3], "accum after trace-only frames")
         assert_bits_equal(ctx.read(4), wanted[4], "denoised after trace-only frames")
         assert not np.array_equal(hist, ctx.read(3))
+
+
+def test_headless_frame_loop(H, scenes, tmp_path):
+    """the headless driver renders a camera path and writes what the reference would display."""
+    from gpu_voxel_raytracer_amd import frame_loop
+    out = str(tmp_path / "castle")
+    img, st = frame_loop.run("castle", 160, 96, frames=6, bounces=3, radius=1, moving=True, out=out, dump_every=3)
+    assert img.shape == (96, 160, 4) and np.isfinite(img).all() and st.frames == 6
+    assert os.path.exists(out + ".png") and os.path.exists(out + "_0003.png") and os.path.exists(out + "_0006.png")
+    # converged static view is less noisy than a single frame
+    one, _ = frame_loop.run("castle", 160, 96, frames=1, bounces=3)
+    many, _ = frame_loop.run("castle", 160, 96, frames=24, bounces=3)
+    def roughness(a):
+        return float(np.abs(np.diff(a[..., :3], axis=1)).mean())
+    assert roughness(many) < roughness(one)
+    img2, _ = frame_loop.run("menger:3:20:5", 96, 64, frames=2, bounces=2)
+    assert np.isfinite(img2).all()
+    assert frame_loop.srgb8(np.array([[[0.0, 0.5, 2.0]]], np.float32)).tolist() == [[[0, 188, 255]]]
