@@ -5,8 +5,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvxrt.so")
-SOURCES = ["vxrt_api.hip", "trace.hip", "post.hip", "scene_host.cpp", "scene_procedural.cpp"]
-HEADERS = ["kernels.h", "scene_host.h", "vx_vec.h", os.path.join("..", "..", "include", "vxrt.h"),
+SOURCES = ["vxrt_api.hip", "trace.hip", "trace_wavefront.hip", "post.hip", "scene_host.cpp", "scene_procedural.cpp"]
+HEADERS = ["kernels.h", "trace_common.h", "scene_host.h", "vx_vec.h", os.path.join("..", "..", "include", "vxrt.h"),
            os.path.join("..", "..", "include", "vxrt_detmath.h")]
 
 # -ffp-contract=off / no fast-math / IEEE divide+sqrt / denormals kept: include/vxrt_detmath.h

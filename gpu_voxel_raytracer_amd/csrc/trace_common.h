@@ -1,0 +1,266 @@
+// trace_common.h — device-side building blocks shared by the tracer's kernels (trace.hip, trace_wavefront.hip):
+// the octree walk, the shading helpers, the blue-noise RNG, ray counting and the 64-byte path record.
+// Everything is in an anonymous namespace: each translation unit gets its own copies, all force-inlined.
+#pragma once
+#include "kernels.h"
+#include "vx_vec.h"
+
+namespace vxrt {
+namespace {
+
+
+constexpr float kAlmostInfinity = 1073741824.0f;  // float(1 << 30)  voxels.comp:8
+constexpr int32_t kLeafBit = int32_t(0x80000000u);
+constexpr int32_t kEmitBit = 1 << 30;
+constexpr int kBlock = 256;
+constexpr uint32_t kNoiseLayer = 128u * 128u;
+constexpr uint32_t kNoiseTotal = kNoiseLayer * 512u;
+
+struct RayHit {
+    float time;
+    int32_t node;
+    f3 normal;
+};
+
+// ray_cube_intersection, voxels.comp:73-90
+__device__ __forceinline__ bool slab(f3 o, f3 inv, f3 sg, f3 c, float half, float& entry, float& exit) {
+    f3 hs = half * sg;
+    f3 en = ((c - hs) - o) * inv;
+    f3 ex = ((c + hs) - o) * inv;
+    entry = vx_max(vx_max(en.x, en.y), en.z);
+    exit = vx_min(vx_min(ex.x, ex.y), ex.z);
+    return exit >= 0.0f && entry < exit;
+}
+
+// current_octant, voxels.comp:119-125 (strict >: ties go to the low side)
+__device__ __forceinline__ uint32_t octant_of(f3 p, f3 c) {
+    return ((p.x - c.x) > 0.0f ? 4u : 0u) + ((p.y - c.y) > 0.0f ? 2u : 0u) + ((p.z - c.z) > 0.0f ? 1u : 0u);
+}
+
+struct SceneView {
+    const SvoRecord* svo;
+    const int32_t* leaves;
+    f3 root_center;
+    f3 root_min;
+    float root_size;
+};
+
+// cast_bounded_ray, voxels.comp:134-247.  `stack` points at this thread's column of the LDS stack
+// (entry l at stack[l * kBlock]).  On the iteration cap the shader returns true without writing the
+// normal; it is defined as 0 here (oracle U1).
+//
+// Shape of the loop (what differs from the shader's text, none of it changes a result):
+//  * descend (voxels.comp:205-221) and pop (:225-243) share one code path for everything they have in
+//    common — new integer path coordinates, node size and centre, the slab test — so a wave whose lanes
+//    are split between the two executes that code once, not twice;
+//  * a saved frame is {masks | next_octant << 16, base}: the sibling to resume with travels with the
+//    node record in LDS, and only frames that can still advance are stored (the shader's node == -1
+//    "complete" frames are never read back: a pop goes straight to the highest level whose bit is set
+//    in has_next_mask);
+//  * leaving the loop (leaf, miss, iteration cap) only sets a status; the leaf word load and the
+//    normal computation happen once after the loop for all lanes of the wave together, instead of
+//    inside the loop each time a single lane hits.
+__device__ __forceinline__ bool cast_ray(const SceneView& sc, f3 o, f3 d, float max_distance, uint2* stack, RayHit& hit) {
+    const uint32_t dir_mask = (d.x < 0.0f ? 4u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u);
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const f3 sg = mk3(vx_sign(inv.x), vx_sign(inv.y), vx_sign(inv.z));
+
+    float entry, exit;
+    if (!slab(o, inv, sg, sc.root_center, 0.5f * sc.root_size, entry, exit)) return false;
+
+    float time = vx_max(0.0f, entry);
+    float size = sc.root_size;
+    f3 center = sc.root_center;
+    uint32_t ix = 0, iy = 0, iz = 0;  // integer path coordinates of the current node, `lvl` bits each
+    uint32_t lvl = 0;
+    uint32_t has_next_mask = 0;       // bit l: level l can still advance to a sibling (frame.node != -1)
+    SvoRecord rec = sc.svo[0];
+    uint32_t octant = octant_of(o + d * time, center);
+
+    enum { kLeaf = 1, kMiss = 2, kCap = 3 };
+    int status;
+    for (int iterations = 1;; iterations++) {
+        if (iterations >= 2048) { status = kCap; break; }        // voxels.comp:166-169
+        if (time > max_distance) { status = kMiss; break; }      // voxels.comp:171-173
+        const uint32_t bit = 1u << octant;
+        if (rec.masks & (bit << 8)) { status = kLeaf; break; }   // value < 0
+
+        // next sibling through the node's mid planes                     voxels.comp:191-203
+        const f3 t_mid = (center - o) * inv;
+        const uint32_t directional = octant ^ dir_mask;
+        const float mx = (directional & 4u) ? kAlmostInfinity : t_mid.x;
+        const float my = (directional & 2u) ? kAlmostInfinity : t_mid.y;
+        const float mz = (directional & 1u) ? kAlmostInfinity : t_mid.z;
+        const float next_time = vx_min(vx_min(mx, my), mz);
+        const uint32_t transition = (mx == next_time) ? 4u : ((my == next_time) ? 2u : ((mz == next_time) ? 1u : 0u));
+        const uint32_t next_octant = octant ^ transition;
+        const bool has_next = next_time <= exit && transition != 0u && (directional & transition) == 0u;
+        const bool is_child = (rec.masks & bit) != 0u;           // value > 0
+
+        if (is_child || !has_next) {
+            uint2 raw;
+            if (is_child) {  // descend: remember where to resume, fetch the child record   voxels.comp:205-214
+                if (has_next) {
+                    stack[lvl * kBlock] = make_uint2(rec.masks | next_octant << 16, rec.base);
+                    has_next_mask |= 1u << lvl;
+                }
+                raw = *reinterpret_cast<const uint2*>(sc.svo + (rec.base + __popc(rec.masks & (bit - 1u))));
+                ix = (ix << 1) | ((octant >> 2) & 1u);
+                iy = (iy << 1) | ((octant >> 1) & 1u);
+                iz = (iz << 1) | (octant & 1u);
+                lvl++;
+            } else {  // pop to the nearest level that can still advance                     voxels.comp:225-234
+                if (has_next_mask == 0u) { status = kMiss; break; }
+                const uint32_t l = 31u - uint32_t(__clz(int(has_next_mask)));
+                has_next_mask &= ~(1u << l);
+                const uint32_t up = lvl - l;
+                ix >>= up; iy >>= up; iz >>= up;
+                lvl = l;
+                raw = stack[l * kBlock];
+                // consume the LDS read here: left alone, the compiler merges it with the descend branch's global
+                // load into one flat_load (either address space), which is slower and waits on both counters
+                asm volatile("" : "+v"(raw.x), "+v"(raw.y));
+            }
+            size = __builtin_ldexpf(sc.root_size, -int(lvl));
+            center = sc.root_min + mk3(float(ix) + 0.5f, float(iy) + 0.5f, float(iz) + 0.5f) * size;
+            float node_entry, node_exit;
+            slab(o, inv, sg, center, 0.5f * size, node_entry, node_exit);
+            if (is_child) {  // voxels.comp:216-221
+                octant = octant_of(o + d * time, center);
+                time = vx_max(time, node_entry);
+            } else {         // voxels.comp:236-242
+                time = exit;
+                octant = (raw.x >> 16) & 7u;
+            }
+            exit = node_exit;
+            rec.masks = raw.x & 0xffffu;
+            rec.base = raw.y;
+        } else {  // empty slot, step to the sibling                                         voxels.comp:222-224
+            octant = next_octant;
+            time = next_time;
+        }
+    }
+
+    hit.time = time;
+    hit.normal = splat3(0.0f);
+    if (status == kMiss) return false;
+    if (status == kCap) {
+        hit.node = kLeafBit;
+        return true;
+    }
+    // leaf                                                                                   voxels.comp:177-189
+    const uint32_t bit = 1u << octant;
+    hit.node = sc.leaves[rec.base + __popc((rec.masks >> 8) & (bit - 1u))];
+    f3 p = o + time * d;
+    f3 delta = mk3(float((octant >> 2) & 1u), float((octant >> 1) & 1u), float(octant & 1u));
+    f3 oc = center + (0.5f * size) * (delta - splat3(0.5f));
+    f3 dist = mk3(vx_abs(p.x - oc.x), vx_abs(p.y - oc.y), vx_abs(p.z - oc.z));
+    float m = vx_max(vx_max(dist.x, dist.y), dist.z);
+    f3 mask = mk3(dist.x == m ? 1.0f : 0.0f, dist.y == m ? 1.0f : 0.0f, dist.z == m ? 1.0f : 0.0f);
+    hit.normal = mask * mk3(-vx_sign(d.x), -vx_sign(d.y), -vx_sign(d.z));
+    return true;
+}
+
+__device__ __forceinline__ f3 node_rgb(int32_t node) {
+    return mk3(float((node >> 16) & 0xff), float((node >> 8) & 0xff), float(node & 0xff));
+}
+// node_color, voxels.comp:253-258
+__device__ __forceinline__ f3 node_color(int32_t node) { return node_rgb(node) / 255.0f; }
+// node_emmitance, voxels.comp:260-266
+__device__ __forceinline__ f3 node_emittance(int32_t node, float emit_strength) {
+    float e = (node & kEmitBit) != 0 ? 1.0f : 0.0f;
+    return ((e * emit_strength) * node_rgb(node)) / 255.0f;
+}
+
+struct Rng {  // rand(), voxels.comp:268-275
+    uint32_t index;
+    const float* noise;
+    __device__ __forceinline__ float next() {
+        index = (index + kNoiseLayer) % kNoiseTotal;
+        return noise[index];
+    }
+};
+
+// random_hemisphere, voxels.comp:277-287
+__device__ __forceinline__ f3 random_hemisphere(f3 n, Rng& rng) {
+    float phi = (2.0f * 3.14159265358979f) * rng.next();
+    f3 r;
+    r.x = 2.0f * rng.next() - 1.0f;
+    float plane_radius = vx_sqrt(1.0f - r.x * r.x);
+    r.y = plane_radius * vx_cos(phi);
+    r.z = plane_radius * vx_sin(phi);
+    return r - n * vx_min(0.0f, 2.0f * dot3(n, r));
+}
+
+__device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+
+// Rays cast by this wave -> one atomic on one of kRaySlots counters, each on a 64-byte line of its own.
+// (A single counter word saturates at ~88 atomics/us chip-wide: with one atomic per wave that alone
+// put a 0.4 ms floor under a 1080p frame.)
+__device__ __forceinline__ void count_rays(unsigned long long* slots, uint32_t rays, int lane) {
+    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
+    if (lane == 0 && rays != 0) {
+        const unsigned slot = (blockIdx.x + blockIdx.y * gridDim.x) * 4u + (threadIdx.x >> 6);
+        atomicAdd(slots + size_t(slot % kRaySlots) * 8u, (unsigned long long)rays);
+    }
+}
+
+// ---- path records and queues (wavefront variants) ------------------------------------------------------
+constexpr unsigned kShards = 64;
+constexpr unsigned kCountStride = 16;  // uints: one 64-byte line per shard counter
+
+struct PathRec {  // 4 x float4
+    f3 hit_pos; int32_t node;
+    f3 dir; uint32_t normal_ambient;   // normal: 2 bits per axis (0:+0, 1:+1, 2:-1, 3:-0); ambient_rays << 8
+    f3 sample; uint32_t rng_index;
+    f3 blend; uint32_t pix;
+};
+
+__device__ __forceinline__ uint32_t pack_axis(float v) { return v == 0.0f ? ((vx_f2u(v) >> 31) ? 3u : 0u) : (v > 0.0f ? 1u : 2u); }
+__device__ __forceinline__ float unpack_axis(uint32_t c) { return c == 0u ? 0.0f : (c == 1u ? 1.0f : (c == 2u ? -1.0f : -0.0f)); }
+
+__device__ __forceinline__ void store_rec(float4* q, const PathRec& r) {
+    q[0] = make_float4(r.hit_pos.x, r.hit_pos.y, r.hit_pos.z, __int_as_float(r.node));
+    q[1] = make_float4(r.dir.x, r.dir.y, r.dir.z, __uint_as_float(r.normal_ambient));
+    q[2] = make_float4(r.sample.x, r.sample.y, r.sample.z, __uint_as_float(r.rng_index));
+    q[3] = make_float4(r.blend.x, r.blend.y, r.blend.z, __uint_as_float(r.pix));
+}
+__device__ __forceinline__ PathRec load_rec(const float4* q) {
+    const float4 a = q[0], b = q[1], c = q[2], d = q[3];
+    PathRec r;
+    r.hit_pos = mk3(a.x, a.y, a.z); r.node = __float_as_int(a.w);
+    r.dir = mk3(b.x, b.y, b.z); r.normal_ambient = __float_as_uint(b.w);
+    r.sample = mk3(c.x, c.y, c.z); r.rng_index = __float_as_uint(c.w);
+    r.blend = mk3(d.x, d.y, d.z); r.pix = __float_as_uint(d.w);
+    return r;
+}
+
+// Append the records of the lanes with `keep` to shard `shard` of the queue (called by all 64 lanes).
+__device__ __forceinline__ void queue_append(const PathQueue& q, unsigned shard, bool keep, const PathRec& rec, int lane) {
+    const unsigned long long m = __ballot(keep);
+    if (m == 0ull) return;
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(q.counts + shard * kCountStride, unsigned(__popcll(m)));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (keep) {
+        const unsigned rank = __builtin_amdgcn_mbcnt_hi(unsigned(m >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(m), 0u));
+        store_rec(q.recs + (size_t(shard) * q.shard_capacity + base + rank) * 4u, rec);
+    }
+}
+
+__device__ __forceinline__ SceneView make_scene(const TraceArgs& a) {
+    SceneView sc;
+    sc.svo = a.svo;
+    sc.leaves = a.leaves;
+    sc.root_center = ld3(a.root_center);
+    sc.root_size = a.root_size;
+    sc.root_min = sc.root_center - splat3(0.5f * a.root_size);
+    return sc;
+}
+
+__device__ __forceinline__ void zero_counts(unsigned* counts, int tid) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid < int(kShards)) counts[tid * kCountStride] = 0u;
+}
+
+}  // namespace
+}  // namespace vxrt
