@@ -90,7 +90,20 @@ struct PathQueue {
     unsigned shard_capacity;  // records per shard
 };
 
+// Ray-queue variant (trace_wavefront.hip): paths and rays of one frame between its shade / trace launches.
+constexpr unsigned kSegments = 8;  // dense queue segments; a block appends to segment blockIdx % 8 with one atomic
+struct RayQueue {
+    float4* state[2];        // [kSegments][seg_capacity][4 float4]  path state, ping-pong between segments of a path
+    float4* rays[2];         // [kSegments][seg_capacity][3 float4]  (origin, flags) (sun dir) (bounce dir)
+    uint4* results;          // [kSegments][seg_capacity][2]         what the walk of each ray ended with
+    unsigned* counts;        // [max_bounces + 1][kSegments] counters, 16 uints (one 64-byte line) apart, zero at frame start
+    unsigned seg_capacity;
+};
+
 hipError_t launch_trace(const TraceArgs& a, hipStream_t s);  // monolithic: one pixel per lane, all bounces
+// ray queues: primary_kernel, then shade / trace-rays launches per path segment with per-lane ray refill
+hipError_t launch_trace_rayqueue(const TraceArgs& a, const PathQueue& hits, unsigned* count_sets[3], unsigned* launch_counter,
+                                 const RayQueue& q, int shade_blocks, int trace_blocks, hipStream_t s);
 // longest-tile-first schedule for the next launch: order[] = tiles sorted by descending cost; cost[] is cleared
 hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t* last_cost, unsigned tiles, hipStream_t s);
 // wavefront: primary_kernel + max_bounces x bounce_kernel; queues[2] ping-pong, count_sets[3] rotate

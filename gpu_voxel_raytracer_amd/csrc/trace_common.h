@@ -60,104 +60,132 @@ struct SceneView {
 //  * leaving the loop (leaf, miss, iteration cap) only sets a status; the leaf word load and the
 //    normal computation happen once after the loop for all lanes of the wave together, instead of
 //    inside the loop each time a single lane hits.
-__device__ __forceinline__ bool cast_ray(const SceneView& sc, f3 o, f3 d, float max_distance, uint2* stack, RayHit& hit) {
-    const uint32_t dir_mask = (d.x < 0.0f ? 4u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u);
-    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const f3 sg = mk3(vx_sign(inv.x), vx_sign(inv.y), vx_sign(inv.z));
+struct Walk {  // the loop-carried state of cast_bounded_ray
+    f3 o, d, inv, sg, center;
+    float time, exit, size;
+    uint32_t ix, iy, iz;      // integer path coordinates of the current node, `lvl` bits each
+    uint32_t lvl;
+    uint32_t has_next_mask;   // bit l: level l can still advance to a sibling (frame.node != -1)
+    uint32_t octant, dir_mask;
+    SvoRecord rec;
+    int iterations;
+};
+enum : int { kWalkOn = 0, kWalkLeaf = 1, kWalkMiss = 2, kWalkCap = 3 };
 
-    float entry, exit;
-    if (!slab(o, inv, sg, sc.root_center, 0.5f * sc.root_size, entry, exit)) return false;
+// voxels.comp:138-160.  false: the ray misses the root cube.
+__device__ __forceinline__ bool walk_begin(Walk& w, const SceneView& sc, f3 o, f3 d) {
+    w.o = o;
+    w.d = d;
+    w.dir_mask = (d.x < 0.0f ? 4u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u);
+    w.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    w.sg = mk3(vx_sign(w.inv.x), vx_sign(w.inv.y), vx_sign(w.inv.z));
+    float entry;
+    if (!slab(o, w.inv, w.sg, sc.root_center, 0.5f * sc.root_size, entry, w.exit)) return false;
+    w.time = vx_max(0.0f, entry);
+    w.size = sc.root_size;
+    w.center = sc.root_center;
+    w.ix = w.iy = w.iz = w.lvl = w.has_next_mask = 0;
+    w.rec = sc.svo[0];
+    w.octant = octant_of(o + d * w.time, w.center);
+    w.iterations = 0;
+    return true;
+}
 
-    float time = vx_max(0.0f, entry);
-    float size = sc.root_size;
-    f3 center = sc.root_center;
-    uint32_t ix = 0, iy = 0, iz = 0;  // integer path coordinates of the current node, `lvl` bits each
-    uint32_t lvl = 0;
-    uint32_t has_next_mask = 0;       // bit l: level l can still advance to a sibling (frame.node != -1)
-    SvoRecord rec = sc.svo[0];
-    uint32_t octant = octant_of(o + d * time, center);
+// One trip of the while(true) loop, voxels.comp:163-246.
+__device__ __forceinline__ int walk_step(Walk& w, const SceneView& sc, float max_distance, uint2* stack) {
+    if (++w.iterations >= 2048) return kWalkCap;             // voxels.comp:166-169
+    if (w.time > max_distance) return kWalkMiss;             // voxels.comp:171-173
+    const uint32_t bit = 1u << w.octant;
+    if (w.rec.masks & (bit << 8)) return kWalkLeaf;          // value < 0
 
-    enum { kLeaf = 1, kMiss = 2, kCap = 3 };
-    int status;
-    for (int iterations = 1;; iterations++) {
-        if (iterations >= 2048) { status = kCap; break; }        // voxels.comp:166-169
-        if (time > max_distance) { status = kMiss; break; }      // voxels.comp:171-173
-        const uint32_t bit = 1u << octant;
-        if (rec.masks & (bit << 8)) { status = kLeaf; break; }   // value < 0
+    // next sibling through the node's mid planes                     voxels.comp:191-203
+    const f3 t_mid = (w.center - w.o) * w.inv;
+    const uint32_t directional = w.octant ^ w.dir_mask;
+    const float mx = (directional & 4u) ? kAlmostInfinity : t_mid.x;
+    const float my = (directional & 2u) ? kAlmostInfinity : t_mid.y;
+    const float mz = (directional & 1u) ? kAlmostInfinity : t_mid.z;
+    const float next_time = vx_min(vx_min(mx, my), mz);
+    const uint32_t transition = (mx == next_time) ? 4u : ((my == next_time) ? 2u : ((mz == next_time) ? 1u : 0u));
+    const uint32_t next_octant = w.octant ^ transition;
+    const bool has_next = next_time <= w.exit && transition != 0u && (directional & transition) == 0u;
+    const bool is_child = (w.rec.masks & bit) != 0u;         // value > 0
 
-        // next sibling through the node's mid planes                     voxels.comp:191-203
-        const f3 t_mid = (center - o) * inv;
-        const uint32_t directional = octant ^ dir_mask;
-        const float mx = (directional & 4u) ? kAlmostInfinity : t_mid.x;
-        const float my = (directional & 2u) ? kAlmostInfinity : t_mid.y;
-        const float mz = (directional & 1u) ? kAlmostInfinity : t_mid.z;
-        const float next_time = vx_min(vx_min(mx, my), mz);
-        const uint32_t transition = (mx == next_time) ? 4u : ((my == next_time) ? 2u : ((mz == next_time) ? 1u : 0u));
-        const uint32_t next_octant = octant ^ transition;
-        const bool has_next = next_time <= exit && transition != 0u && (directional & transition) == 0u;
-        const bool is_child = (rec.masks & bit) != 0u;           // value > 0
-
-        if (is_child || !has_next) {
-            uint2 raw;
-            if (is_child) {  // descend: remember where to resume, fetch the child record   voxels.comp:205-214
-                if (has_next) {
-                    stack[lvl * kBlock] = make_uint2(rec.masks | next_octant << 16, rec.base);
-                    has_next_mask |= 1u << lvl;
-                }
-                raw = *reinterpret_cast<const uint2*>(sc.svo + (rec.base + __popc(rec.masks & (bit - 1u))));
-                ix = (ix << 1) | ((octant >> 2) & 1u);
-                iy = (iy << 1) | ((octant >> 1) & 1u);
-                iz = (iz << 1) | (octant & 1u);
-                lvl++;
-            } else {  // pop to the nearest level that can still advance                     voxels.comp:225-234
-                if (has_next_mask == 0u) { status = kMiss; break; }
-                const uint32_t l = 31u - uint32_t(__clz(int(has_next_mask)));
-                has_next_mask &= ~(1u << l);
-                const uint32_t up = lvl - l;
-                ix >>= up; iy >>= up; iz >>= up;
-                lvl = l;
-                raw = stack[l * kBlock];
-                // consume the LDS read here: left alone, the compiler merges it with the descend branch's global
-                // load into one flat_load (either address space), which is slower and waits on both counters
-                asm volatile("" : "+v"(raw.x), "+v"(raw.y));
+    if (is_child || !has_next) {
+        uint2 raw;
+        if (is_child) {  // descend: remember where to resume, fetch the child record   voxels.comp:205-214
+            if (has_next) {
+                stack[w.lvl * kBlock] = make_uint2(w.rec.masks | next_octant << 16, w.rec.base);
+                w.has_next_mask |= 1u << w.lvl;
             }
-            size = __builtin_ldexpf(sc.root_size, -int(lvl));
-            center = sc.root_min + mk3(float(ix) + 0.5f, float(iy) + 0.5f, float(iz) + 0.5f) * size;
-            float node_entry, node_exit;
-            slab(o, inv, sg, center, 0.5f * size, node_entry, node_exit);
-            if (is_child) {  // voxels.comp:216-221
-                octant = octant_of(o + d * time, center);
-                time = vx_max(time, node_entry);
-            } else {         // voxels.comp:236-242
-                time = exit;
-                octant = (raw.x >> 16) & 7u;
-            }
-            exit = node_exit;
-            rec.masks = raw.x & 0xffffu;
-            rec.base = raw.y;
-        } else {  // empty slot, step to the sibling                                         voxels.comp:222-224
-            octant = next_octant;
-            time = next_time;
+            raw = *reinterpret_cast<const uint2*>(sc.svo + (w.rec.base + __popc(w.rec.masks & (bit - 1u))));
+            w.ix = (w.ix << 1) | ((w.octant >> 2) & 1u);
+            w.iy = (w.iy << 1) | ((w.octant >> 1) & 1u);
+            w.iz = (w.iz << 1) | (w.octant & 1u);
+            w.lvl++;
+        } else {  // pop to the nearest level that can still advance                     voxels.comp:225-234
+            if (w.has_next_mask == 0u) return kWalkMiss;
+            const uint32_t l = 31u - uint32_t(__clz(int(w.has_next_mask)));
+            w.has_next_mask &= ~(1u << l);
+            const uint32_t up = w.lvl - l;
+            w.ix >>= up; w.iy >>= up; w.iz >>= up;
+            w.lvl = l;
+            raw = stack[l * kBlock];
+            // consume the LDS read here: left alone, the compiler merges it with the descend branch's global
+            // load into one flat_load (either address space), which is slower and waits on both counters
+            asm volatile("" : "+v"(raw.x), "+v"(raw.y));
         }
+        w.size = __builtin_ldexpf(sc.root_size, -int(w.lvl));
+        w.center = sc.root_min + mk3(float(w.ix) + 0.5f, float(w.iy) + 0.5f, float(w.iz) + 0.5f) * w.size;
+        float node_entry, node_exit;
+        slab(w.o, w.inv, w.sg, w.center, 0.5f * w.size, node_entry, node_exit);
+        if (is_child) {  // voxels.comp:216-221
+            w.octant = octant_of(w.o + w.d * w.time, w.center);
+            w.time = vx_max(w.time, node_entry);
+        } else {         // voxels.comp:236-242
+            w.time = w.exit;
+            w.octant = (raw.x >> 16) & 7u;
+        }
+        w.exit = node_exit;
+        w.rec.masks = raw.x & 0xffffu;
+        w.rec.base = raw.y;
+    } else {  // empty slot, step to the sibling                                         voxels.comp:222-224
+        w.octant = next_octant;
+        w.time = next_time;
     }
+    return kWalkOn;
+}
 
-    hit.time = time;
-    hit.normal = splat3(0.0f);
-    if (status == kMiss) return false;
-    if (status == kCap) {
-        hit.node = kLeafBit;
-        return true;
-    }
-    // leaf                                                                                   voxels.comp:177-189
-    const uint32_t bit = 1u << octant;
-    hit.node = sc.leaves[rec.base + __popc((rec.masks >> 8) & (bit - 1u))];
+// index of the leaf word the walk stopped at (status kWalkLeaf)
+__device__ __forceinline__ uint32_t walk_leaf_index(const Walk& w) {
+    const uint32_t bit = 1u << w.octant;
+    return w.rec.base + __popc((w.rec.masks >> 8) & (bit - 1u));
+}
+
+// voxels.comp:177-189: normal of a hit at `time` on the unit voxel whose centre is `oc`
+__device__ __forceinline__ f3 hit_normal(f3 o, f3 d, float time, f3 oc) {
     f3 p = o + time * d;
-    f3 delta = mk3(float((octant >> 2) & 1u), float((octant >> 1) & 1u), float(octant & 1u));
-    f3 oc = center + (0.5f * size) * (delta - splat3(0.5f));
     f3 dist = mk3(vx_abs(p.x - oc.x), vx_abs(p.y - oc.y), vx_abs(p.z - oc.z));
     float m = vx_max(vx_max(dist.x, dist.y), dist.z);
     f3 mask = mk3(dist.x == m ? 1.0f : 0.0f, dist.y == m ? 1.0f : 0.0f, dist.z == m ? 1.0f : 0.0f);
-    hit.normal = mask * mk3(-vx_sign(d.x), -vx_sign(d.y), -vx_sign(d.z));
+    return mask * mk3(-vx_sign(d.x), -vx_sign(d.y), -vx_sign(d.z));
+}
+
+__device__ __forceinline__ bool cast_ray(const SceneView& sc, f3 o, f3 d, float max_distance, uint2* stack, RayHit& hit) {
+    Walk w;
+    if (!walk_begin(w, sc, o, d)) return false;
+    int status;
+    do { status = walk_step(w, sc, max_distance, stack); } while (status == kWalkOn);
+    hit.time = w.time;
+    hit.normal = splat3(0.0f);
+    if (status == kWalkMiss) return false;
+    if (status == kWalkCap) {
+        hit.node = kLeafBit;
+        return true;
+    }
+    hit.node = sc.leaves[walk_leaf_index(w)];
+    f3 delta = mk3(float((w.octant >> 2) & 1u), float((w.octant >> 1) & 1u), float(w.octant & 1u));
+    f3 oc = w.center + (0.5f * w.size) * (delta - splat3(0.5f));
+    hit.normal = hit_normal(o, d, w.time, oc);
     return true;
 }
 
@@ -193,6 +221,7 @@ __device__ __forceinline__ f3 random_hemisphere(f3 n, Rng& rng) {
 }
 
 __device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+__device__ __forceinline__ f3 xyz4(float4 v) { return mk3(v.x, v.y, v.z); }
 
 // Rays cast by this wave -> one atomic on one of kRaySlots counters, each on a 64-byte line of its own.
 // (A single counter word saturates at ~88 atomics/us chip-wide: with one atomic per wave that alone

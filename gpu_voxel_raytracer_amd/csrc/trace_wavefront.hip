@@ -184,6 +184,312 @@ __global__ __launch_bounds__(kBlock, VXRT_BOUNCE_WAVES) void bounce_kernel(const
 }
 
 
+// ------------------------------------------------------------------------------------------------------
+// Ray-queue variant: shading and traversal in separate launches, rays traced by persistent waves that
+// REFILL EACH LANE as soon as its ray ends.
+//
+// What the monolithic kernel loses (oracle step statistics, menger bench frame): after the primary phase a
+// wave's lanes trace rays of wildly different length (mean 8 octree steps, p99 50-70) in lockstep phases, so
+// the six later ray phases keep only 13-27 % of the lanes busy.  Compacting dead paths does not help much —
+// the variance between LIVE rays is the loss.  Here:
+//
+//   primary_kernel     (above)  primary rays, G-buffer, hits -> sharded PathRec queue
+//   shade_kernel<true>           hit 0: RNG, sun sample, BRDF sample -> path state + (sun ray, bounce ray)
+//   trace_rays_kernel            persistent waves; each wave owns a contiguous range of the stage's rays and
+//                                hands a new ray to every lane that goes idle (wave64 ballot + mbcnt prefix
+//                                over the idle lanes, no atomics); a ray's end state (time, leaf index, voxel
+//                                coordinates) is stored raw — no shading code inside the traversal loop
+//   shade_kernel<false>          per path: apply the sun result, resolve the bounce hit (leaf word, normal),
+//                                shade it, emit the next two rays — or finish the pixel
+//
+// Paths are kept dense: a block appends its survivors with one atomicAdd on the counter of queue segment
+// blockIdx % 8 (block-wide prefix through LDS), so trace waves can split the rays evenly without a scan.
+// The per-path operation order is that of voxels.comp, the results are bit-identical to trace_kernel's.
+// ------------------------------------------------------------------------------------------------------
+constexpr unsigned kFlagSun = 1u, kFlagBounce = 2u;
+#ifndef VXRT_MIN_RAYS_PER_WAVE
+#define VXRT_MIN_RAYS_PER_WAVE 64
+#endif
+#ifndef VXRT_REFILL_LANES
+#define VXRT_REFILL_LANES 16
+#endif
+constexpr int kRefillLanes = VXRT_REFILL_LANES;  // refill when this many lanes of the wave are idle (or all the rest are done)
+constexpr unsigned kMinRaysPerWave = VXRT_MIN_RAYS_PER_WAVE;
+
+struct SegTable {  // the 8 segment counts of one stage as exclusive prefix sums
+    unsigned pre[kSegments + 1];
+};
+__device__ __forceinline__ SegTable load_segments(const unsigned* counts, int stage) {
+    SegTable t;
+    t.pre[0] = 0;
+#pragma unroll
+    for (unsigned s = 0; s < kSegments; s++) t.pre[s + 1] = t.pre[s] + counts[(unsigned(stage) * kSegments + s) * kCountStride];
+    return t;
+}
+// dense path index -> slot in the segmented arrays
+__device__ __forceinline__ unsigned segment_slot(const SegTable& t, unsigned j, unsigned cap) {
+    unsigned s = 0, first = 0;  // select chain with compile-time indices: no runtime-indexed array (that would go to scratch)
+#pragma unroll
+    for (unsigned k = 1; k < kSegments; k++)
+        if (j >= t.pre[k]) { s = k; first = t.pre[k]; }
+    return s * cap + (j - first);
+}
+
+// Block-wide dense append: returns this thread's slot in segment blockIdx % 8 of stage `stage` (or ~0u).
+__device__ __forceinline__ unsigned dense_append(const RayQueue& q, int stage, bool keep, unsigned* lds_counts, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) lds_counts[wave] = unsigned(__popcll(m));
+    __syncthreads();
+    const unsigned c0 = lds_counts[0], c1 = lds_counts[1], c2 = lds_counts[2], c3 = lds_counts[3];
+    const unsigned seg = blockIdx.x % kSegments;
+    if (tid == 0) {
+        const unsigned total = c0 + c1 + c2 + c3;
+        lds_counts[4] = total ? atomicAdd(q.counts + (unsigned(stage) * kSegments + seg) * kCountStride, total) : 0u;
+    }
+    __syncthreads();
+    const unsigned base = lds_counts[4];
+    __syncthreads();  // lds_counts is rewritten by the next call
+    if (!keep) return ~0u;
+    const unsigned before = wave == 0 ? 0u : (wave == 1 ? c0 : (wave == 2 ? c0 + c1 : c0 + c1 + c2));
+    const unsigned rank = __builtin_amdgcn_mbcnt_hi(unsigned(m >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(m), 0u));
+    return seg * q.seg_capacity + base + before + rank;
+}
+
+struct Shaded {  // what shading a hit produces
+    f3 sample, blend, pend_sun, pend_emit, origin, sun_dir, bounce_dir;
+    uint32_t ambient_rays, flags;
+};
+
+// voxels.comp:314-371 for a hit at path segment `bounce` — everything between two cast_ray calls.
+__device__ __forceinline__ Shaded shade_hit(const TraceArgs& a, int bounce, f3 hit_pos, f3 dir, f3 n, int32_t node, f3 sample, f3 blend,
+                                            uint32_t ambient_rays, Rng& rng, f3 sun_dir, f3 sun_color) {
+    Shaded r;
+    const f3 color = bounce == 0 ? splat3(1.0f) : node_color(node);   // voxels.comp:317
+    const f3 emit = node_emittance(node, a.emit_strength);
+    r.origin = hit_pos + 1e-5f * n;                                    // voxels.comp:333,353,370
+    r.pend_sun = r.pend_emit = r.sun_dir = splat3(0.0f);
+    r.flags = bounce + 1 < a.max_bounces ? kFlagBounce : 0u;
+    if (rng.next() < a.specularity) {  // specular                     voxels.comp:326-334
+        r.bounce_dir = norm3(reflect3(dir, n));
+        sample = sample + emit * blend;
+        blend = blend * ((2.0f * color) * dot3(r.bounce_dir, n));
+    } else if (a.sun_strength > 0.0f) {  // diffuse + sun sample         voxels.comp:339-371
+        float r0 = rng.next(), r1 = rng.next(), r2 = rng.next();
+        f3 up_dir = norm3(cross3(mk3(r0, r1, r2), sun_dir));
+        f3 right_dir = norm3(cross3(sun_dir, up_dir));
+        float dx = 2.0f * rng.next() - 1.0f;
+        float dy = 2.0f * rng.next() - 1.0f;
+        f3 light_dir = ld3(a.sun_dir_n) + (dx * right_dir + dy * up_dir) * a.sun_size;
+        r.sun_dir = norm3(-light_dir);
+        ambient_rays++;
+        r.pend_sun = ((sun_color * color) * blend) * vx_max(0.0f, dot3(n, r.sun_dir));
+        r.bounce_dir = random_hemisphere(n, rng);
+        r.pend_emit = emit * blend;
+        blend = blend * (color * dot3(n, r.bounce_dir));
+        r.flags |= kFlagSun;
+    } else {  // diffuse, sun switched off
+        r.bounce_dir = random_hemisphere(n, rng);
+        sample = sample + emit * blend;
+        blend = blend * (color * dot3(n, r.bounce_dir));
+    }
+    r.sample = sample;
+    r.blend = blend;
+    r.ambient_rays = ambient_rays;
+    return r;
+}
+
+// kFirst: paths come from primary_kernel's sharded hit queue (hit already resolved); otherwise from stage-1.
+template <bool kFirst>
+__global__ __launch_bounds__(kBlock) void shade_kernel(const TraceArgs a, const PathQueue hits, const RayQueue q, unsigned* zero, int stage) {
+    __shared__ unsigned lds_counts[8];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    if (kFirst) zero_counts(zero, tid);
+    const SceneView sc = make_scene(a);
+    const f3 sun_dir = ld3(a.sun_dir), sun_color = ld3(a.sun_color), sky = ld3(a.sky_color);
+
+    // work list: kFirst -> 64-entry chunks of the sharded hit queue; else dense path indices of stage-1
+    unsigned my_count = 0, my_chunks = 0, incl = 0, total_items = 0;
+    SegTable seg{};
+    if (kFirst) {
+        my_count = hits.counts[lane * kCountStride];
+        my_chunks = (my_count + 63u) / 64u;
+        incl = my_chunks;
+        for (int off = 1; off < 64; off <<= 1) {
+            unsigned v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        total_items = __shfl(incl, 63, 64) * 64u;  // padded: one item = one lane of a chunk
+    } else {
+        seg = load_segments(q.counts, stage - 1);
+        total_items = seg.pre[kSegments];
+    }
+    const unsigned per_trip = gridDim.x * unsigned(kBlock);
+    const unsigned trips = (total_items + per_trip - 1u) / per_trip;  // same for every block: barriers inside
+    const float4* state_in = q.state[(stage + 1) & 1];
+    const float4* rays_in = q.rays[(stage + 1) & 1];
+    float4* state_out = q.state[stage & 1];
+    float4* rays_out = q.rays[stage & 1];
+
+    for (unsigned trip = 0; trip < trips; trip++) {
+        const unsigned item = trip * per_trip + blockIdx.x * unsigned(kBlock) + unsigned(tid);
+        bool have = false, keep = false;
+        f3 hit_pos = splat3(0.0f), dir = splat3(0.0f), n = splat3(0.0f), sample = splat3(0.0f), blend = splat3(0.0f);
+        int32_t node = 0;
+        uint32_t ambient_rays = 1, pix = 0;
+        Rng rng;
+        rng.noise = a.noise;
+        rng.index = 0;
+        if (kFirst) {
+            const unsigned c = item / 64u;  // wave-uniform
+            const unsigned long long above = __ballot(incl > c);
+            if (above != 0ull) {
+                const int sh = __ffsll((long long)above) - 1;
+                const unsigned first = __shfl(incl - my_chunks, sh, 64);
+                const unsigned count_q = __shfl(my_count, sh, 64);
+                const unsigned entry = (c - first) * 64u + unsigned(lane);
+                if (entry < count_q) {
+                    const PathRec rec = load_rec(hits.recs + (size_t(sh) * hits.shard_capacity + entry) * 4u);
+                    hit_pos = rec.hit_pos; dir = rec.dir; node = rec.node;
+                    n = mk3(unpack_axis(rec.normal_ambient & 3u), unpack_axis((rec.normal_ambient >> 2) & 3u), unpack_axis((rec.normal_ambient >> 4) & 3u));
+                    ambient_rays = rec.normal_ambient >> 8;
+                    sample = rec.sample; blend = rec.blend; rng.index = rec.rng_index; pix = rec.pix;
+                    have = true;
+                }
+            }
+        } else if (item < total_items) {
+            const unsigned slot = segment_slot(seg, item, q.seg_capacity);
+            const float4 s0 = state_in[size_t(slot) * 4], s1 = state_in[size_t(slot) * 4 + 1], s2 = state_in[size_t(slot) * 4 + 2],
+                         s3 = state_in[size_t(slot) * 4 + 3];
+            const float4 r0 = rays_in[size_t(slot) * 3];
+            sample = xyz4(s0); rng.index = __float_as_uint(s0.w);
+            blend = xyz4(s1); pix = __float_as_uint(s1.w);
+            ambient_rays = __float_as_uint(s2.w);
+            const uint32_t flags = __float_as_uint(r0.w);
+            const f3 o = xyz4(r0);
+            if (flags & kFlagSun) {  // voxels.comp:357-367: the sun sample counts unless something is in the way
+                const uint4 rs = q.results[size_t(slot) * 2];
+                if ((rs.w >> 16 & 3u) == unsigned(kWalkMiss)) sample = sample + xyz4(s2);
+                sample = sample + xyz4(s3);
+            }
+            bool finished = true;
+            if (flags & kFlagBounce) {
+                const uint4 rb = q.results[size_t(slot) * 2 + 1];
+                const unsigned status = rb.w >> 16 & 3u;
+                const f3 d = xyz4(rays_in[size_t(slot) * 3 + 2]);
+                if (status == unsigned(kWalkMiss)) {
+                    sample = sample + sky * blend;                                        // voxels.comp:384
+                } else {
+                    const float time = __uint_as_float(rb.x);
+                    hit_pos = o + d * time;
+                    dir = d;
+                    if (status == unsigned(kWalkCap)) {
+                        node = kLeafBit;
+                        n = splat3(0.0f);
+                    } else {
+                        node = sc.leaves[rb.y];
+                        const unsigned lvl = rb.w >> 20 & 15u;  // level of the node the leaf sits in
+                        const float voxel = __builtin_ldexpf(sc.root_size, -int(lvl) - 1);
+                        const f3 oc = sc.root_min + mk3(float(rb.z & 0xffffu) + 0.5f, float(rb.z >> 16) + 0.5f, float(rb.w & 0xffffu) + 0.5f) * voxel;
+                        n = hit_normal(o, d, time, oc);
+                    }
+                    finished = false;
+                    have = true;
+                }
+            }
+            if (finished) {
+                f3 outc = sample / float(ambient_rays);                                   // voxels.comp:391
+                a.out_color[pix] = make_float4(outc.x, outc.y, outc.z, 1.0f);
+            }
+        }
+
+        Shaded sh{};
+        if (have) {
+            sh = shade_hit(a, stage, hit_pos, dir, n, node, sample, blend, ambient_rays, rng, sun_dir, sun_color);
+            if (sh.flags == 0u) {  // nothing left to trace (specular hit at the last segment): the pixel is done
+                f3 outc = sh.sample / float(sh.ambient_rays);
+                a.out_color[pix] = make_float4(outc.x, outc.y, outc.z, 1.0f);
+            } else {
+                keep = true;
+            }
+        }
+        const unsigned slot = dense_append(q, stage, keep, lds_counts, tid);
+        if (keep) {
+            float4* so = state_out + size_t(slot) * 4;
+            so[0] = make_float4(sh.sample.x, sh.sample.y, sh.sample.z, __uint_as_float(rng.index));
+            so[1] = make_float4(sh.blend.x, sh.blend.y, sh.blend.z, __uint_as_float(pix));
+            so[2] = make_float4(sh.pend_sun.x, sh.pend_sun.y, sh.pend_sun.z, __uint_as_float(sh.ambient_rays));
+            so[3] = make_float4(sh.pend_emit.x, sh.pend_emit.y, sh.pend_emit.z, 0.0f);
+            float4* ro = rays_out + size_t(slot) * 3;
+            ro[0] = make_float4(sh.origin.x, sh.origin.y, sh.origin.z, __uint_as_float(sh.flags));
+            ro[1] = make_float4(sh.sun_dir.x, sh.sun_dir.y, sh.sun_dir.z, 0.0f);
+            ro[2] = make_float4(sh.bounce_dir.x, sh.bounce_dir.y, sh.bounce_dir.z, 0.0f);
+        }
+    }
+}
+
+// Persistent waves trace the rays of stage `stage` (2 per path: sun, bounce).  Result per ray:
+//   x = bits(time), y = leaf index, z = voxel x | y << 16, w = voxel z | status << 16 | node level << 20.
+__global__ __launch_bounds__(kBlock) void trace_rays_kernel(const TraceArgs a, const RayQueue q, int stage) {
+    extern __shared__ uint2 lds_stack[];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const SceneView sc = make_scene(a);
+    uint2* stack = lds_stack + tid;
+    const SegTable seg = load_segments(q.counts, stage);
+    const unsigned total_rays = seg.pre[kSegments] * 2u;
+    const unsigned total_waves = gridDim.x * 4u;
+    unsigned per_wave = (total_rays + total_waves - 1u) / total_waves;
+    if (per_wave < kMinRaysPerWave) per_wave = kMinRaysPerWave;
+    const unsigned w_index = blockIdx.x * 4u + unsigned(wave);
+    unsigned cursor = w_index * per_wave;
+    const unsigned end = cursor + per_wave < total_rays ? cursor + per_wave : total_rays;
+    const float4* rays = q.rays[stage & 1];
+
+    Walk w;
+    bool active = false;
+    unsigned res_slot = 0;
+    uint32_t rays_cast = 0;
+    if (cursor < end) {
+        for (;;) {
+            const unsigned long long idle = __ballot(!active);
+            const int n_idle = __popcll(idle);
+            if (cursor < end && (n_idle >= kRefillLanes || n_idle == 64)) {
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi(unsigned(idle >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(idle), 0u));
+                const unsigned left = end - cursor;
+                const unsigned take = unsigned(n_idle) < left ? unsigned(n_idle) : left;
+                if (!active && rank < take) {
+                    const unsigned g = cursor + rank;
+                    const unsigned slot = segment_slot(seg, g >> 1, q.seg_capacity);
+                    const unsigned which = g & 1u;
+                    const float4 r0 = rays[size_t(slot) * 3];
+                    res_slot = slot * 2u + which;
+                    if (__float_as_uint(r0.w) & (which ? kFlagBounce : kFlagSun)) {
+                        const f3 d = xyz4(rays[size_t(slot) * 3 + 1 + which]);
+                        rays_cast++;
+                        if (walk_begin(w, sc, xyz4(r0), d)) active = true;
+                        else q.results[res_slot] = make_uint4(0u, 0u, 0u, unsigned(kWalkMiss) << 16);
+                    }
+                }
+                cursor += take;
+            } else if (n_idle == 64) {
+                break;
+            }
+            if (active) {
+                const int status = walk_step(w, sc, kAlmostInfinity, stack);
+                if (status != kWalkOn) {
+                    const unsigned vx = (w.ix << 1) | ((w.octant >> 2) & 1u), vy = (w.iy << 1) | ((w.octant >> 1) & 1u), vz = (w.iz << 1) | (w.octant & 1u);
+                    q.results[res_slot] = make_uint4(__float_as_uint(w.time), status == kWalkLeaf ? walk_leaf_index(w) : 0u, vx | vy << 16,
+                                                     vz | unsigned(status) << 16 | w.lvl << 20);
+                    active = false;
+                }
+            }
+        }
+    }
+    count_rays(a.ray_counter, rays_cast, lane);
+}
+
 }  // namespace
 
 hipError_t launch_trace_wavefront(const TraceArgs& a, const PathQueue queues[2], unsigned* count_sets[3], unsigned* launch_counter,
@@ -214,4 +520,25 @@ hipError_t launch_trace_wavefront(const TraceArgs& a, const PathQueue queues[2],
     return hipGetLastError();
 }
 
+
+hipError_t launch_trace_rayqueue(const TraceArgs& a, const PathQueue& hits_in, unsigned* count_sets[3], unsigned* launch_counter,
+                                 const RayQueue& q, int shade_blocks, int trace_blocks, hipStream_t s) {
+    dim3 grid((a.band.width + 15) / 16, (a.band.local_rows + 15) / 16);
+    const size_t lds = size_t(a.stack_levels) * kBlock * sizeof(uint2);
+    hipError_t e = hipMemsetAsync(q.counts, 0, size_t(a.max_bounces + 1) * kSegments * kCountStride * sizeof(unsigned), s);
+    if (e != hipSuccess) return e;
+    // the sharded hit queue's counter sets rotate as in launch_trace_wavefront: launch J writes set (J+1)%3,
+    // the consumer (launch J+1) reads it and clears set J%3
+    unsigned J = *launch_counter;
+    PathQueue hits = hits_in;
+    hits.counts = count_sets[(J + 1) % 3];
+    hipLaunchKernelGGL(primary_kernel, grid, dim3(kBlock), lds, s, a, hits, count_sets[(J + 2) % 3]);
+    hipLaunchKernelGGL(shade_kernel<true>, dim3(shade_blocks), dim3(kBlock), 0, s, a, hits, q, count_sets[J % 3], 0);
+    *launch_counter = J + 2;
+    for (int stage = 0; stage < a.max_bounces; stage++) {
+        hipLaunchKernelGGL(trace_rays_kernel, dim3(trace_blocks), dim3(kBlock), lds, s, a, q, stage);
+        hipLaunchKernelGGL(shade_kernel<false>, dim3(shade_blocks), dim3(kBlock), 0, s, a, hits, q, nullptr, stage + 1);
+    }
+    return hipGetLastError();
+}
 }  // namespace vxrt

@@ -99,11 +99,19 @@ struct vxrt_ctx {
     // stats
     unsigned long long* d_rays = nullptr;
     // wavefront tracer: two path queues (ping-pong) and three rotating sets of 64 shard counters
-    float4* d_queue[2] = {nullptr, nullptr};
-    unsigned* d_counts = nullptr;
+    struct StreamQueues {  // per trace stream; allocated only for the queue-based variants
+        float4* hitq[2] = {nullptr, nullptr};  // sharded PathRec queues (variant 2: ping-pong; variant 3: [0] = primary hits)
+        unsigned* counts3 = nullptr;            // three rotating sets of 64 shard counters
+        unsigned launches = 0;
+        RayQueue rq{};                          // variant 3
+        void* rq_block = nullptr;
+    };
+    std::vector<StreamQueues> queues;
     unsigned shard_capacity = 0;
-    unsigned wavefront_launches = 0;
-    int trace_variant = 0;  // 0 = monolithic trace_kernel (all bounces in one launch), 2 = wavefront (slower, kept for A/B)
+    // 0 = monolithic trace_kernel (all bounces in one launch; default), 2 = wavefront launches per path segment,
+    // 3 = ray queues: shade / trace launches with per-lane ray refill
+    int trace_variant = 0;
+    int shade_blocks = 1024;
     // longest-tile-first scheduling of the monolithic kernel: cost of every 16x16 tile in the last frame -> order
     struct TileSchedule {  // one per trace stream: costs of the frame it traced last, and the order made from them
         uint32_t* cost = nullptr;
@@ -145,7 +153,7 @@ void free_images(vxrt_ctx* c) {
         if (sl.last_use) (void)hipEventDestroy(sl.last_use);
     }
     c->ring.clear();
-    float4** imgs[] = {&c->accum[0], &c->accum[1], &c->denoised, &c->halo, &c->d_queue[0], &c->d_queue[1]};
+    float4** imgs[] = {&c->accum[0], &c->accum[1], &c->denoised, &c->halo};
     for (float4** p : imgs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -153,6 +161,12 @@ void free_images(vxrt_ctx* c) {
     for (vxrt_ctx::TileSchedule& t : c->schedules)
         for (uint32_t** p : {&t.cost, &t.order, &t.last_cost}) { if (*p) (void)hipFree(*p); *p = nullptr; }
     c->schedules.clear();
+    for (vxrt_ctx::StreamQueues& sq : c->queues) {
+        for (float4** p : {&sq.hitq[0], &sq.hitq[1]}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        if (sq.counts3) (void)hipFree(sq.counts3);
+        if (sq.rq_block) (void)hipFree(sq.rq_block);
+    }
+    c->queues.clear();
 }
 
 int alloc_images(vxrt_ctx* c) {
@@ -178,8 +192,33 @@ int alloc_images(vxrt_ctx* c) {
     // path queues: every 8x8-pixel wave of the primary launch appends to shard (wave index % 64)
     const size_t waves = size_t((c->band.width + 15) / 16) * size_t((c->band.local_rows + 15) / 16) * 4;
     c->shard_capacity = unsigned((waves + 63) / 64 * 64);
-    for (int i = 0; i < 2; i++)
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_queue[i]), (size_t(c->shard_capacity) * 64 + 1) * 64));
+    if (c->trace_variant != 0) {
+        c->queues.resize(size_t(c->inflight));
+        for (vxrt_ctx::StreamQueues& sq : c->queues) {
+            const size_t hit_bytes = (size_t(c->shard_capacity) * 64 + 1) * 64;
+            for (int i = 0; i < (c->trace_variant == 2 ? 2 : 1); i++) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sq.hitq[i]), hit_bytes));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sq.counts3), 3 * 64 * 64));
+            HIP_TRY(hipMemsetAsync(sq.counts3, 0, 3 * 64 * 64, c->stream));
+            sq.launches = 0;
+            if (c->trace_variant == 3) {
+                // Dense queues in kSegments segments.  A shade launch of G blocks (G a multiple of 8) hands every segment
+                // G/8 blocks x 256 items per trip, so a segment receives at most its eighth of the paths rounded up to
+                // a whole trip: paths/8 + 32 G.
+                const size_t cap = waves * 64 / kSegments + size_t(c->shade_blocks) * 32 + 1024;
+                const size_t per_path = 2 * 64 + 2 * 48 + 32;  // state x2, rays x2, results
+                const size_t counts_bytes = size_t(c->cfg.max_bounces + 1) * kSegments * 64;
+                HIP_TRY(hipMalloc(&sq.rq_block, kSegments * cap * per_path + counts_bytes + 256));
+                char* p = static_cast<char*>(sq.rq_block);
+                sq.rq.state[0] = reinterpret_cast<float4*>(p); p += kSegments * cap * 64;
+                sq.rq.state[1] = reinterpret_cast<float4*>(p); p += kSegments * cap * 64;
+                sq.rq.rays[0] = reinterpret_cast<float4*>(p); p += kSegments * cap * 48;
+                sq.rq.rays[1] = reinterpret_cast<float4*>(p); p += kSegments * cap * 48;
+                sq.rq.results = reinterpret_cast<uint4*>(p); p += kSegments * cap * 32;
+                sq.rq.counts = reinterpret_cast<unsigned*>(p);
+                sq.rq.seg_capacity = unsigned(cap);
+            }
+        }
+    }
     const size_t tiles = waves / 4;
     c->schedules.resize(size_t(c->inflight));
     for (vxrt_ctx::TileSchedule& t : c->schedules) {
@@ -400,9 +439,15 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipStreamCreate"));
     c->inflight = cfg->frames_in_flight == 0 ? 1 : int(cfg->frames_in_flight);
     if (const char* v = getenv("VXRT_INFLIGHT")) c->inflight = atoi(v);
+    // vxrt_config.tracer: 0 auto, 1 monolithic, 2 wavefront, 3 ray queues (internally 0, 2, 3).  Measured on MI355X with
+    // frames in flight: the monolithic kernel wins at 3-4 bounces, the queue variants when paths run 8 bounces deep.
+    if (cfg->tracer > 3) { set_error("tracer must be 0..3"); return fail(VXRT_E_INVALID); }
+    c->trace_variant = cfg->tracer == 0 ? (cfg->max_bounces < 6 ? 0 : 3) : (cfg->tracer == 1 ? 0 : int(cfg->tracer));
     if (const char* v = getenv("VXRT_TRACE_VARIANT")) c->trace_variant = atoi(v);
+    if (const char* v = getenv("VXRT_SHADE_BLOCKS")) c->shade_blocks = atoi(v);
+    c->shade_blocks = (c->shade_blocks < 8 ? 8 : (c->shade_blocks > 2048 ? 2048 : c->shade_blocks) + 7) / 8 * 8;
+    if (const char* v = getenv("VXRT_TRACE_BLOCKS")) c->trace_blocks = atoi(v);
     if (c->inflight < 1 || c->inflight > 16) { set_error("frames_in_flight must be 1..16"); return fail(VXRT_E_INVALID); }
-    if (c->trace_variant != 0) c->inflight = 1;  // the wavefront variant shares its queues between frames
     c->trace_streams.assign(size_t(c->inflight), nullptr);
     if (c->inflight == 1) {
         c->trace_streams[0] = c->stream;
@@ -420,9 +465,6 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) {
     }
     if (hipMalloc(reinterpret_cast<void**>(&c->d_rays), kRaySlots * 64) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipMalloc counter"));
     if (hipMemsetAsync(c->d_rays, 0, kRaySlots * 64, c->stream) != hipSuccess) return fail(hip_fail(hipGetLastError(), "memset counter"));
-    if (hipMalloc(reinterpret_cast<void**>(&c->d_counts), 3 * 64 * 64) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipMalloc queue counters"));
-    if (hipMemsetAsync(c->d_counts, 0, 3 * 64 * 64, c->stream) != hipSuccess) return fail(hip_fail(hipGetLastError(), "memset queue counters"));
-    if (const char* v = getenv("VXRT_TRACE_BLOCKS")) c->trace_blocks = atoi(v);
     if (const char* v = getenv("VXRT_TILE_ORDER")) c->use_tile_order = atoi(v);
     if (const char* v = getenv("VXRT_TRACE_SPLIT")) c->trace_split = unsigned(strtoul(v, nullptr, 0));
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(hip_fail(hipGetLastError(), "sync"));
@@ -442,7 +484,6 @@ int vxrt_destroy(vxrt_ctx* c) {
     if (c->d_leaves) (void)hipFree(c->d_leaves);
     if (c->d_noise) (void)hipFree(c->d_noise);
     if (c->d_rays) (void)hipFree(c->d_rays);
-    if (c->d_counts) (void)hipFree(c->d_counts);
     for (hipStream_t t : c->trace_streams) if (t && t != c->stream) (void)hipStreamDestroy(t);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -612,9 +653,13 @@ int vxrt_render(vxrt_ctx* c, uint32_t flags) {
                 }
                 sched.age++;
             } else {
-                PathQueue queues[2] = {{c->d_queue[0], nullptr, c->shard_capacity}, {c->d_queue[1], nullptr, c->shard_capacity}};
-                unsigned* sets[3] = {c->d_counts, c->d_counts + 64 * 16, c->d_counts + 2 * 64 * 16};
-                HIP_TRY(launch_trace_wavefront(a, queues, sets, &c->wavefront_launches, c->trace_blocks, c->trace_split, ts));
+                vxrt_ctx::StreamQueues& sq = c->queues[lane];
+                PathQueue queues[2] = {{sq.hitq[0], nullptr, c->shard_capacity}, {sq.hitq[1], nullptr, c->shard_capacity}};
+                unsigned* sets[3] = {sq.counts3, sq.counts3 + 64 * 16, sq.counts3 + 2 * 64 * 16};
+                if (c->trace_variant == 2)
+                    HIP_TRY(launch_trace_wavefront(a, queues, sets, &sq.launches, c->trace_blocks, c->trace_split, ts));
+                else
+                    HIP_TRY(launch_trace_rayqueue(a, queues[0], sets, &sq.launches, sq.rq, c->shade_blocks, c->trace_blocks, ts));
                 if (timed) HIP_TRY(hipEventRecord(p.b, ts));
             }
             if (timed) c->pending.push_back(p);

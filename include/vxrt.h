@@ -98,6 +98,11 @@ typedef struct vxrt_config {
                                  reference's single queue).  F = 2..8: the TRACE stage of up to F consecutive
                                  frames may run concurrently (one HIP stream each, ring of F+2 G-buffer slots);
                                  temporal/denoise still run in frame order.  Results are identical.       */
+    uint32_t tracer;          /* scheduling of the trace stage; every choice gives bit-identical images:
+                                 0 auto (1 for max_bounces < 6, else 3), 1 monolithic kernel (one pixel per lane,
+                                 all bounces, longest-tile-first), 2 wavefront (one launch per path segment, live
+                                 paths compacted in between), 3 ray queues (shade / trace launches, lanes refilled
+                                 ray by ray).                                                              */
 } vxrt_config;
 
 typedef enum vxrt_image {

@@ -138,6 +138,9 @@ def test_full_size_bench_config_crops(O, H, scenes, noise):
     {"VXRT_TRACE_VARIANT": "2", "VXRT_TRACE_SPLIT": "0x1"},   # wavefront: primary launch + one launch for all segments
     {"VXRT_TRACE_VARIANT": "2", "VXRT_TRACE_SPLIT": "0x5"},   # wavefront: queues compacted before segments 0 and 2
     {"VXRT_TRACE_VARIANT": "2", "VXRT_TRACE_SPLIT": "0xff", "VXRT_TRACE_BLOCKS": "64"},  # every segment its own launch; few waves loop over many chunks
+    {"VXRT_TRACE_VARIANT": "3"},                                                        # ray queues: shade / trace launches, per-lane refill
+    {"VXRT_TRACE_VARIANT": "3", "VXRT_TRACE_BLOCKS": "3", "VXRT_SHADE_BLOCKS": "5"},    # ... few waves: many refills per lane, several trips
+    {"VXRT_TRACE_VARIANT": "3", "VXRT_INFLIGHT": "3"},                                  # ... with frames in flight
 ])
 def test_every_trace_variant_is_bit_exact(O, H, scenes, noise, monkeypatch, env):
     """The scheduling variants of the tracer (read from the environment when a context is created) change
@@ -272,3 +275,21 @@ def test_iteration_cap(O, H, noise):
         assert rays == ref[3]
         capped = (ref[2][..., 3].view(np.uint32) == 0x80000000)
     assert iters[0] < 2048 or node[0] == -2147483648
+
+
+def test_tracer_field_of_the_config(O, H, scenes, noise):
+    """vxrt_config.tracer picks the scheduling variant (0 = auto: ray queues from 6 bounces on); same image either way."""
+    from gpu_voxel_raytracer_amd import Context, Camera, TRACE, VxrtError
+    pos, mrgb, size = scenes.load_scene("castle")
+    cam = scenes.close_camera(size)
+    imgs = []
+    for tracer, bounces in ((0, 8), (1, 8), (2, 8), (3, 8)):
+        with Context(128, 80, max_bounces=bounces, noise=noise, tracer=tracer) as ctx:
+            ctx.recreate_octree(pos, mrgb)
+            ctx.camera = Camera(*cam)
+            ctx.render(TRACE)
+            imgs.append(ctx.read(0))
+    for im in imgs[1:]:
+        assert_bits_equal(im, imgs[0], "tracer variants")
+    with pytest.raises(VxrtError):
+        Context(64, 64, tracer=7)
