@@ -103,7 +103,7 @@ struct RayQueue {
 hipError_t launch_trace(const TraceArgs& a, hipStream_t s);  // monolithic: one pixel per lane, all bounces
 // ray queues: primary_kernel, then shade / trace-rays launches per path segment with per-lane ray refill
 hipError_t launch_trace_rayqueue(const TraceArgs& a, const PathQueue& hits, unsigned* count_sets[3], unsigned* launch_counter,
-                                 const RayQueue& q, int shade_blocks, int trace_blocks, hipStream_t s);
+                                 const RayQueue& q, int shade_blocks, int trace_blocks, unsigned min_rays_per_wave, hipStream_t s);
 // longest-tile-first schedule for the next launch: order[] = tiles sorted by descending cost; cost[] is cleared
 hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t* last_cost, unsigned tiles, hipStream_t s);
 // wavefront: primary_kernel + max_bounces x bounce_kernel; queues[2] ping-pong, count_sets[3] rotate

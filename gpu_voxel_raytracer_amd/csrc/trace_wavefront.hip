@@ -431,17 +431,18 @@ __global__ __launch_bounds__(kBlock) void shade_kernel(const TraceArgs a, const 
 
 // Persistent waves trace the rays of stage `stage` (2 per path: sun, bounce).  Result per ray:
 //   x = bits(time), y = leaf index, z = voxel x | y << 16, w = voxel z | status << 16 | node level << 20.
-__global__ __launch_bounds__(kBlock) void trace_rays_kernel(const TraceArgs a, const RayQueue q, int stage) {
+__global__ __launch_bounds__(kBlock) void trace_rays_kernel(const TraceArgs a, const RayQueue q, int stage, unsigned min_rays_per_wave) {
     extern __shared__ uint2 lds_stack[];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const SceneView sc = make_scene(a);
     uint2* stack = lds_stack + tid;
     const SegTable seg = load_segments(q.counts, stage);
-    const unsigned total_rays = seg.pre[kSegments] * 2u;
+    const unsigned n_paths = seg.pre[kSegments];
+    const unsigned total_rays = n_paths * 2u;
     const unsigned total_waves = gridDim.x * 4u;
     unsigned per_wave = (total_rays + total_waves - 1u) / total_waves;
-    if (per_wave < kMinRaysPerWave) per_wave = kMinRaysPerWave;
+    if (per_wave < min_rays_per_wave) per_wave = min_rays_per_wave;
     const unsigned w_index = blockIdx.x * 4u + unsigned(wave);
     unsigned cursor = w_index * per_wave;
     const unsigned end = cursor + per_wave < total_rays ? cursor + per_wave : total_rays;
@@ -460,9 +461,11 @@ __global__ __launch_bounds__(kBlock) void trace_rays_kernel(const TraceArgs a, c
                 const unsigned left = end - cursor;
                 const unsigned take = unsigned(n_idle) < left ? unsigned(n_idle) : left;
                 if (!active && rank < take) {
+                    // rays [0, N) are the paths' sun rays (all towards the sun, origins in tile order: coherent),
+                    // rays [N, 2N) their bounce rays (random directions)
                     const unsigned g = cursor + rank;
-                    const unsigned slot = segment_slot(seg, g >> 1, q.seg_capacity);
-                    const unsigned which = g & 1u;
+                    const unsigned which = g >= n_paths ? 1u : 0u;
+                    const unsigned slot = segment_slot(seg, which ? g - n_paths : g, q.seg_capacity);
                     const float4 r0 = rays[size_t(slot) * 3];
                     res_slot = slot * 2u + which;
                     if (__float_as_uint(r0.w) & (which ? kFlagBounce : kFlagSun)) {
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(kBlock) void trace_rays_kernel(const TraceArgs a, c
                 break;
             }
             if (active) {
-                const int status = walk_step(w, sc, kAlmostInfinity, stack);
+                const int status = walk_step_uniform(w, sc, kAlmostInfinity, stack);
                 if (status != kWalkOn) {
                     const unsigned vx = (w.ix << 1) | ((w.octant >> 2) & 1u), vy = (w.iy << 1) | ((w.octant >> 1) & 1u), vz = (w.iz << 1) | (w.octant & 1u);
                     q.results[res_slot] = make_uint4(__float_as_uint(w.time), status == kWalkLeaf ? walk_leaf_index(w) : 0u, vx | vy << 16,
@@ -522,7 +525,7 @@ hipError_t launch_trace_wavefront(const TraceArgs& a, const PathQueue queues[2],
 
 
 hipError_t launch_trace_rayqueue(const TraceArgs& a, const PathQueue& hits_in, unsigned* count_sets[3], unsigned* launch_counter,
-                                 const RayQueue& q, int shade_blocks, int trace_blocks, hipStream_t s) {
+                                 const RayQueue& q, int shade_blocks, int trace_blocks, unsigned min_rays_per_wave, hipStream_t s) {
     dim3 grid((a.band.width + 15) / 16, (a.band.local_rows + 15) / 16);
     const size_t lds = size_t(a.stack_levels) * kBlock * sizeof(uint2);
     hipError_t e = hipMemsetAsync(q.counts, 0, size_t(a.max_bounces + 1) * kSegments * kCountStride * sizeof(unsigned), s);
@@ -536,7 +539,7 @@ hipError_t launch_trace_rayqueue(const TraceArgs& a, const PathQueue& hits_in, u
     hipLaunchKernelGGL(shade_kernel<true>, dim3(shade_blocks), dim3(kBlock), 0, s, a, hits, q, count_sets[J % 3], 0);
     *launch_counter = J + 2;
     for (int stage = 0; stage < a.max_bounces; stage++) {
-        hipLaunchKernelGGL(trace_rays_kernel, dim3(trace_blocks), dim3(kBlock), lds, s, a, q, stage);
+        hipLaunchKernelGGL(trace_rays_kernel, dim3(trace_blocks), dim3(kBlock), lds, s, a, q, stage, min_rays_per_wave);
         hipLaunchKernelGGL(shade_kernel<false>, dim3(shade_blocks), dim3(kBlock), 0, s, a, hits, q, nullptr, stage + 1);
     }
     return hipGetLastError();

@@ -112,6 +112,7 @@ struct vxrt_ctx {
     // 3 = ray queues: shade / trace launches with per-lane ray refill
     int trace_variant = 0;
     int shade_blocks = 1024;
+    unsigned rays_per_wave = 256;  // ray-queue tracer: fewest rays a trace wave takes (more = better lane refill, fewer waves)
     // longest-tile-first scheduling of the monolithic kernel: cost of every 16x16 tile in the last frame -> order
     struct TileSchedule {  // one per trace stream: costs of the frame it traced last, and the order made from them
         uint32_t* cost = nullptr;
@@ -445,6 +446,7 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) {
     c->trace_variant = cfg->tracer == 0 ? (cfg->max_bounces < 6 ? 0 : 3) : (cfg->tracer == 1 ? 0 : int(cfg->tracer));
     if (const char* v = getenv("VXRT_TRACE_VARIANT")) c->trace_variant = atoi(v);
     if (const char* v = getenv("VXRT_SHADE_BLOCKS")) c->shade_blocks = atoi(v);
+    if (const char* v = getenv("VXRT_RAYS_PER_WAVE")) c->rays_per_wave = unsigned(atoi(v));
     c->shade_blocks = (c->shade_blocks < 8 ? 8 : (c->shade_blocks > 2048 ? 2048 : c->shade_blocks) + 7) / 8 * 8;
     if (const char* v = getenv("VXRT_TRACE_BLOCKS")) c->trace_blocks = atoi(v);
     if (c->inflight < 1 || c->inflight > 16) { set_error("frames_in_flight must be 1..16"); return fail(VXRT_E_INVALID); }
@@ -659,7 +661,7 @@ int vxrt_render(vxrt_ctx* c, uint32_t flags) {
                 if (c->trace_variant == 2)
                     HIP_TRY(launch_trace_wavefront(a, queues, sets, &sq.launches, c->trace_blocks, c->trace_split, ts));
                 else
-                    HIP_TRY(launch_trace_rayqueue(a, queues[0], sets, &sq.launches, sq.rq, c->shade_blocks, c->trace_blocks, ts));
+                    HIP_TRY(launch_trace_rayqueue(a, queues[0], sets, &sq.launches, sq.rq, c->shade_blocks, c->trace_blocks, c->rays_per_wave, ts));
                 if (timed) HIP_TRY(hipEventRecord(p.b, ts));
             }
             if (timed) c->pending.push_back(p);
