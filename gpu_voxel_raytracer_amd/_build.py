@@ -35,6 +35,21 @@ def build(force=False, verbose=False, extra_flags=()):
     return LIB
 
 
+TOOL = os.path.join(HERE, "vxrt_render")
+TOOL_SRC = os.path.join(os.path.dirname(HERE), "tools", "vxrt_render.cpp")
+
+
+def build_tool(force=False):
+    """The C++ headless driver (tools/vxrt_render.cpp over include/vxrt.hpp), linked against libvxrt.so."""
+    build()
+    if not force and os.path.exists(TOOL) and os.path.getmtime(TOOL) >= max(os.path.getmtime(TOOL_SRC), os.path.getmtime(LIB)):
+        return TOOL
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", TOOL_SRC, "-o", TOOL, "-L" + HERE, "-lvxrt",
+                           "-Wl,-rpath,$ORIGIN"])
+    return TOOL
+
+
 if __name__ == "__main__":
     import sys
     build(force="-f" in sys.argv, verbose=True)
+    build_tool(force="-f" in sys.argv)

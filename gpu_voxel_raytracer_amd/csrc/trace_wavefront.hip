@@ -207,14 +207,10 @@ __global__ __launch_bounds__(kBlock, VXRT_BOUNCE_WAVES) void bounce_kernel(const
 // The per-path operation order is that of voxels.comp, the results are bit-identical to trace_kernel's.
 // ------------------------------------------------------------------------------------------------------
 constexpr unsigned kFlagSun = 1u, kFlagBounce = 2u;
-#ifndef VXRT_MIN_RAYS_PER_WAVE
-#define VXRT_MIN_RAYS_PER_WAVE 64
-#endif
 #ifndef VXRT_REFILL_LANES
 #define VXRT_REFILL_LANES 16
 #endif
 constexpr int kRefillLanes = VXRT_REFILL_LANES;  // refill when this many lanes of the wave are idle (or all the rest are done)
-constexpr unsigned kMinRaysPerWave = VXRT_MIN_RAYS_PER_WAVE;
 
 struct SegTable {  // the 8 segment counts of one stage as exclusive prefix sums
     unsigned pre[kSegments + 1];
@@ -304,7 +300,7 @@ template <bool kFirst>
 __global__ __launch_bounds__(kBlock) void shade_kernel(const TraceArgs a, const PathQueue hits, const RayQueue q, unsigned* zero, int stage) {
     __shared__ unsigned lds_counts[8];
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int lane = tid & 63;
     if (kFirst) zero_counts(zero, tid);
     const SceneView sc = make_scene(a);
     const f3 sun_dir = ld3(a.sun_dir), sun_color = ld3(a.sun_color), sky = ld3(a.sky_color);

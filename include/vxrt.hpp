@@ -1,0 +1,148 @@
+// vxrt.hpp — C++17 host-side mirror of the reference's render-loop types over the C ABI (vxrt.h).
+//
+// The reference's host is Rust (src/main.rs, src/context.rs, src/camera.rs); no Rust toolchain exists in the build
+// image, so the compiled-language host above the C ABI is this header: the same names and argument meaning —
+//   Camera{position, direction, fov}                         src/camera.rs:5-9
+//   Uniforms / TemporalUniforms / DenoiseUniforms            src/context.rs:425-525, 304-325
+//   Context::new / resize / recreate_octree / render         src/context.rs:595-660, 1430-1461, 799-810, 2004-2075
+// Errors are reported as vxrt::Error exceptions carrying the vxrt_status and the library's message, where the
+// reference returns anyhow::Error (or panics).  Header-only; link with -lvxrt.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "vxrt.h"
+
+namespace vxrt {
+
+class Error : public std::runtime_error {
+  public:
+    Error(int status, const std::string& where)
+        : std::runtime_error(where + ": " + vxrt_status_string(status) + " (" + vxrt_last_error() + ")"), status_(status) {}
+    int status() const { return status_; }
+
+  private:
+    int status_;
+};
+
+inline void check(int status, const char* where) {
+    if (status != VXRT_OK) throw Error(status, where);
+}
+
+using Vec3 = std::array<float, 3>;
+
+// src/camera.rs:5-9; the default is the reference's start camera (src/context.rs:618-622), fov = 70 degrees.
+struct Camera {
+    Vec3 position{0.0f, 0.0f, -2.0f};
+    Vec3 direction{0.0f, 0.0f, 1.0f};
+    float fov = 70.0f * (3.14159274f / 180.0f);
+
+    // Camera::axis_scaled (src/camera.rs:19-28): right, up, forward_ray
+    std::array<Vec3, 3> axis_scaled(uint32_t width, uint32_t height) const {
+        std::array<Vec3, 3> out{};
+        check(vxrt_camera_axis_scaled(position.data(), direction.data(), fov, width, height, out[0].data(), out[1].data(), out[2].data()),
+              "vxrt_camera_axis_scaled");
+        return out;
+    }
+};
+
+struct Uniforms : vxrt_uniforms {
+    Uniforms() { vxrt_default_uniforms(this); }   // Uniforms::default(), src/context.rs:471-498
+};
+struct TemporalUniforms : vxrt_temporal {
+    TemporalUniforms() { vxrt_default_temporal(this); }
+};
+struct DenoiseUniforms : vxrt_denoise {
+    DenoiseUniforms() { vxrt_default_denoise(this); }
+};
+
+// A voxel as the reference's adapters produce it: ([i16; 3], [material, r, g, b]) (src/context.rs:777, 913-933).
+struct VoxelList {
+    std::vector<std::array<int16_t, 3>> pos;
+    std::vector<std::array<uint8_t, 4>> mrgb;
+    std::array<uint32_t, 3> size{};
+};
+
+// vox::parse + Context::voxels_from_vox (src/vox.rs:11-70, src/context.rs:913-933)
+inline VoxelList voxels_from_vox(const std::vector<uint8_t>& bytes) {
+    VoxelList v;
+    size_t n = 0;
+    check(vxrt_vox_to_voxels(bytes.data(), bytes.size(), nullptr, nullptr, 0, &n, v.size.data()), "vxrt_vox_to_voxels");
+    v.pos.resize(n);
+    v.mrgb.resize(n);
+    check(vxrt_vox_to_voxels(bytes.data(), bytes.size(), reinterpret_cast<int16_t(*)[3]>(v.pos.data()),
+                             reinterpret_cast<uint8_t(*)[4]>(v.mrgb.data()), n, &n, v.size.data()),
+          "vxrt_vox_to_voxels");
+    return v;
+}
+
+class Context {
+  public:
+    Camera camera;
+    Uniforms uniforms;
+    TemporalUniforms temporal_uniforms;
+    DenoiseUniforms denoise_uniforms;
+
+    Context(uint32_t width, uint32_t height, uint32_t max_bounces = 3, int device = 0, uint32_t frames_in_flight = 1,
+            uint32_t rank = 0, uint32_t nranks = 1)
+        : width_(width), height_(height) {
+        vxrt_config cfg{};
+        cfg.width = width; cfg.height = height; cfg.device = device; cfg.max_bounces = max_bounces;
+        cfg.noise_seed = 0x5EED0001u; cfg.noise = nullptr; cfg.rank = rank; cfg.nranks = nranks; cfg.band_rows = 16;
+        cfg.frames_in_flight = frames_in_flight; cfg.tracer = 0;
+        check(vxrt_create(&cfg, &ctx_), "vxrt_create");
+    }
+    ~Context() { vxrt_destroy(ctx_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+
+    // Context::recreate_octree (src/context.rs:799-810)
+    void recreate_octree(const VoxelList& voxels) {
+        check(vxrt_set_voxels(ctx_, reinterpret_cast<const int16_t(*)[3]>(voxels.pos.data()),
+                              reinterpret_cast<const uint8_t(*)[4]>(voxels.mrgb.data()), voxels.pos.size()),
+              "vxrt_set_voxels");
+    }
+    void load_vox(const std::string& path) { check(vxrt_load_vox(ctx_, path.c_str()), "vxrt_load_vox"); }
+    void set_menger(uint32_t level, uint32_t clip, std::array<uint8_t, 4> mrgb, uint32_t emissive_period) {
+        check(vxrt_set_menger(ctx_, level, clip, mrgb.data(), emissive_period), "vxrt_set_menger");
+    }
+    // Context::resize (src/context.rs:1430-1461)
+    void resize(uint32_t width, uint32_t height) {
+        check(vxrt_resize(ctx_, width, height), "vxrt_resize");
+        width_ = width; height_ = height;
+    }
+    // Context::update_bindings + render (src/context.rs:2136-2162, 2004-2075)
+    void render(uint32_t flags = VXRT_ALL) {
+        check(vxrt_set_camera(ctx_, camera.position.data(), camera.direction.data(), camera.fov), "vxrt_set_camera");
+        check(vxrt_set_scene_params(ctx_, &uniforms), "vxrt_set_scene_params");
+        check(vxrt_set_temporal(ctx_, &temporal_uniforms), "vxrt_set_temporal");
+        check(vxrt_set_denoise(ctx_, &denoise_uniforms), "vxrt_set_denoise");
+        check(vxrt_render(ctx_, flags), "vxrt_render");
+    }
+    void sync() { check(vxrt_sync(ctx_), "vxrt_sync"); }
+    std::vector<float> read(vxrt_image which) {
+        uint32_t rows = 0;
+        check(vxrt_local_rows(ctx_, &rows, nullptr), "vxrt_local_rows");
+        std::vector<float> img(size_t(rows) * width_ * 4);
+        check(vxrt_read(ctx_, which, img.data(), img.size() * sizeof(float)), "vxrt_read");
+        return img;
+    }
+    vxrt_stats stats() {
+        vxrt_stats s{};
+        check(vxrt_get_stats(ctx_, &s), "vxrt_get_stats");
+        return s;
+    }
+    uint32_t width() const { return width_; }
+    uint32_t height() const { return height_; }
+    vxrt_ctx* handle() { return ctx_; }
+
+  private:
+    vxrt_ctx* ctx_ = nullptr;
+    uint32_t width_, height_;
+};
+
+}  // namespace vxrt

@@ -55,3 +55,12 @@ def test_null_and_invalid_arguments_return_errors(H):
     n = ctypes.c_size_t(0)
     assert lib.vxrt_vox_to_voxels(None, 0, None, None, 0, ctypes.byref(n), None) == H.E_INVALID
     assert lib.vxrt_menger_voxels(12, None, None, None, 0, ctypes.byref(n)) == H.E_INVALID
+
+
+def test_cpp_header_compiles_and_links():
+    """include/vxrt.hpp (the C++ host mirror) and tools/vxrt_render.cpp build against libvxrt.so with g++ alone."""
+    from gpu_voxel_raytracer_amd import _build
+    tool = _build.build_tool(force=True)
+    assert os.path.exists(tool)
+    out = subprocess.run([tool], capture_output=True, text=True)
+    assert out.returncode == 2 and "usage:" in out.stderr

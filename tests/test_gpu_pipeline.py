@@ -211,3 +211,29 @@ def test_headless_frame_loop(H, scenes, tmp_path):
     img2, _ = frame_loop.run("menger:3:20:5", 96, 64, frames=2, bounces=2)
     assert np.isfinite(img2).all()
     assert frame_loop.srgb8(np.array([[[0.0, 0.5, 2.0]]], np.float32)).tolist() == [[[0, 188, 255]]]
+
+
+def test_cpp_host_driver_matches_python_host(H, scenes, tmp_path):
+    """tools/vxrt_render.cpp (C++ host over include/vxrt.hpp: Camera / Uniforms / Context as in the reference)
+    renders the same frames as the ctypes host: byte-identical float image."""
+    import subprocess
+    from gpu_voxel_raytracer_amd import ALL, DENOISED, Camera, Context, _build
+    tool = _build.build_tool()
+    w, h, frames, bounces, radius = 160, 90, 3, 4, 2
+    ppm, raw = str(tmp_path / "m.ppm"), str(tmp_path / "m.f32")
+    out = subprocess.run([tool, "menger:4", str(w), str(h), str(frames), str(bounces), str(radius), ppm, raw],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    got = np.fromfile(raw, np.float32).reshape(h, w, 4)
+    with Context(w, h, max_bounces=bounces) as ctx:
+        ctx.set_menger(4, 0, (0, 0x7b, 0xa2, 0x3f), 0)
+        ctx.camera = Camera(*scenes.bench_camera((81, 81, 81)))
+        ctx.denoise_uniforms.radius = radius
+        for _ in range(frames):
+            ctx.render(ALL)
+        want = ctx.read(DENOISED)
+    assert_bits_equal(got, want, "C++ driver vs Python host")
+    header = b"P6\n160 90\n255\n"
+    assert open(ppm, "rb").read(len(header)) == header and os.path.getsize(ppm) == len(header) + w * h * 3
+    bad = subprocess.run([tool, "/nonexistent.vox", "64", "64", "1", "3", "0", ppm], capture_output=True, text=True)
+    assert bad.returncode == 1 and "cannot open" in bad.stderr

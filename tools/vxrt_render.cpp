@@ -1,0 +1,79 @@
+// vxrt_render — headless render loop in C++ over include/vxrt.hpp: what the reference's src/main.rs does with a
+// window (load a model, place the camera, render frames) ending in a PPM of the last denoised frame and, optionally,
+// a raw float dump.
+//
+//   vxrt_render <scene.vox | menger:<level>[:clip[:emissive_period]]> <width> <height> <frames> <bounces> <radius> <out.ppm> [out.f32]
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+
+#include "../include/vxrt.hpp"
+
+static unsigned char srgb8(float x) {  // what a Bgra8UnormSrgb swap chain stores (src/context.rs:696-706)
+    if (!(x == x)) x = 0.0f;
+    x = std::min(1.0f, std::max(0.0f, x));
+    float y = x <= 0.0031308f ? 12.92f * x : 1.055f * std::pow(x, 1.0f / 2.4f) - 0.055f;
+    return static_cast<unsigned char>(y * 255.0f + 0.5f);
+}
+
+int main(int argc, char** argv) {
+    if (argc < 8) {
+        std::fprintf(stderr, "usage: %s <scene.vox|menger:L[:clip[:period]]> <width> <height> <frames> <bounces> <radius> <out.ppm> [out.f32]\n", argv[0]);
+        return 2;
+    }
+    try {
+        const std::string scene = argv[1];
+        const uint32_t width = std::atoi(argv[2]), height = std::atoi(argv[3]);
+        const int frames = std::atoi(argv[4]);
+        vxrt::Context ctx(width, height, std::atoi(argv[5]));
+        ctx.denoise_uniforms.radius = std::atoi(argv[6]);
+        float extent[3];
+        if (scene.rfind("menger:", 0) == 0) {
+            unsigned level = 0, clip = 0, period = 0;
+            std::sscanf(scene.c_str() + 7, "%u:%u:%u", &level, &clip, &period);
+            ctx.set_menger(level, clip, {0, 0x7b, 0xa2, 0x3f}, period);
+            unsigned side = 1;
+            for (unsigned l = 0; l < level; l++) side *= 3;
+            if (clip && clip < side) side = clip;
+            extent[0] = extent[1] = extent[2] = side * 0.5f;
+        } else {
+            std::ifstream f(scene, std::ios::binary);
+            if (!f) throw std::runtime_error("cannot open " + scene);
+            std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+            vxrt::VoxelList voxels = vxrt::voxels_from_vox(bytes);
+            ctx.recreate_octree(voxels);
+            // file axes (x, y, z) -> renderer axes (x, z, y), half a world unit per voxel
+            extent[0] = voxels.size[0] * 0.5f; extent[1] = voxels.size[2] * 0.5f; extent[2] = voxels.size[1] * 0.5f;
+        }
+        // the fixed outside view of SURVEY.md §8d: position = c + e * (-0.9, 0.6, -1.2), looking at c
+        const float e = std::max(extent[0], std::max(extent[1], extent[2]));
+        const float k[3] = {-0.9f, 0.6f, -1.2f};
+        for (int i = 0; i < 3; i++) {
+            const float c = extent[i] * 0.5f;
+            ctx.camera.position[i] = c + e * k[i];
+            ctx.camera.direction[i] = c - ctx.camera.position[i];
+        }
+        for (int f = 0; f < frames; f++) ctx.render(VXRT_ALL);
+        std::vector<float> img = ctx.read(VXRT_DENOISED);
+        const vxrt_stats st = ctx.stats();
+        std::ofstream ppm(argv[7], std::ios::binary);
+        ppm << "P6\n" << width << " " << height << "\n255\n";
+        for (size_t p = 0; p < size_t(width) * height; p++) {
+            const unsigned char rgb[3] = {srgb8(img[4 * p]), srgb8(img[4 * p + 1]), srgb8(img[4 * p + 2])};
+            ppm.write(reinterpret_cast<const char*>(rgb), 3);
+        }
+        if (argc > 8) {
+            std::ofstream raw(argv[8], std::ios::binary);
+            raw.write(reinterpret_cast<const char*>(img.data()), std::streamsize(img.size() * sizeof(float)));
+        }
+        std::printf("%s: %llu frames, %llu rays, %ux%u -> %s\n", scene.c_str(), (unsigned long long)st.frames, (unsigned long long)st.rays, width, height, argv[7]);
+        return 0;
+    } catch (const std::exception& ex) {
+        std::fprintf(stderr, "vxrt_render: %s\n", ex.what());
+        return 1;
+    }
+}
