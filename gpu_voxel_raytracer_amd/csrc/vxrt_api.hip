@@ -444,7 +444,8 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) {
     // frames in flight: the monolithic kernel wins at 3-4 bounces, the queue variants when paths run 8 bounces deep.
     if (cfg->tracer > 3) { set_error("tracer must be 0..3"); return fail(VXRT_E_INVALID); }
     c->trace_variant = cfg->tracer == 0 ? (cfg->max_bounces < 6 ? 0 : 3) : (cfg->tracer == 1 ? 0 : int(cfg->tracer));
-    if (const char* v = getenv("VXRT_TRACE_VARIANT")) c->trace_variant = atoi(v);
+    if (const char* v = getenv("VXRT_TRACE_VARIANT")) c->trace_variant = atoi(v);  // A/B override for benchmarks and tests
+    if (c->trace_variant != 2 && c->trace_variant != 3) c->trace_variant = 0;
     if (const char* v = getenv("VXRT_SHADE_BLOCKS")) c->shade_blocks = atoi(v);
     if (const char* v = getenv("VXRT_RAYS_PER_WAVE")) c->rays_per_wave = unsigned(atoi(v));
     c->shade_blocks = (c->shade_blocks < 8 ? 8 : (c->shade_blocks > 2048 ? 2048 : c->shade_blocks) + 7) / 8 * 8;

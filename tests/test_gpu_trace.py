@@ -141,6 +141,8 @@ def test_full_size_bench_config_crops(O, H, scenes, noise):
     {"VXRT_TRACE_VARIANT": "3"},                                                        # ray queues: shade / trace launches, per-lane refill
     {"VXRT_TRACE_VARIANT": "3", "VXRT_TRACE_BLOCKS": "3", "VXRT_SHADE_BLOCKS": "5"},    # ... few waves: many refills per lane, several trips
     {"VXRT_TRACE_VARIANT": "3", "VXRT_INFLIGHT": "3"},                                  # ... with frames in flight
+    {"VXRT_TRACE_VARIANT": "2", "VXRT_TRACE_SPLIT": "0x3", "VXRT_INFLIGHT": "4"},       # wavefront with frames in flight
+    {"VXRT_TRACE_VARIANT": "3", "VXRT_RAYS_PER_WAVE": "1000", "VXRT_INFLIGHT": "2"},    # fat trace waves: ~16 refills per lane
 ])
 def test_every_trace_variant_is_bit_exact(O, H, scenes, noise, monkeypatch, env):
     """The scheduling variants of the tracer (read from the environment when a context is created) change
