@@ -67,6 +67,10 @@ struct TemporalArgs {
     float inv[12];  // affine inverse of the old camera matrix (temporal.comp:75-82), rows + translation
     float sample_blending, maximum_blending, blending_distance_cutoff;
     int has_history;
+    // fused denoise for radius 0 (the reference's default): out = mix(c, albedo * c, albedo_factor) of the blended colour
+    const float4* albedo;   // null: no fusion
+    float4* denoised;
+    float albedo_factor;
 };
 
 struct DenoiseArgs {

@@ -102,6 +102,11 @@ __global__ __launch_bounds__(256) void temporal_kernel(const TemporalArgs a) {
     f3 blended = depth >= 0.0f ? mix3(xyz(old_color), color, blending) : color;
     float next_blending = vx_clamp((1.0f - a.sample_blending) * blending, 1.0f - a.maximum_blending, 1.0f);
     a.new_color[pix] = make_float4(blended.x, blended.y, blended.z, next_blending);
+    if (a.albedo != nullptr) {  // denoise.comp:88-92 with radius 0, on the value just written
+        const f3 alb = xyz(a.albedo[pix]);
+        const f3 out = mix3(blended, alb * blended, a.albedo_factor);
+        a.denoised[pix] = make_float4(out.x, out.y, out.z, 1.0f);
+    }
 }
 
 // A staged pixel of the denoise apron is two float4 in two LDS arrays (each read is a conflict-free

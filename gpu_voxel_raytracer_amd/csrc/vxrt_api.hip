@@ -684,6 +684,7 @@ int vxrt_render(vxrt_ctx* c, uint32_t flags) {
     const bool post = (flags & (VXRT_TEMPORAL | VXRT_DENOISE)) != 0;
     if (post && c->traced > 0) HIP_TRY(hipStreamWaitEvent(c->stream, cur.trace_done, 0));
 
+    bool fused_denoise = false;
     if (flags & VXRT_TEMPORAL) {
         vxrt_ctx::Slot& hist = c->ring[size_t(c->hist_slot >= 0 ? c->hist_slot : c->slot)];
         TemporalArgs a;
@@ -699,6 +700,11 @@ int vxrt_render(vxrt_ctx* c, uint32_t flags) {
         a.sample_blending = c->temporal.sample_blending;
         a.maximum_blending = c->temporal.maximum_blending;
         a.blending_distance_cutoff = c->temporal.blending_distance_cutoff;
+        // radius 0: the denoise stage is a per-pixel function of this stage's output — do it in the same pass
+        fused_denoise = (flags & VXRT_DENOISE) != 0 && c->denoise.radius == 0;
+        a.albedo = fused_denoise ? cur.albedo : nullptr;
+        a.denoised = c->denoised;
+        a.albedo_factor = c->denoise.albedo_factor;
         if (c->band.local_rows > 0) {
             EventPair p;
             if (timed) { p = take_pair(c, 1); HIP_TRY(hipEventRecord(p.a, c->stream)); }
@@ -717,7 +723,7 @@ int vxrt_render(vxrt_ctx* c, uint32_t flags) {
     }
     if (flags & VXRT_TRACE) c->old_cam_valid = true;  // the next frame's "old" camera is this frame's
 
-    if (flags & VXRT_DENOISE) {
+    if ((flags & VXRT_DENOISE) && !fused_denoise) {
         DenoiseArgs a;
         a.colors = c->accum_is_sampled ? cur.sampled_color : c->accum[c->last];
         a.nd = cur.nd;
