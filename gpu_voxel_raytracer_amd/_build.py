@@ -5,9 +5,11 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvxrt.so")
-SOURCES = ["vxrt_api.hip", "trace.hip", "trace_wavefront.hip", "post.hip", "scene_host.cpp", "scene_procedural.cpp"]
+SOURCES = ["vxrt_api.hip", "trace.hip", "trace_wavefront.hip", "post.hip", "noise.hip", "scene_host.cpp", "scene_procedural.cpp",
+           "noise_zip.cpp", "vox_scene.cpp"]
 HEADERS = ["kernels.h", "trace_common.h", "scene_host.h", "vx_vec.h", os.path.join("..", "..", "include", "vxrt.h"),
-           os.path.join("..", "..", "include", "vxrt_detmath.h")]
+           os.path.join("..", "..", "include", "vxrt_detmath.h"),
+           os.path.join("..", "..", "include", "vxrt_bluenoise.h")]
 
 # -ffp-contract=off / no fast-math / IEEE divide+sqrt / denormals kept: include/vxrt_detmath.h
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
@@ -28,7 +30,7 @@ def build(force=False, verbose=False, extra_flags=()):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra_flags = list(extra_flags) + os.environ.get("VXRT_HIPCC_FLAGS", "").split()
-    cmd = [hipcc] + FLAGS + extra_flags + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    cmd = [hipcc] + FLAGS + extra_flags + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB, "-lz"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -116,6 +116,8 @@ hipError_t launch_trace_wavefront(const TraceArgs& a, const PathQueue queues[2],
 hipError_t launch_temporal(const TemporalArgs& a, hipStream_t s);
 hipError_t launch_denoise(const DenoiseArgs& a, hipStream_t s);
 hipError_t launch_noise_fill(float* dst, uint32_t seed, size_t n, hipStream_t s);
+// void-and-cluster blue noise (include/vxrt_bluenoise.h): `layers` layers of size x size floats, one block per layer
+hipError_t launch_blue_noise(float* dst, uint32_t seed, uint32_t first_layer, uint32_t layers, int size, hipStream_t s);
 // detmath probe for the device-vs-host bit-equality test (tests/test_detmath_gpu.py)
 hipError_t launch_detmath_probe(int fn, const float* x, const float* y, float* out, size_t n, hipStream_t s);
 

@@ -229,18 +229,6 @@ __global__ __launch_bounds__(256) void denoise_kernel(const DenoiseArgs a) {
     a.output[pix] = make_float4(out.x, out.y, out.z, 1.0f);
 }
 
-__global__ void noise_fill_kernel(float* dst, uint32_t seed, size_t n) {
-    size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    size_t stride = size_t(gridDim.x) * blockDim.x;
-    for (; i < n; i += stride) {
-        uint32_t z = uint32_t(i) * 0x9E3779B9u + seed;
-        z ^= z >> 16; z *= 0x85EBCA6Bu;
-        z ^= z >> 13; z *= 0xC2B2AE35u;
-        z ^= z >> 16;
-        dst[i] = float(z >> 8) * (1.0f / 16777216.0f);
-    }
-}
-
 __global__ void detmath_probe_kernel(int fn, const float* x, const float* y, float* out, size_t n) {
     size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -282,11 +270,6 @@ hipError_t launch_denoise(const DenoiseArgs& a, hipStream_t s) {
     int tw = 16 + 2 * int(a.radius), taps = 2 * int(a.radius) + 1;
     size_t lds = size_t(tw) * tw * 32 + size_t(taps * taps + 3) / 4 * 16;
     hipLaunchKernelGGL(denoise_kernel, grid, dim3(256), lds, s, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_noise_fill(float* dst, uint32_t seed, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(noise_fill_kernel, dim3(2048), dim3(256), 0, s, dst, seed, n);
     return hipGetLastError();
 }
 

@@ -27,6 +27,16 @@ struct VoxScene {
 // (src/vox.rs:11-101, src/context.rs:913-933).
 int decode_vox(const uint8_t* bytes, size_t len, VoxScene* out);
 
+// Whole MagicaVoxel scenes (vox_scene.cpp): flags = VXRT_VOX_* of vxrt.h; 0 = decode_vox.  bounds: inclusive voxel
+// bounding box in the renderer's axes.
+int decode_vox_scene(const uint8_t* bytes, size_t len, uint32_t flags, VoxScene* out, int32_t bounds_lo[3], int32_t bounds_hi[3]);
+// Context::create_voxels (src/context.rs:838-910) with a seeded generator.
+void default_scene(uint32_t seed, std::vector<Voxel>* out);
+
+// The reference's blue-noise archive format (noise_zip.cpp; src/context.rs:1042-1116).
+int noise_zip_read(const char* path, std::vector<float>* pixels, uint32_t* size, uint32_t* layers);
+int noise_zip_write(const char* path, const float* table, uint32_t size, uint32_t layers);
+
 // Sparse octree in the layout shaders/voxels.comp:58-63 reads: 5-word header
 // [cx, cy, cz, root_size, child_size] (f32 bits) followed by 8 int32 slots per node
 // (0 empty, >0 child node, <0 leaf word).  Built with the insertion order and overwrite rule of

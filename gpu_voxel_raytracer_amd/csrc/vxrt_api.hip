@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/vxrt.h"
+#include "../../include/vxrt_bluenoise.h"
 #include "kernels.h"
 #include "scene_host.h"
 #include "vx_vec.h"
@@ -395,6 +396,7 @@ const char* vxrt_status_string(int status) {
         case VXRT_E_IO: return "failed to read file";
         case VXRT_E_SCENE: return "voxel list cannot be represented";
         case VXRT_E_NOSCENE: return "no scene set";
+        case VXRT_E_NOISE: return "failed to load blue noise";
         default: return "unknown status";
     }
 }
@@ -1019,6 +1021,84 @@ int vxrt_set_menger(vxrt_ctx* c, uint32_t level, uint32_t clip, const uint8_t mr
     uint32_t depth = 0;
     if (int rc = build_menger_svo(level, clip, mrgb, emissive_period, &recs, &leaves, &depth)) return rc;
     return upload_svo(c, recs, leaves, depth);
+}
+
+// ---- blue noise (include/vxrt_bluenoise.h, csrc/noise.hip, csrc/noise_zip.cpp) ----------------------------------
+int vxrt_blue_noise(int32_t device, uint32_t seed, uint32_t size, uint32_t first_layer, uint32_t layers, float* out) {
+    if (!out || layers == 0) { set_error("null argument"); return VXRT_E_INVALID; }
+    if (size < 16 || size > VXBN_MAX_SIZE || (size & (size - 1)) != 0) { set_error("blue-noise size must be a power of two in 16..128"); return VXRT_E_INVALID; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return hip_fail(e == hipSuccess ? hipErrorNoDevice : e, "hipGetDeviceCount");
+    if (device < 0 || device >= ndev) { set_error("device ordinal out of range"); return VXRT_E_INVALID; }
+    HIP_TRY(hipSetDevice(device));
+    const size_t bytes = size_t(layers) * size * size * sizeof(float);
+    float* d = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), bytes));
+    hipError_t le = launch_blue_noise(d, seed, first_layer, layers, int(size), nullptr);
+    if (le == hipSuccess) le = hipDeviceSynchronize();
+    if (le == hipSuccess) le = hipMemcpy(out, d, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (le != hipSuccess) return hip_fail(le, "blue noise");
+    return VXRT_OK;
+}
+
+int vxrt_noise_zip_read(const char* path, float* out, size_t cap_floats, uint32_t* size, uint32_t* layers) {
+    if (!path || !size || !layers) { set_error("null argument"); return VXRT_E_INVALID; }
+    std::vector<float> px;
+    if (int rc = noise_zip_read(path, &px, size, layers)) return rc;
+    if (out) {
+        if (cap_floats < px.size()) { set_error("buffer too small for the archive's images"); return VXRT_E_INVALID; }
+        memcpy(out, px.data(), px.size() * sizeof(float));
+    }
+    return VXRT_OK;
+}
+
+int vxrt_noise_zip_write(const char* path, const float* table, uint32_t size, uint32_t layers) {
+    if (!path || !table) { set_error("null argument"); return VXRT_E_INVALID; }
+    return noise_zip_write(path, table, size, layers);
+}
+
+int vxrt_set_noise(vxrt_ctx* c, const float* table) {
+    if (!c || !table) { set_error("null argument"); return VXRT_E_INVALID; }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = vxrt_sync(c)) return rc;
+    HIP_TRY(hipMemcpy(c->d_noise, table, kNoiseCount * sizeof(float), hipMemcpyHostToDevice));
+    return VXRT_OK;
+}
+
+// ---- wider scene input (csrc/vox_scene.cpp) ------------------------------------------------------------------------
+int vxrt_vox_scene_to_voxels(const uint8_t* bytes, size_t len, uint32_t flags, int16_t (*pos)[3], uint8_t (*mrgb)[4], size_t cap,
+                             size_t* n, int32_t bounds_min[3], int32_t bounds_max[3]) {
+    if (!bytes || !n) { set_error("null argument"); return VXRT_E_INVALID; }
+    if (flags & ~uint32_t(VXRT_VOX_ALL_MODELS | VXRT_VOX_LENIENT_MATERIALS | VXRT_VOX_REBASE)) { set_error("unknown flag"); return VXRT_E_INVALID; }
+    VoxScene scene;
+    int32_t lo[3], hi[3];
+    if (int rc = decode_vox_scene(bytes, len, flags, &scene, lo, hi)) return rc;
+    *n = scene.voxels.size();
+    for (int a = 0; a < 3; a++) {
+        if (bounds_min) bounds_min[a] = lo[a];
+        if (bounds_max) bounds_max[a] = hi[a];
+    }
+    for (size_t i = 0; i < scene.voxels.size() && i < cap; i++) {
+        const Voxel& v = scene.voxels[i];
+        if (pos) { pos[i][0] = v.x; pos[i][1] = v.y; pos[i][2] = v.z; }
+        if (mrgb) { mrgb[i][0] = v.m; mrgb[i][1] = v.r; mrgb[i][2] = v.g; mrgb[i][3] = v.b; }
+    }
+    return VXRT_OK;
+}
+
+int vxrt_default_scene_voxels(uint32_t seed, int16_t (*pos)[3], uint8_t (*mrgb)[4], size_t cap, size_t* n) {
+    if (!n) { set_error("null argument"); return VXRT_E_INVALID; }
+    std::vector<Voxel> voxels;
+    default_scene(seed, &voxels);
+    *n = voxels.size();
+    for (size_t i = 0; i < voxels.size() && i < cap; i++) {
+        const Voxel& v = voxels[i];
+        if (pos) { pos[i][0] = v.x; pos[i][1] = v.y; pos[i][2] = v.z; }
+        if (mrgb) { mrgb[i][0] = v.m; mrgb[i][1] = v.r; mrgb[i][2] = v.g; mrgb[i][3] = v.b; }
+    }
+    return VXRT_OK;
 }
 
 // device-vs-host bit equality probe of include/vxrt_detmath.h (test hook; host arrays in and out)

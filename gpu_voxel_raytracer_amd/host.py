@@ -26,13 +26,14 @@ _LIB = None
 class VxrtError(RuntimeError):
     def __init__(self, status, where, detail=""):
         self.status = status
+        self.detail = detail
         super().__init__(f"{where}: status {status} ({detail})")
 
 
 # vxrt_status (include/vxrt.h)
 OK, E_INVALID, E_DEVICE = 0, -1, -2
 E_VOX_MAGIC, E_VOX_VERSION, E_VOX_NOMAIN, E_VOX_EOF, E_VOX_CHUNK = -10, -11, -12, -13, -14
-E_VOX_MATERIAL, E_VOX_NOMATL, E_VOX_NOMODEL, E_IO, E_SCENE, E_NOSCENE = -15, -16, -17, -18, -20, -21
+E_VOX_MATERIAL, E_VOX_NOMATL, E_VOX_NOMODEL, E_IO, E_SCENE, E_NOSCENE, E_NOISE = -15, -16, -17, -18, -20, -21, -30
 
 # vxrt_image
 SAMPLED_COLOR, NORMAL_DEPTH, ALBEDO_NODE, ACCUM_COLOR, DENOISED = range(5)
@@ -175,6 +176,60 @@ def noise_table(seed=DEFAULT_NOISE_SEED, n=NOISE_LEN):
     return out
 
 
+def blue_noise(seed=DEFAULT_NOISE_SEED, size=128, first_layer=0, layers=512, device=0):
+    """Void-and-cluster blue noise made on the GPU (include/vxrt_bluenoise.h) -> float32[layers, size, size]: the kind
+    of table the reference loads from its missing resources/blue-noise-128.zip (src/context.rs:1016-1040)."""
+    out = np.zeros((layers, size, size), np.float32)
+    _check(lib().vxrt_blue_noise(C.c_int32(device), C.c_uint32(seed), C.c_uint32(size), C.c_uint32(first_layer),
+                                 C.c_uint32(layers), _p(out)), "vxrt_blue_noise")
+    return out
+
+
+def load_blue_noise(path):
+    """Context::load_blue_noise (src/context.rs:1042-1085): -> (image size, float32 pixels of all images appended)."""
+    size, layers = C.c_uint32(0), C.c_uint32(0)
+    enc = os.fsencode(path)
+    _check(lib().vxrt_noise_zip_read(enc, None, C.c_size_t(0), C.byref(size), C.byref(layers)), "vxrt_noise_zip_read")
+    out = np.zeros(layers.value * size.value * size.value, np.float32)
+    _check(lib().vxrt_noise_zip_read(enc, _p(out), C.c_size_t(out.size), C.byref(size), C.byref(layers)), "vxrt_noise_zip_read")
+    return int(size.value), out
+
+
+def save_blue_noise(path, table, size=128):
+    """Writes a table in the reference's archive format (one stored entry per layer)."""
+    t = np.ascontiguousarray(table, np.float32).reshape(-1, size, size)
+    _check(lib().vxrt_noise_zip_write(os.fsencode(path), _p(t), C.c_uint32(size), C.c_uint32(len(t))), "vxrt_noise_zip_write")
+
+
+VOX_ALL_MODELS, VOX_LENIENT_MATERIALS, VOX_REBASE = 1, 2, 4
+
+
+def vox_scene_to_voxels(data: bytes, flags=VOX_ALL_MODELS):
+    """Whole MagicaVoxel scenes (every shape instance of the scene graph, see vxrt.h) ->
+    (pos int16[n,3], mrgb uint8[n,4], (bounds_min, bounds_max)) in the renderer's axes."""
+    buf = np.frombuffer(data, np.uint8)
+    n = C.c_size_t(0)
+    lo, hi = np.zeros(3, np.int32), np.zeros(3, np.int32)
+    _check(lib().vxrt_vox_scene_to_voxels(_p(buf), C.c_size_t(len(data)), C.c_uint32(flags), None, None, C.c_size_t(0),
+                                          C.byref(n), _p(lo), _p(hi)), "vxrt_vox_scene_to_voxels")
+    pos = np.zeros((n.value, 3), np.int16)
+    mrgb = np.zeros((n.value, 4), np.uint8)
+    _check(lib().vxrt_vox_scene_to_voxels(_p(buf), C.c_size_t(len(data)), C.c_uint32(flags), _p(pos), _p(mrgb),
+                                          C.c_size_t(n.value), C.byref(n), _p(lo), _p(hi)), "vxrt_vox_scene_to_voxels")
+    return pos, mrgb, (tuple(int(v) for v in lo), tuple(int(v) for v in hi))
+
+
+def default_scene_voxels(seed=1):
+    """Context::create_voxels (src/context.rs:838-910), the reference's start-up scene, seeded."""
+    n = C.c_size_t(0)
+    _check(lib().vxrt_default_scene_voxels(C.c_uint32(seed), None, None, C.c_size_t(0), C.byref(n)), "vxrt_default_scene_voxels")
+    pos = np.zeros((n.value, 3), np.int16)
+    mrgb = np.zeros((n.value, 4), np.uint8)
+    _check(lib().vxrt_default_scene_voxels(C.c_uint32(seed), _p(pos), _p(mrgb), C.c_size_t(n.value), C.byref(n)),
+           "vxrt_default_scene_voxels")
+    return pos, mrgb
+
+
 def menger_voxels(level, mrgb=(0, 0xb0, 0xd0, 0x60), clip=0, emissive_period=0):
     """Voxel list of the (clipped) level-`level` Menger sponge; the list form of Context.set_menger's scene."""
     m = np.asarray(mrgb, np.uint8)
@@ -254,8 +309,21 @@ class Context:
         _check(lib().vxrt_set_menger(self._h, C.c_uint32(level), C.c_uint32(clip), _p(m), C.c_uint32(emissive_period)),
                "vxrt_set_menger")
 
-    def load_vox(self, path):
-        _check(lib().vxrt_load_vox(self._h, os.fsencode(path)), "vxrt_load_vox")
+    def load_vox(self, path, flags=0):
+        """vox::load + voxels_from_vox + recreate_octree (src/context.rs:1817-1821); flags: VOX_* for whole scenes."""
+        if flags == 0:
+            _check(lib().vxrt_load_vox(self._h, os.fsencode(path)), "vxrt_load_vox")
+        else:
+            with open(path, "rb") as f:
+                pos, mrgb, _ = vox_scene_to_voxels(f.read(), flags)
+            self.recreate_octree(pos, mrgb)
+
+    def set_noise(self, table):
+        """Replaces the noise table (512*128*128 floats), e.g. with blue_noise() or load_blue_noise()."""
+        t = np.ascontiguousarray(table, np.float32).reshape(-1)
+        if t.size != NOISE_LEN:
+            raise ValueError("noise table must hold 512*128*128 floats")
+        _check(lib().vxrt_set_noise(self._h, _p(t)), "vxrt_set_noise")
 
     def load_vox_bytes(self, data: bytes):
         buf = np.frombuffer(data, np.uint8)

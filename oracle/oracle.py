@@ -88,6 +88,8 @@ def lib():
         _lib.orc_voxels_from_vox.restype = C.c_long
         _lib.orc_create_octree.restype = C.c_long
         _lib.orc_trace.restype = C.c_longlong
+        _lib.orc_default_scene.restype = C.c_long
+        _lib.orc_parse_raw_f32img.restype = C.c_long
     return _lib
 
 
@@ -112,6 +114,35 @@ def voxels_from_vox(data: bytes):
     mrgb = np.zeros((n, 4), np.uint8)
     lib().orc_voxels_from_vox(_p(buf), C.c_size_t(len(data)), _p(pos), _p(mrgb), C.c_size_t(n), _p(size))
     return pos, mrgb, tuple(int(s) for s in size)
+
+
+def default_scene(seed):
+    """Context::create_voxels (src/context.rs:838-910) with the seeded draws documented in ovox.cpp."""
+    n = lib().orc_default_scene(C.c_uint32(seed), None, None, C.c_size_t(0))
+    pos = np.zeros((n, 3), np.int16)
+    mrgb = np.zeros((n, 4), np.uint8)
+    lib().orc_default_scene(C.c_uint32(seed), _p(pos), _p(mrgb), C.c_size_t(n))
+    return pos, mrgb
+
+
+def blue_noise_layer(seed, layer, size=128):
+    """One layer of the void-and-cluster table specified in include/vxrt_bluenoise.h -> float32[size, size]."""
+    out = np.zeros((size, size), np.float32)
+    rc = lib().orc_blue_noise_layer(C.c_uint32(seed), C.c_uint32(layer), C.c_int(size), _p(out))
+    if rc != 0:
+        raise OracleError(rc)
+    return out
+
+
+def parse_raw_f32img(data: bytes):
+    """parse_raw_f32img (src/context.rs:1087-1116): BE u32 w, BE u32 h, w*h BE f32 -> float32[h, w]."""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    out = np.zeros(max(len(data) // 4, 1), np.float32)
+    n = lib().orc_parse_raw_f32img(_p(buf), C.c_size_t(len(data)), _p(out), C.c_size_t(len(out)), C.byref(w), C.byref(h))
+    if n < 0:
+        raise OracleError(n)
+    return out[:n].reshape(h.value, w.value)
 
 
 def default_palette():

@@ -10,6 +10,7 @@
 #include "oracle.h"
 
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <string>
@@ -263,6 +264,55 @@ void orc_camera_axis_scaled(const float* position, const float* direction, float
     out9[0] = right.x; out9[1] = right.y; out9[2] = right.z;
     out9[3] = up.x; out9[4] = up.y; out9[5] = up.z;
     out9[6] = fr.x; out9[7] = fr.y; out9[8] = fr.z;
+}
+
+// Context::create_voxels (src/context.rs:838-910): the start-up scene.  The reference draws its colours from
+// rand::thread_rng(); draw k is defined here as the hash documented at vxrt_noise_table (include/vxrt.h) of
+// (seed, k): gen_range(50..=255) = 50 + h % 206, gen_bool(p) = (h >> 8) * 2^-24 < p.  Returns the voxel count;
+// writes at most cap entries.
+long orc_default_scene(uint32_t seed, int16_t* pos, uint8_t* mrgb, size_t cap) {
+    const int radius = 256;
+    uint32_t k = 0;
+    auto draw = [&]() {
+        uint32_t z = k * 0x9E3779B9u + seed;
+        k++;
+        z ^= z >> 16; z *= 0x85EBCA6Bu; z ^= z >> 13; z *= 0xC2B2AE35u; z ^= z >> 16;
+        return z;
+    };
+    size_t n = 0;
+    auto push = [&](int x, int y, int z, uint8_t m, uint8_t r, uint8_t g, uint8_t b) {
+        if (n < cap) {
+            pos[3 * n] = (int16_t)x; pos[3 * n + 1] = (int16_t)y; pos[3 * n + 2] = (int16_t)z;
+            mrgb[4 * n] = m; mrgb[4 * n + 1] = r; mrgb[4 * n + 2] = g; mrgb[4 * n + 3] = b;
+        }
+        n++;
+    };
+    // :861-876 — heights[x][z]: the lower half of a sphere inside the radius, 0 outside
+    auto height_at = [&](int x, int z, bool* some) {
+        *some = !(x < -radius || x > radius || z < -radius || z > radius);  // :879-881
+        if (!*some) return 0;
+        if (x * x + z * z <= radius * radius) return (int)(-sqrtf((float)(radius * radius) - (float)(x * x) - (float)(z * z)));
+        return 0;
+    };
+    for (int x = -radius; x <= radius; x++)
+        for (int z = -radius; z <= radius; z++) {
+            bool some;
+            int curr = height_at(x, z, &some);
+            int low = curr;
+            const int dx[4] = {-1, 1, 0, 0}, dz[4] = {0, 0, -1, 1};
+            for (int i = 0; i < 4; i++) {  // :895-899
+                int h = height_at(x + dx[i], z + dz[i], &some);
+                if (!some) h = curr;
+                if (h < low) low = h;
+            }
+            for (int y = low; y <= curr; y++) {  // :900-902, color(0.01, ..) :849-858
+                uint8_t r = (uint8_t)(50 + draw() % 206), g = (uint8_t)(50 + draw() % 206), b = (uint8_t)(50 + draw() % 206);
+                bool emissive = (float)(draw() >> 8) * (1.0f / 16777216.0f) < 0.01f;
+                push(x, y, z, emissive ? 0x40 : 0x00, r, g, b);
+            }
+        }
+    for (int x = -radius; x <= radius; x++) push(x, -10, 0, 0x40, 255, 255, 255);  // :907-910
+    return (long)n;
 }
 
 }  // extern "C"

@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""CPU-side what-if for the monolithic tracer's wave scheduling (no GPU): takes the oracle's per-ray octree step
+counts of the bench frame (orc_trace_steps) and prices three ways of running an 8x8 tile on one wave64:
+
+  sync   every lane casts its next ray, the wave leaves the walk loop when the LAST lane's ray ends, then all shade
+         (trace.hip today);
+  gated  lanes run free: a lane whose ray ended waits; the shading block runs when >= T lanes wait or nobody walks;
+  dense  lower bound: all steps and all shading events packed 64 per instruction.
+
+Costs are in wave-instructions: C_STEP per walk trip, C_SHADE per shading block execution (includes walk_begin).
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gpu_voxel_raytracer_amd import scenes  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+C_STEP = float(os.environ.get("C_STEP", 100))
+C_SHADE = float(os.environ.get("C_SHADE", 450))
+
+
+def steps_for(scene="menger", view="bench", w=1920, h=1080, bounces=4):
+    pos, mrgb, size = scenes.load_scene(scene)
+    cam = scenes.bench_camera(size) if view == "bench" else scenes.close_camera(size)
+    octree = O.create_octree(pos, mrgb)
+    noise = O.noise_table()
+    u = O.Uniforms.default()
+    u.set_camera(cam[0], O.camera_axis_scaled(cam[0], cam[1], cam[2], w, h))
+    u.frame_number = 1
+    out = np.zeros((h, w, 17), np.int32)
+    O.lib().orc_trace_steps(O._p(octree), O._p(noise), C.byref(u), C.c_int(bounces), C.c_int(0), C.c_int(0), C.c_int(w),
+                            C.c_int(h), O._p(out), C.c_int(os.cpu_count()))
+    return out
+
+
+def tiles_of(st):
+    h, w, _ = st.shape
+    hh, ww = h // 8 * 8, w // 8 * 8
+    t = st[:hh, :ww].reshape(hh // 8, 8, ww // 8, 8, 17).transpose(0, 2, 1, 3, 4).reshape(-1, 64, 17)
+    return t
+
+
+def price_sync(t):
+    rays = t[:, :, 1:]                       # [tile, lane, round]
+    trips = rays.max(axis=1)                 # per round: the longest lane
+    rounds = (rays > 0).any(axis=1).sum(axis=1)
+    return trips.sum(axis=1) * C_STEP + rounds * C_SHADE
+
+
+def price_gated(t, threshold):
+    """Event simulation per tile (python loop over trips; only tiles with work)."""
+    cost = np.zeros(len(t))
+    for i, tile in enumerate(t):
+        rays = tile[:, 1:]
+        nr = (rays > 0).sum(axis=1)
+        if nr.max() == 0:
+            continue
+        cur = np.zeros(64, np.int64)            # index of the ray a lane is on
+        left = rays[:, 0].astype(np.int64)      # steps left in the current ray (0 = waiting for shading / done)
+        walking = left > 0
+        waiting = np.zeros(64, bool)
+        c = C_SHADE  # ray generation
+        while True:
+            if walking.any():
+                left[walking] -= 1
+                c += C_STEP
+                fin = walking & (left == 0)
+                walking &= ~fin
+                waiting |= fin
+            if waiting.any() and (waiting.sum() >= threshold or not walking.any()):
+                c += C_SHADE
+                idx = np.nonzero(waiting)[0]
+                cur[idx] += 1
+                more = cur[idx] < nr[idx]
+                nxt = idx[more]
+                left[nxt] = rays[nxt, cur[nxt]]
+                walking[nxt] = True
+                waiting[idx] = False
+            if not walking.any() and not waiting.any():
+                break
+        cost[i] = c
+    return cost
+
+
+def main():
+    view = sys.argv[1] if len(sys.argv) > 1 else "bench"
+    st = steps_for(view=view)
+    t = tiles_of(st)
+    rays = (t[:, :, 1:] > 0).sum()
+    steps = t[:, :, 0].sum()
+    print(f"view {view}: {len(t)} tiles, {rays} rays, {steps} steps ({steps / rays:.1f}/ray)")
+    sync = price_sync(t)
+    dense = steps / 64 * C_STEP + rays / 64 * C_SHADE
+    print(f"sync : total {sync.sum() / 1e6:8.1f} M wave-instr, longest tile {sync.max() / 1e3:7.1f} k")
+    print(f"dense: total {dense / 1e6:8.1f} M")
+    # the gated simulation is slow in python: sample the tiles with work
+    work = np.nonzero(t[:, :, 0].sum(axis=1) > 0)[0]
+    rng = np.random.default_rng(1)
+    pick = rng.choice(work, size=min(600, len(work)), replace=False)
+    base = sync[pick].sum()
+    for thr in (1, 8, 16, 24, 32, 48):
+        g = price_gated(t[pick], thr)
+        print(f"gated T={thr:2d}: {g.sum() / base:6.3f} x sync on {len(pick)} sampled tiles, longest {g.max() / 1e3:7.1f} k "
+              f"(sync longest of the sample {sync[pick].max() / 1e3:7.1f} k)")
+
+
+if __name__ == "__main__":
+    main()
+
+
+def decompose(view="bench"):
+    st = steps_for(view=view)
+    t = tiles_of(st)
+    rays = t[:, :, 1:]
+    trips = rays.max(axis=1)
+    live = (rays > 0).sum(axis=1)
+    rounds = (rays > 0).any(axis=1)
+    print("round: tiles-in-round, wave trips (M), lane-steps (M), utilisation, mean live lanes")
+    for r in range(rays.shape[2]):
+        if not rounds[:, r].any():
+            break
+        tr = trips[:, r].sum()
+        ls = rays[:, :, r].sum()
+        print(f"  {r}: {rounds[:, r].sum():6d} {tr / 1e6:7.3f} {ls / 1e6:8.3f} {ls / (64 * tr):6.3f} {live[rounds[:, r], r].mean():6.1f}")
+    print(f"walk {trips.sum() * C_STEP / 1e6:.1f} M, shade {rounds.sum() * C_SHADE / 1e6:.1f} M wave-instr")
