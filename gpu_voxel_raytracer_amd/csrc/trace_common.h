@@ -234,6 +234,128 @@ __device__ __forceinline__ int walk_step_uniform(Walk& w, const SceneView& sc, f
     return status;
 }
 
+// ---- the walk for regular rays ---------------------------------------------------------------------------------
+// A ray is "regular" when every component of 1/dir is finite and non-zero (all but ~1e-7 of the rays: a direction
+// component that is exactly 0 needs an exactly-0.5 noise sample).  For such rays no NaN can arise in the walk — every
+// time is fl(fl(plane - origin) * inv) with finite inv — so GLSL's min/max (vx_min / vx_max, compare + select) equal the
+// hardware's v_min3 / v_max3, the transition of voxels.comp:198-201 is never 0, and dir_mask agrees with sign(inv).
+//
+// On top of that, a descend needs no arithmetic for its slab test: all cube planes are dyadic, so the time at which the
+// ray crosses a plane, fl(fl(p - o) * inv), depends on the plane's coordinate p only — not on the node whose test
+// computed it.  A child's near / far plane along an axis is the parent's near plane and mid plane (child on the near
+// side) or its mid plane and far plane (child on the far side), and "far side" is the step's own `directional` bit.
+// So with the per-axis crossing times of the current node kept in registers (en: near planes, ex: far planes), the
+// child's are a select between them and the t_mid the step has just computed:
+//     ray_cube_intersection(child) (voxels.comp:73-90, :218)  ==  max3(en'), min3(ex')      — bit for bit.
+// A pop recomputes en / ex of the node it returns to by the shader's formula (the frames in LDS stay 8 bytes).
+struct WalkF {
+    f3 o, d, inv, center;
+    f3 en, ex;                // crossing times of the current node's near / far planes
+    float time, exit;
+    uint32_t ix, iy, iz, lvl;
+    uint32_t has_next_mask, octant, dir_mask;
+    SvoRecord rec;
+    int iterations;
+};
+
+__device__ __forceinline__ float vx_min3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+__device__ __forceinline__ float vx_max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+__device__ __forceinline__ float vx_copysign(float mag, float sgn) { return __builtin_copysignf(mag, sgn); }
+
+__device__ __forceinline__ bool ray_is_regular(f3 inv) {
+    const float big = __builtin_inff();
+    return vx_abs(inv.x) > 0.0f && vx_abs(inv.x) < big && vx_abs(inv.y) > 0.0f && vx_abs(inv.y) < big && vx_abs(inv.z) > 0.0f &&
+           vx_abs(inv.z) < big;
+}
+
+// crossing times of the near / far planes of the cube (c, half): the operands of ray_cube_intersection's max / min
+__device__ __forceinline__ void plane_times(f3 o, f3 inv, f3 c, float half, f3& en, f3& ex) {
+    const f3 hs = mk3(vx_copysign(half, inv.x), vx_copysign(half, inv.y), vx_copysign(half, inv.z));  // half * sign(inv)
+    en = ((c - hs) - o) * inv;
+    ex = ((c + hs) - o) * inv;
+}
+
+// voxels.comp:138-160 for a regular ray (inv already computed).  false: the ray misses the root cube.
+__device__ __forceinline__ bool walkf_begin(WalkF& w, const SceneView& sc, f3 o, f3 d, f3 inv) {
+    w.o = o;
+    w.d = d;
+    w.inv = inv;
+    w.dir_mask = (d.x < 0.0f ? 4u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u);
+    plane_times(o, inv, sc.root_center, 0.5f * sc.root_size, w.en, w.ex);
+    const float entry = vx_max3(w.en.x, w.en.y, w.en.z);
+    w.exit = vx_min3(w.ex.x, w.ex.y, w.ex.z);
+    if (!(w.exit >= 0.0f && entry < w.exit)) return false;
+    w.time = vx_max(0.0f, entry);
+    w.center = sc.root_center;
+    w.ix = w.iy = w.iz = w.lvl = w.has_next_mask = 0;
+    w.rec = sc.svo[0];
+    w.octant = octant_of(o + d * w.time, w.center);
+    w.iterations = 0;
+    return true;
+}
+
+// One trip of the while(true) loop (voxels.comp:163-246) for a regular ray, max_distance = 2^30.
+__device__ __forceinline__ int walkf_step(WalkF& w, const SceneView& sc, uint2* stack) {
+    if (++w.iterations >= 2048) return kWalkCap;             // voxels.comp:166-169
+    if (w.time > kAlmostInfinity) return kWalkMiss;          // voxels.comp:171-173
+    const uint32_t bit = 1u << w.octant;
+    if (w.rec.masks & (bit << 8)) return kWalkLeaf;          // value < 0
+
+    const f3 tm = (w.center - w.o) * w.inv;                  // voxels.comp:191
+    const uint32_t directional = w.octant ^ w.dir_mask;
+    const bool far_x = (directional & 4u) != 0u, far_y = (directional & 2u) != 0u, far_z = (directional & 1u) != 0u;
+    const float mx = far_x ? kAlmostInfinity : tm.x;
+    const float my = far_y ? kAlmostInfinity : tm.y;
+    const float mz = far_z ? kAlmostInfinity : tm.z;
+    const float next_time = vx_min3(mx, my, mz);
+    const uint32_t transition = (mx == next_time) ? 4u : ((my == next_time) ? 2u : 1u);
+    const bool has_next = next_time <= w.exit && (directional & transition) == 0u;
+    const bool is_child = (w.rec.masks & bit) != 0u;         // value > 0
+
+    if (is_child || !has_next) {
+        uint2 raw;
+        if (is_child) {  // voxels.comp:205-214
+            if (has_next) {
+                stack[w.lvl * kBlock] = make_uint2(w.rec.masks | (w.octant ^ transition) << 16, w.rec.base);
+                w.has_next_mask |= 1u << w.lvl;
+            }
+            raw = *reinterpret_cast<const uint2*>(sc.svo + (w.rec.base + __popc(w.rec.masks & (bit - 1u))));
+            w.ix = (w.ix << 1) | ((w.octant >> 2) & 1u);
+            w.iy = (w.iy << 1) | ((w.octant >> 1) & 1u);
+            w.iz = (w.iz << 1) | (w.octant & 1u);
+            w.lvl++;
+        } else {         // voxels.comp:225-234
+            if (w.has_next_mask == 0u) return kWalkMiss;
+            const uint32_t l = 31u - uint32_t(__clz(int(w.has_next_mask)));
+            w.has_next_mask &= ~(1u << l);
+            const uint32_t up = w.lvl - l;
+            w.ix >>= up; w.iy >>= up; w.iz >>= up;
+            w.lvl = l;
+            raw = stack[l * kBlock];
+            asm volatile("" : "+v"(raw.x), "+v"(raw.y));  // keep it an LDS read (see walk_step)
+        }
+        const float size = __builtin_ldexpf(sc.root_size, -int(w.lvl));
+        w.center = sc.root_min + mk3(float(w.ix) + 0.5f, float(w.iy) + 0.5f, float(w.iz) + 0.5f) * size;
+        if (is_child) {  // voxels.comp:216-221, the slab test by selection
+            w.en = mk3(far_x ? tm.x : w.en.x, far_y ? tm.y : w.en.y, far_z ? tm.z : w.en.z);
+            w.ex = mk3(far_x ? w.ex.x : tm.x, far_y ? w.ex.y : tm.y, far_z ? w.ex.z : tm.z);
+            w.octant = octant_of(w.o + w.d * w.time, w.center);
+            w.time = vx_max(w.time, vx_max3(w.en.x, w.en.y, w.en.z));
+        } else {         // voxels.comp:236-242
+            plane_times(w.o, w.inv, w.center, 0.5f * size, w.en, w.ex);
+            w.time = w.exit;
+            w.octant = (raw.x >> 16) & 7u;
+        }
+        w.exit = vx_min3(w.ex.x, w.ex.y, w.ex.z);
+        w.rec.masks = raw.x & 0xffffu;
+        w.rec.base = raw.y;
+    } else {  // voxels.comp:222-224
+        w.octant ^= transition;
+        w.time = next_time;
+    }
+    return kWalkOn;
+}
+
 // index of the leaf word the walk stopped at (status kWalkLeaf)
 __device__ __forceinline__ uint32_t walk_leaf_index(const Walk& w) {
     const uint32_t bit = 1u << w.octant;
@@ -249,23 +371,51 @@ __device__ __forceinline__ f3 hit_normal(f3 o, f3 d, float time, f3 oc) {
     return mask * mk3(-vx_sign(d.x), -vx_sign(d.y), -vx_sign(d.z));
 }
 
-__device__ __forceinline__ bool cast_ray(const SceneView& sc, f3 o, f3 d, float max_distance, uint2* stack, RayHit& hit) {
-    Walk w;
-    if (!walk_begin(w, sc, o, d)) return false;
-    int status;
-    do { status = walk_step(w, sc, max_distance, stack); } while (status == kWalkOn);
-    hit.time = w.time;
+// hit resolution shared by both walks: leaf word and normal (voxels.comp:177-189)
+__device__ __forceinline__ bool finish_ray(const SceneView& sc, int status, f3 o, f3 d, float time, f3 center, uint32_t lvl,
+                                           uint32_t octant, uint32_t leaf_index, RayHit& hit) {
+    hit.time = time;
     hit.normal = splat3(0.0f);
     if (status == kWalkMiss) return false;
     if (status == kWalkCap) {
         hit.node = kLeafBit;
         return true;
     }
-    hit.node = sc.leaves[walk_leaf_index(w)];
-    f3 delta = mk3(float((w.octant >> 2) & 1u), float((w.octant >> 1) & 1u), float(w.octant & 1u));
-    f3 oc = w.center + (0.5f * w.size) * (delta - splat3(0.5f));
-    hit.normal = hit_normal(o, d, w.time, oc);
+    hit.node = sc.leaves[leaf_index];
+    const float size = __builtin_ldexpf(sc.root_size, -int(lvl));
+    f3 delta = mk3(float((octant >> 2) & 1u), float((octant >> 1) & 1u), float(octant & 1u));
+    f3 oc = center + (0.5f * size) * (delta - splat3(0.5f));
+    hit.normal = hit_normal(o, d, time, oc);
     return true;
+}
+
+__device__ __forceinline__ bool cast_ray(const SceneView& sc, f3 o, f3 d, float max_distance, uint2* stack, RayHit& hit) {
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    int status = kWalkMiss;
+    f3 center = splat3(0.0f);
+    float time = 0.0f;
+    uint32_t lvl = 0, octant = 0, leaf = 0;
+    bool entered;
+    if (ray_is_regular(inv) && max_distance == kAlmostInfinity) {
+        WalkF w;
+        entered = walkf_begin(w, sc, o, d, inv);
+        if (entered) {
+            do { status = walkf_step(w, sc, stack); } while (status == kWalkOn);
+            const uint32_t bit = 1u << w.octant;
+            center = w.center; time = w.time; lvl = w.lvl; octant = w.octant;
+            leaf = w.rec.base + __popc((w.rec.masks >> 8) & (bit - 1u));
+        }
+    } else {  // a direction component is 0 (or NaN): the shader's text, NaN and all
+        Walk w;
+        entered = walk_begin(w, sc, o, d);
+        if (entered) {
+            do { status = walk_step(w, sc, max_distance, stack); } while (status == kWalkOn);
+            center = w.center; time = w.time; lvl = w.lvl; octant = w.octant;
+            leaf = walk_leaf_index(w);
+        }
+    }
+    if (!entered) return false;
+    return finish_ray(sc, status, o, d, time, center, lvl, octant, leaf, hit);
 }
 
 __device__ __forceinline__ f3 node_rgb(int32_t node) {

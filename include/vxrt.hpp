@@ -80,6 +80,40 @@ inline VoxelList voxels_from_vox(const std::vector<uint8_t>& bytes) {
     return v;
 }
 
+// Whole MagicaVoxel scenes: every shape instance of the scene graph (flags: VXRT_VOX_*, see vxrt.h).
+inline VoxelList voxels_from_vox_scene(const std::vector<uint8_t>& bytes, uint32_t flags = VXRT_VOX_ALL_MODELS) {
+    VoxelList v;
+    size_t n = 0;
+    check(vxrt_vox_scene_to_voxels(bytes.data(), bytes.size(), flags, nullptr, nullptr, 0, &n, nullptr, nullptr), "vxrt_vox_scene_to_voxels");
+    v.pos.resize(n);
+    v.mrgb.resize(n);
+    check(vxrt_vox_scene_to_voxels(bytes.data(), bytes.size(), flags, reinterpret_cast<int16_t(*)[3]>(v.pos.data()),
+                                   reinterpret_cast<uint8_t(*)[4]>(v.mrgb.data()), n, &n, nullptr, nullptr),
+          "vxrt_vox_scene_to_voxels");
+    return v;
+}
+
+// Context::create_voxels (src/context.rs:838-910): the scene the reference starts with, seeded.
+inline VoxelList create_voxels(uint32_t seed = 1) {
+    VoxelList v;
+    size_t n = 0;
+    check(vxrt_default_scene_voxels(seed, nullptr, nullptr, 0, &n), "vxrt_default_scene_voxels");
+    v.pos.resize(n);
+    v.mrgb.resize(n);
+    check(vxrt_default_scene_voxels(seed, reinterpret_cast<int16_t(*)[3]>(v.pos.data()), reinterpret_cast<uint8_t(*)[4]>(v.mrgb.data()), n, &n),
+          "vxrt_default_scene_voxels");
+    return v;
+}
+
+// Context::load_blue_noise (src/context.rs:1042-1085): (image size, all images' pixels appended).
+inline std::pair<uint32_t, std::vector<float>> load_blue_noise(const std::string& path) {
+    uint32_t size = 0, layers = 0;
+    check(vxrt_noise_zip_read(path.c_str(), nullptr, 0, &size, &layers), "vxrt_noise_zip_read");
+    std::vector<float> px(size_t(layers) * size * size);
+    check(vxrt_noise_zip_read(path.c_str(), px.data(), px.size(), &size, &layers), "vxrt_noise_zip_read");
+    return {size, std::move(px)};
+}
+
 class Context {
   public:
     Camera camera;
@@ -107,6 +141,19 @@ class Context {
               "vxrt_set_voxels");
     }
     void load_vox(const std::string& path) { check(vxrt_load_vox(ctx_, path.c_str()), "vxrt_load_vox"); }
+    // Context::create_blue_noise_buffer (src/context.rs:1016-1040): the archive must hold 128x128 images, 512 of them
+    // (BLUE_NOISE_SIZE, and the table length shaders/voxels.comp:65-71 indexes).
+    void load_blue_noise(const std::string& path) {
+        auto [size, px] = vxrt::load_blue_noise(path);
+        if (size != 128 || px.size() != size_t(512) * 128 * 128) throw Error(VXRT_E_NOISE, "blue noise images must be 512 x 128 x 128");
+        check(vxrt_set_noise(ctx_, px.data()), "vxrt_set_noise");
+    }
+    // Makes the table the reference's repository does not ship, on the GPU (include/vxrt_bluenoise.h).
+    void generate_blue_noise(uint32_t seed = 0x5EED0001u, int device = 0) {
+        std::vector<float> table(size_t(512) * 128 * 128);
+        check(vxrt_blue_noise(device, seed, 128, 0, 512, table.data()), "vxrt_blue_noise");
+        check(vxrt_set_noise(ctx_, table.data()), "vxrt_set_noise");
+    }
     void set_menger(uint32_t level, uint32_t clip, std::array<uint8_t, 4> mrgb, uint32_t emissive_period) {
         check(vxrt_set_menger(ctx_, level, clip, mrgb.data(), emissive_period), "vxrt_set_menger");
     }

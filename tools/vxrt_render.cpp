@@ -2,7 +2,10 @@
 // window (load a model, place the camera, render frames) ending in a PPM of the last denoised frame and, optionally,
 // a raw float dump.
 //
-//   vxrt_render <scene.vox | menger:<level>[:clip[:emissive_period]]> <width> <height> <frames> <bounces> <radius> <out.ppm> [out.f32]
+//   vxrt_render <scene.vox | menger:<level>[:clip[:emissive_period]] | default[:seed]> <width> <height> <frames> <bounces> <radius> <out.ppm> [out.f32]
+//
+// `default` is the reference's start-up scene and camera (src/context.rs:838-910, 618-622).  VXRT_NOISE=blue generates the
+// blue-noise table on the GPU, VXRT_NOISE=<file.zip> loads one in the reference's resource format (src/context.rs:1016-1116).
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -31,8 +34,19 @@ int main(int argc, char** argv) {
         const int frames = std::atoi(argv[4]);
         vxrt::Context ctx(width, height, std::atoi(argv[5]));
         ctx.denoise_uniforms.radius = std::atoi(argv[6]);
+        if (const char* noise = std::getenv("VXRT_NOISE")) {
+            if (std::strcmp(noise, "blue") == 0) ctx.generate_blue_noise();
+            else ctx.load_blue_noise(noise);
+        }
         float extent[3];
-        if (scene.rfind("menger:", 0) == 0) {
+        bool start_camera = false;
+        if (scene.rfind("default", 0) == 0) {
+            unsigned seed = 1;
+            std::sscanf(scene.c_str() + 7, ":%u", &seed);
+            ctx.recreate_octree(vxrt::create_voxels(seed));
+            extent[0] = extent[1] = extent[2] = 0.0f;
+            start_camera = true;  // Camera{} is the reference's start camera
+        } else if (scene.rfind("menger:", 0) == 0) {
             unsigned level = 0, clip = 0, period = 0;
             std::sscanf(scene.c_str() + 7, "%u:%u:%u", &level, &clip, &period);
             ctx.set_menger(level, clip, {0, 0x7b, 0xa2, 0x3f}, period);
@@ -52,7 +66,7 @@ int main(int argc, char** argv) {
         // the fixed outside view of SURVEY.md §8d: position = c + e * (-0.9, 0.6, -1.2), looking at c
         const float e = std::max(extent[0], std::max(extent[1], extent[2]));
         const float k[3] = {-0.9f, 0.6f, -1.2f};
-        for (int i = 0; i < 3; i++) {
+        for (int i = 0; i < 3 && !start_camera; i++) {
             const float c = extent[i] * 0.5f;
             ctx.camera.position[i] = c + e * k[i];
             ctx.camera.direction[i] = c - ctx.camera.position[i];
