@@ -151,9 +151,11 @@ def main():
         rays = int(r.item())
 
     if rank == 0:
-        # Roofline of the dominant kernel (trace_kernel).  With F frames in flight F launches overlap on the GPU,
-        # so a launch's own duration (HIP events on its stream; rocprofv3 reports the same) is ~F x the time the
-        # chip spends per frame: achieved = F x algorithmic bytes per launch / average launch duration.
+        # Roofline of the trace stage = trace_kernel (every pixel up to its second hit) + bounce_kernel (the paths still
+        # alive there, compacted), back to back on one stream; launch_ms is the HIP-event time around the pair
+        # (rocprofv3's two average durations add up to it).  With F frames in flight F such pairs overlap on the GPU,
+        # so a pair's own duration is ~F x the time the chip spends per frame:
+        # achieved = F x algorithmic bytes per frame / average pair duration.
         launch_ms = kernel_ms / max(st.timed_frames, 1)
         alg = algorithmic_bytes(local_px, BOUNCES, st.scene_bytes)
         conc = max(1, min(args.inflight, args.steps))
@@ -168,7 +170,7 @@ def main():
                        "frames_in_flight": args.inflight,
                        "rays_per_frame": rays // args.steps, "rays_per_pixel": round(rays / args.steps / (WIDTH * HEIGHT), 4),
                        "mpixels_per_s": round(WIDTH * HEIGHT * args.steps / elapsed / 1e6, 1)},
-            "roofline": {"bound": "hbm", "kernel": "trace_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "trace_kernel + bounce_kernel (one trace stage)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": measured_traffic() if (world == 1 and args.view == "bench" and BOUNCES == 4) else None,
                          "launch_ms": round(launch_ms, 4), "concurrent_launches": conc,

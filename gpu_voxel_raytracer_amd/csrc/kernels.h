@@ -28,6 +28,13 @@ struct BandMap {  // which rows of the frame this context owns (vxrt_config.rank
     int width, height, local_rows, band_rows, rank, nranks;
 };
 
+// A queue of 64-byte path records in 64 shards (trace_common.h: PathRec, queue_append).
+struct PathQueue {
+    float4* recs;             // [64 shards][shard_capacity][4 float4]
+    unsigned* counts;         // 64 counters, 16 uints (one 64-byte line) apart
+    unsigned shard_capacity;  // records per shard
+};
+
 struct TraceArgs {
     const SvoRecord* svo;
     const int32_t* leaves;
@@ -54,6 +61,11 @@ struct TraceArgs {
     float sky_color[3];
     float sun_exponent;      // 1.0 / pow(sun_size, 2)  voxels.comp:380
     float sun_size, sun_strength, emit_strength, specularity;
+    // monolithic kernel with a compacted tail (tracer 4): a path that is still alive when it reaches hit number
+    // `tail_from` (>= 1; 0: off) is appended to `tail` instead of being followed; bounce_kernel finishes those paths
+    PathQueue tail;
+    unsigned* tail_zero;   // counter set to clear for a later launch (see launch_trace_wavefront)
+    int tail_from;
 };
 
 struct TemporalArgs {
@@ -88,12 +100,6 @@ struct DenoiseArgs {
 };
 
 // Queue of live paths between two launches of the wavefront tracer (trace.hip): 64-byte records in 64 shards.
-struct PathQueue {
-    float4* recs;             // [64 shards][shard_capacity][4 float4]
-    unsigned* counts;         // 64 counters, 16 uints (one 64-byte line) apart
-    unsigned shard_capacity;  // records per shard
-};
-
 // Ray-queue variant (trace_wavefront.hip): paths and rays of one frame between its shade / trace launches.
 constexpr unsigned kSegments = 8;  // dense queue segments; a block appends to segment blockIdx % 8 with one atomic
 struct RayQueue {
@@ -113,6 +119,9 @@ hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t* last_cos
 // wavefront: primary_kernel + max_bounces x bounce_kernel; queues[2] ping-pong, count_sets[3] rotate
 hipError_t launch_trace_wavefront(const TraceArgs& a, const PathQueue queues[2], unsigned* count_sets[3], unsigned* launch_counter,
                                   int blocks, unsigned split_mask, hipStream_t s);
+// bounce_kernel launches for path segments from.. of the paths queued in queues[0] (tracer 2 and the tail of tracer 4)
+hipError_t launch_bounces(const TraceArgs& a, const PathQueue queues[2], unsigned* count_sets[3], unsigned* launch_counter, int blocks,
+                          unsigned split_mask, int from, hipStream_t s);
 hipError_t launch_temporal(const TemporalArgs& a, hipStream_t s);
 hipError_t launch_denoise(const DenoiseArgs& a, hipStream_t s);
 hipError_t launch_noise_fill(float* dst, uint32_t seed, size_t n, hipStream_t s);

@@ -28,7 +28,10 @@ namespace vxrt {
 namespace {
 
 
-__global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs a) {
+#ifndef VXRT_TRACE_WAVES
+#define VXRT_TRACE_WAVES 5   // waves per SIMD the register allocation aims for (96 VGPRs)
+#endif
+__global__ __launch_bounds__(kBlock, VXRT_TRACE_WAVES) void trace_kernel(const TraceArgs a) {
     extern __shared__ uint2 lds_stack[];  // [stack_levels][kBlock]
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -45,6 +48,10 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs a) {
     const bool active = x < a.band.width && lrow < a.band.local_rows && y < a.band.height;
 
     uint32_t rays = 0;
+    bool to_tail = false;  // this lane's path continues in bounce_kernel (TraceArgs::tail)
+    PathRec rec;
+    rec.node = 0; rec.normal_ambient = 0; rec.rng_index = 0; rec.pix = 0;
+    rec.hit_pos = rec.dir = rec.sample = rec.blend = splat3(0.0f);
     if (active) {
         SceneView sc;
         sc.svo = a.svo;
@@ -99,6 +106,18 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs a) {
 
             const f3 n = hit.normal;
             const f3 hit_pos = o + d * hit.time;
+            if (bounce == a.tail_from && bounce > 0) {  // hand the path over, in the state bounce_kernel resumes from
+                rec.hit_pos = hit_pos;
+                rec.node = hit.node;
+                rec.dir = d;
+                rec.normal_ambient = pack_axis(n.x) | pack_axis(n.y) << 2 | pack_axis(n.z) << 4 | ambient_rays << 8;
+                rec.sample = sample;
+                rec.blend = blend;
+                rec.rng_index = rng.index;
+                rec.pix = uint32_t(pix);
+                to_tail = true;
+                break;
+            }
             const f3 color = bounce == 0 ? splat3(1.0f) : node_color(hit.node);
             const f3 emit = node_emittance(hit.node, a.emit_strength);
             if (bounce == 0) {  // first-hit G-buffer                           voxels.comp:320-324,392-396
@@ -141,8 +160,14 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs a) {
             if (++bounce >= a.max_bounces) break;
         }
 
-        f3 out = sample / float(ambient_rays);  // voxels.comp:391
-        a.out_color[pix] = make_float4(out.x, out.y, out.z, 1.0f);
+        if (!to_tail) {
+            f3 out = sample / float(ambient_rays);  // voxels.comp:391
+            a.out_color[pix] = make_float4(out.x, out.y, out.z, 1.0f);
+        }
+    }
+    if (a.tail_from > 0) {
+        zero_counts(a.tail_zero, tid);
+        queue_append(a.tail, (blockIdx.x * 4u + unsigned(wave)) % kShards, to_tail, rec, lane);
     }
 
     count_rays(a.ray_counter, rays, lane);

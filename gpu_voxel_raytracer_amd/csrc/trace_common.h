@@ -421,11 +421,28 @@ __device__ __forceinline__ bool cast_ray(const SceneView& sc, f3 o, f3 d, float 
 __device__ __forceinline__ f3 node_rgb(int32_t node) {
     return mk3(float((node >> 16) & 0xff), float((node >> 8) & 0xff), float(node & 0xff));
 }
+// c / 255.0f for c = 0..255 (IEEE division, folded by the compiler): node_color's three divisions are a table lookup.
+#define VX_D1(c) float(c) / 255.0f
+#define VX_D4(c) VX_D1(c), VX_D1(c + 1), VX_D1(c + 2), VX_D1(c + 3)
+#define VX_D16(c) VX_D4(c), VX_D4(c + 4), VX_D4(c + 8), VX_D4(c + 12)
+#define VX_D64(c) VX_D16(c), VX_D16(c + 16), VX_D16(c + 32), VX_D16(c + 48)
+__device__ const float kOver255[256] = {VX_D64(0), VX_D64(64), VX_D64(128), VX_D64(192)};
 // node_color, voxels.comp:253-258
-__device__ __forceinline__ f3 node_color(int32_t node) { return node_rgb(node) / 255.0f; }
-// node_emmitance, voxels.comp:260-266
+__device__ __forceinline__ f3 node_color(int32_t node) {
+#ifdef VXRT_AB_NO_LUT
+    return node_rgb(node) / 255.0f;
+#else
+    return mk3(kOver255[(node >> 16) & 0xff], kOver255[(node >> 8) & 0xff], kOver255[node & 0xff]);
+#endif
+}
+// node_emmitance, voxels.comp:260-266: ((e * emit_strength) * rgb) / 255 with e = 0 or 1.  For a voxel that does not emit
+// the numerator is 0 * emit_strength * rgb = 0 (for any finite emit_strength) and the three divisions are skipped.
 __device__ __forceinline__ f3 node_emittance(int32_t node, float emit_strength) {
-    float e = (node & kEmitBit) != 0 ? 1.0f : 0.0f;
+    const bool emits = (node & kEmitBit) != 0;
+#ifndef VXRT_AB_NO_LUT
+    if (!emits && 0.0f * emit_strength == 0.0f) return splat3(0.0f);
+#endif
+    float e = emits ? 1.0f : 0.0f;
     return ((e * emit_strength) * node_rgb(node)) / 255.0f;
 }
 

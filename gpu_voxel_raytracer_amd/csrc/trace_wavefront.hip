@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const TraceArgs a, cons
 }
 
 #ifndef VXRT_BOUNCE_WAVES
-#define VXRT_BOUNCE_WAVES 4
+#define VXRT_BOUNCE_WAVES 5
 #endif
 __global__ __launch_bounds__(kBlock, VXRT_BOUNCE_WAVES) void bounce_kernel(const TraceArgs a, const PathQueue in, const PathQueue out, unsigned* zero,
                                                         int first_bounce, int last_bounce) {
@@ -491,24 +491,20 @@ __global__ __launch_bounds__(kBlock) void trace_rays_kernel(const TraceArgs a, c
 
 }  // namespace
 
-hipError_t launch_trace_wavefront(const TraceArgs& a, const PathQueue queues[2], unsigned* count_sets[3], unsigned* launch_counter,
-                                  int blocks, unsigned split_mask, hipStream_t s) {
-    dim3 grid((a.band.width + 15) / 16, (a.band.local_rows + 15) / 16);
+// bounce_kernel launches for the path segments from..max_bounces-1 of the paths in queues[0] (written by launch J-1 with
+// count set J%3).  Bit k of split_mask set: a new launch (with compaction of the live paths) starts at path segment k.
+// Launch J reads count set J%3, writes (J+1)%3 and clears (J+2)%3 (the set launch J-1 consumed).
+hipError_t launch_bounces(const TraceArgs& a, const PathQueue queues[2], unsigned* count_sets[3], unsigned* launch_counter, int blocks,
+                          unsigned split_mask, int from, hipStream_t s) {
     size_t lds = size_t(a.stack_levels) * kBlock * sizeof(uint2);
-    // launch J reads count set J%3, writes (J+1)%3 and clears (J+2)%3 (the set launch J-1 consumed)
     unsigned J = *launch_counter;
-    PathQueue out = queues[0];
-    out.counts = count_sets[(J + 1) % 3];
-    hipLaunchKernelGGL(primary_kernel, grid, dim3(kBlock), lds, s, a, out, count_sets[(J + 2) % 3]);
-    J++;
-    // bit k of split_mask set: a new launch (with compaction of the live paths) starts at path segment k
     int stage = 0;
-    for (int first = 0; first < a.max_bounces;) {
+    for (int first = from; first < a.max_bounces;) {
         int last = first;
         while (last + 1 < a.max_bounces && !((split_mask >> (last + 1)) & 1u)) last++;
         PathQueue in = queues[stage & 1];
         in.counts = count_sets[J % 3];
-        out = queues[(stage & 1) ^ 1];
+        PathQueue out = queues[(stage & 1) ^ 1];
         out.counts = count_sets[(J + 1) % 3];
         hipLaunchKernelGGL(bounce_kernel, dim3(blocks), dim3(kBlock), lds, s, a, in, out, count_sets[(J + 2) % 3], first, last);
         J++;
@@ -517,6 +513,18 @@ hipError_t launch_trace_wavefront(const TraceArgs& a, const PathQueue queues[2],
     }
     *launch_counter = J;
     return hipGetLastError();
+}
+
+hipError_t launch_trace_wavefront(const TraceArgs& a, const PathQueue queues[2], unsigned* count_sets[3], unsigned* launch_counter,
+                                  int blocks, unsigned split_mask, hipStream_t s) {
+    dim3 grid((a.band.width + 15) / 16, (a.band.local_rows + 15) / 16);
+    size_t lds = size_t(a.stack_levels) * kBlock * sizeof(uint2);
+    unsigned J = *launch_counter;
+    PathQueue out = queues[0];
+    out.counts = count_sets[(J + 1) % 3];
+    hipLaunchKernelGGL(primary_kernel, grid, dim3(kBlock), lds, s, a, out, count_sets[(J + 2) % 3]);
+    *launch_counter = J + 1;
+    return launch_bounces(a, queues, count_sets, launch_counter, blocks, split_mask, 0, s);
 }
 
 

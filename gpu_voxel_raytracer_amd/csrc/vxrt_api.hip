@@ -126,6 +126,8 @@ struct vxrt_ctx {
     int last_schedule = 0;
     int use_tile_order = 1;
     int trace_blocks = 2048;
+    int tail_from = 1;  // tracer 4: the hit number at which live paths move to the compacted launches
+    unsigned tail_split = 0;  // ... bit k: the tail compacts again and starts a new launch at path segment k
     unsigned trace_split = 0x1;  // bit k: compact live paths and start a new launch at path segment k
     uint64_t frames = 0, pixels = 0, timed_frames = 0;
     double ms[3] = {0, 0, 0};
@@ -198,7 +200,7 @@ int alloc_images(vxrt_ctx* c) {
         c->queues.resize(size_t(c->inflight));
         for (vxrt_ctx::StreamQueues& sq : c->queues) {
             const size_t hit_bytes = (size_t(c->shard_capacity) * 64 + 1) * 64;
-            for (int i = 0; i < (c->trace_variant == 2 ? 2 : 1); i++) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sq.hitq[i]), hit_bytes));
+            for (int i = 0; i < (c->trace_variant == 3 ? 1 : 2); i++) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sq.hitq[i]), hit_bytes));
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sq.counts3), 3 * 64 * 64));
             HIP_TRY(hipMemsetAsync(sq.counts3, 0, 3 * 64 * 64, c->stream));
             sq.launches = 0;
@@ -442,12 +444,19 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipStreamCreate"));
     c->inflight = cfg->frames_in_flight == 0 ? 1 : int(cfg->frames_in_flight);
     if (const char* v = getenv("VXRT_INFLIGHT")) c->inflight = atoi(v);
-    // vxrt_config.tracer: 0 auto, 1 monolithic, 2 wavefront, 3 ray queues (internally 0, 2, 3).  Measured on MI355X with
-    // frames in flight: the monolithic kernel wins at 3-4 bounces, the queue variants when paths run 8 bounces deep.
-    if (cfg->tracer > 3) { set_error("tracer must be 0..3"); return fail(VXRT_E_INVALID); }
-    c->trace_variant = cfg->tracer == 0 ? (cfg->max_bounces < 6 ? 0 : 3) : (cfg->tracer == 1 ? 0 : int(cfg->tracer));
+    // vxrt_config.tracer: 0 auto, 1 monolithic, 2 wavefront, 3 ray queues, 4 monolithic head + compacted tail (internally
+    // 0, 2, 3, 4).  Measured on MI355X with frames in flight (menger 1080p 4 bounces / monu10 4K 8 bounces, ms per frame):
+    // tracer 1: 0.219 / 0.52-1.53, tracer 3: 0.275 / 0.82-1.10, tracer 4: 0.175 / 0.54-0.94 -> auto = 4 whenever a path
+    // can have a second hit, with one more compaction at path segment 3 from 6 bounces on.
+    if (cfg->tracer > 4) { set_error("tracer must be 0..4"); return fail(VXRT_E_INVALID); }
+    c->trace_variant = cfg->tracer == 0 ? 4 : (cfg->tracer == 1 ? 0 : int(cfg->tracer));
+    c->tail_split = cfg->max_bounces >= 6 ? 0x8u : 0u;
     if (const char* v = getenv("VXRT_TRACE_VARIANT")) c->trace_variant = atoi(v);  // A/B override for benchmarks and tests
-    if (c->trace_variant != 2 && c->trace_variant != 3) c->trace_variant = 0;
+    if (c->trace_variant != 2 && c->trace_variant != 3 && c->trace_variant != 4) c->trace_variant = 0;
+    if (c->trace_variant == 4 && cfg->max_bounces < 2) c->trace_variant = 0;  // no tail to compact
+    if (const char* v = getenv("VXRT_TAIL_FROM")) c->tail_from = atoi(v);
+    if (c->tail_from < 1 || c->tail_from >= int(cfg->max_bounces)) c->tail_from = 1;
+    if (const char* v = getenv("VXRT_TAIL_SPLIT")) c->tail_split = unsigned(strtoul(v, nullptr, 0));
     if (const char* v = getenv("VXRT_SHADE_BLOCKS")) c->shade_blocks = atoi(v);
     if (const char* v = getenv("VXRT_RAYS_PER_WAVE")) c->rays_per_wave = unsigned(atoi(v));
     c->shade_blocks = (c->shade_blocks < 8 ? 8 : (c->shade_blocks > 2048 ? 2048 : c->shade_blocks) + 7) / 8 * 8;
@@ -645,8 +654,25 @@ int vxrt_render(vxrt_ctx* c, uint32_t flags) {
         if (c->band.local_rows > 0) {
             EventPair p;
             if (timed) { p = take_pair(c, 0); HIP_TRY(hipEventRecord(p.a, ts)); }
-            if (c->trace_variant == 0) {
-                HIP_TRY(launch_trace(a, ts));
+            a.tail = PathQueue{nullptr, nullptr, 0};
+            a.tail_zero = nullptr;
+            a.tail_from = 0;
+            if (c->trace_variant == 0 || c->trace_variant == 4) {
+                if (c->trace_variant == 4) {
+                    // count sets rotate as in launch_trace_wavefront: launch J reads set J%3, writes (J+1)%3, clears (J+2)%3
+                    vxrt_ctx::StreamQueues& sq = c->queues[lane];
+                    unsigned* sets[3] = {sq.counts3, sq.counts3 + 64 * 16, sq.counts3 + 2 * 64 * 16};
+                    const unsigned J = sq.launches;
+                    a.tail = PathQueue{sq.hitq[0], sets[(J + 1) % 3], c->shard_capacity};
+                    a.tail_zero = sets[(J + 2) % 3];
+                    a.tail_from = c->tail_from;
+                    HIP_TRY(launch_trace(a, ts));
+                    sq.launches = J + 1;
+                    PathQueue queues[2] = {{sq.hitq[0], nullptr, c->shard_capacity}, {sq.hitq[1], nullptr, c->shard_capacity}};
+                    HIP_TRY(launch_bounces(a, queues, sets, &sq.launches, c->trace_blocks, c->tail_split, c->tail_from, ts));
+                } else {
+                    HIP_TRY(launch_trace(a, ts));
+                }
                 if (timed) HIP_TRY(hipEventRecord(p.b, ts));
                 // Re-sort the tiles for this stream's coming frames from the costs just measured: after its first
                 // frame, then every 8th (costs keep accumulating as a running maximum in between; ~7 us per sort).
@@ -835,7 +861,10 @@ int vxrt_get_stats(vxrt_ctx* c, vxrt_stats* out) {
 int vxrt_reset_stats(vxrt_ctx* c) {
     if (!valid_ctx(c)) return VXRT_E_INVALID;
     if (int rc = vxrt_sync(c)) return rc;
-    HIP_TRY(hipMemset(c->d_rays, 0, kRaySlots * 64));
+    // on the context's own stream and waited for: a null-stream hipMemset is neither ordered against the
+    // non-blocking trace streams nor guaranteed to have finished when it returns
+    HIP_TRY(hipMemsetAsync(c->d_rays, 0, kRaySlots * 64, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     c->frames = c->pixels = c->timed_frames = 0;
     c->ms[0] = c->ms[1] = c->ms[2] = 0.0;
     return VXRT_OK;

@@ -120,9 +120,11 @@ def lib():
     """Load libvxrt.so (building it with hipcc first if it is stale or missing)."""
     global _LIB
     if _LIB is None:
-        path = _build.LIB
-        if not os.path.exists(path):
-            path = _build.build()
+        path = os.environ.get("VXRT_LIB")  # A/B builds of the library (scripts/ab_build.sh); the product build otherwise
+        if not path:
+            path = _build.LIB
+            if not os.path.exists(path):
+                path = _build.build()
         L = C.CDLL(path)
         L.vxrt_last_error.restype = C.c_char_p
         L.vxrt_status_string.restype = C.c_char_p

@@ -100,10 +100,12 @@ typedef struct vxrt_config {
                                  frames may run concurrently (one HIP stream each, ring of F+2 G-buffer slots);
                                  temporal/denoise still run in frame order.  Results are identical.       */
     uint32_t tracer;          /* scheduling of the trace stage; every choice gives bit-identical images:
-                                 0 auto (1 for max_bounces < 6, else 3), 1 monolithic kernel (one pixel per lane,
+                                 0 auto (4 when max_bounces >= 2, else 1), 1 monolithic kernel (one pixel per lane,
                                  all bounces, longest-tile-first), 2 wavefront (one launch per path segment, live
                                  paths compacted in between), 3 ray queues (shade / trace launches, lanes refilled
-                                 ray by ray).                                                              */
+                                 ray by ray), 4 monolithic head + compacted tail (the monolithic kernel follows a
+                                 path up to its second hit; the paths still alive there — about a third of a
+                                 geometry tile's lanes — are queued and finished by a dense launch).          */
 } vxrt_config;
 
 typedef enum vxrt_image {

@@ -1,0 +1,17 @@
+#!/bin/bash
+# usage: scripts/ab_build.sh <tag> [extra hipcc flags...]  -> gpu_voxel_raytracer_amd/libvxrt_<tag>.so  (select with VXRT_LIB=...)
+# A/B builds of the library for same-box comparisons (boxes differ by a few per cent, so A and B must run in one gpurun call).
+set -e
+tag=$1; shift
+cd "$(dirname "$0")/.."
+python - "$tag" "$@" <<'PY'
+import sys, shutil
+from gpu_voxel_raytracer_amd import _build
+tag, flags = sys.argv[1], sys.argv[2:]
+keep = _build.LIB + ".keep"
+shutil.copy(_build.LIB, keep)
+_build.build(force=True, extra_flags=flags)
+shutil.move(_build.LIB, _build.LIB.replace("libvxrt.so", f"libvxrt_{tag}.so"))
+shutil.move(keep, _build.LIB)
+print("built", tag, flags)
+PY

@@ -11,4 +11,4 @@ for view in ("bench", "close"):
         ctx.render_frames(TRACE, 10); ctx.sync(); ctx.reset_stats()
         n = 60
         t0 = time.perf_counter(); ctx.render_frames(TRACE, n); ctx.sync(); dt = (time.perf_counter() - t0) / n
-        print(f"variant {os.environ.get('VXRT_TRACE_VARIANT', '0')} {view}: {dt * 1e3:.3f} ms/frame, {ctx.stats().rays / n / dt / 1e9:.2f} Gray/s")
+        print(f"variant {os.environ.get('VXRT_TRACE_VARIANT', '0')} tail {os.environ.get('VXRT_TAIL_FROM', '-')}/{os.environ.get('VXRT_TAIL_SPLIT', '-')} {view}: {dt * 1e3:.3f} ms/frame, {ctx.stats().rays / n / dt / 1e9:.2f} Gray/s")

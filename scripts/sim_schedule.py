@@ -128,3 +128,21 @@ def decompose(view="bench"):
         ls = rays[:, :, r].sum()
         print(f"  {r}: {rounds[:, r].sum():6d} {tr / 1e6:7.3f} {ls / 1e6:8.3f} {ls / (64 * tr):6.3f} {live[rounds[:, r], r].mean():6.1f}")
     print(f"walk {trips.sum() * C_STEP / 1e6:.1f} M, shade {rounds.sum() * C_SHADE / 1e6:.1f} M wave-instr")
+
+
+def hybrid(view="bench", split_round=3):
+    """rounds < split_round per 8x8 tile (monolithic), the paths still alive compacted (tile order) into dense waves of 64."""
+    st = steps_for(view=view)
+    t = tiles_of(st)
+    rays = t[:, :, 1:]
+    head = rays[:, :, :split_round]
+    head_cost = head.max(axis=1).sum() * C_STEP + (head > 0).any(axis=1).sum() * C_SHADE
+    alive = rays[:, :, split_round] > 0
+    paths = rays[alive][:, split_round:]                      # [n_paths, rounds], tile order preserved
+    n = len(paths)
+    pad = (-n) % 64
+    paths = np.concatenate([paths, np.zeros((pad, paths.shape[1]), paths.dtype)]).reshape(-1, 64, paths.shape[1])
+    tail_cost = paths.max(axis=1).sum() * C_STEP + (paths > 0).any(axis=1).sum() * C_SHADE
+    full = rays.max(axis=1).sum() * C_STEP + (rays > 0).any(axis=1).sum() * C_SHADE
+    print(f"view {view} split at round {split_round}: {n} paths survive; monolithic {full / 1e6:.1f} M, hybrid {head_cost / 1e6:.1f} + {tail_cost / 1e6:.1f} "
+          f"= {(head_cost + tail_cost) / 1e6:.1f} M wave-instr ({(head_cost + tail_cost) / full:.3f} x)")

@@ -51,6 +51,7 @@ def test_bands_and_halo_equal_single_context(H, scenes, noise, nranks, w, h, rad
                     p, n = C.c_void_p(), C.c_void_p()
                     assert rt.hipMalloc(C.byref(p), nbytes) == 0 and rt.hipMalloc(C.byref(n), nbytes) == 0
                     rt.hipMemset(p, 0xff, nbytes); rt.hipMemset(n, 0xff, nbytes)
+                    rt.hipDeviceSynchronize()   # hipMemset is not ordered against the context's non-blocking stream
                     c.halo_export(p.value, n.value)
                     bufs[r] = (p, n)
                 for r, c in enumerate(ctxs):

@@ -143,6 +143,10 @@ def test_full_size_bench_config_crops(O, H, scenes, noise):
     {"VXRT_TRACE_VARIANT": "3", "VXRT_INFLIGHT": "3"},                                  # ... with frames in flight
     {"VXRT_TRACE_VARIANT": "2", "VXRT_TRACE_SPLIT": "0x3", "VXRT_INFLIGHT": "4"},       # wavefront with frames in flight
     {"VXRT_TRACE_VARIANT": "3", "VXRT_RAYS_PER_WAVE": "1000", "VXRT_INFLIGHT": "2"},    # fat trace waves: ~16 refills per lane
+    {"VXRT_TRACE_VARIANT": "4"},                                                        # monolithic head + compacted tail (from hit 1)
+    {"VXRT_TRACE_VARIANT": "4", "VXRT_TAIL_FROM": "2", "VXRT_INFLIGHT": "4"},           # ... tail from hit 2, frames in flight
+    {"VXRT_TRACE_VARIANT": "4", "VXRT_TRACE_BLOCKS": "16", "VXRT_TILE_ORDER": "0"},     # ... few tail waves, raster tile order
+    {"VXRT_TRACE_VARIANT": "4", "VXRT_TAIL_SPLIT": "0xc", "VXRT_INFLIGHT": "3"},        # ... tail compacted again at segments 2 and 3
 ])
 def test_every_trace_variant_is_bit_exact(O, H, scenes, noise, monkeypatch, env):
     """The scheduling variants of the tracer (read from the environment when a context is created) change
@@ -280,12 +284,12 @@ def test_iteration_cap(O, H, noise):
 
 
 def test_tracer_field_of_the_config(O, H, scenes, noise):
-    """vxrt_config.tracer picks the scheduling variant (0 = auto: ray queues from 6 bounces on); same image either way."""
+    """vxrt_config.tracer picks the scheduling variant (0 = auto: monolithic head + compacted tail); same image either way."""
     from gpu_voxel_raytracer_amd import Context, Camera, TRACE, VxrtError
     pos, mrgb, size = scenes.load_scene("castle")
     cam = scenes.close_camera(size)
     imgs = []
-    for tracer, bounces in ((0, 8), (1, 8), (2, 8), (3, 8)):
+    for tracer, bounces in ((0, 8), (1, 8), (2, 8), (3, 8), (4, 8)):
         with Context(128, 80, max_bounces=bounces, noise=noise, tracer=tracer) as ctx:
             ctx.recreate_octree(pos, mrgb)
             ctx.camera = Camera(*cam)
