@@ -41,13 +41,15 @@ def algorithmic_bytes(pixels, bounces, scene_bytes):
     return 48 * pixels + scene_bytes + min(8 * bounces, 512) * 128 * 128 * 4
 
 
-def measured_traffic():
-    """HBM bytes per trace_kernel launch from the rocprofv3 PMC passes recorded in profiles/ (FETCH_SIZE and
-    WRITE_SIZE need separate passes and cannot be collected from inside this process); None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01", "trace_traffic_pmc.json")
+def measured_traffic(frames_per_launch):
+    """HBM bytes per trace-stage launch (trace_kernel + bounce_kernel over frames_per_launch frames) from the rocprofv3 PMC
+    passes recorded in profiles/ (FETCH_SIZE and WRITE_SIZE need separate passes and cannot be collected from inside this
+    process), scaled to this run's frames per launch; None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01", "trace_stage_summary.json")
     try:
-        return float(json.load(open(path))["hbm_bytes_per_launch_corrected"])
-    except (OSError, KeyError, ValueError):
+        t = json.load(open(path))["traffic"]
+        return float(t["hbm_bytes_per_launch_corrected"]) / float(t["frames_per_launch"]) * frames_per_launch
+    except (OSError, KeyError, ValueError, TypeError, ZeroDivisionError):
         return None
 
 
@@ -81,10 +83,12 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--view", default="bench", choices=["bench", "close"])
+    ap.add_argument("--view", default="bench", choices=["bench", "close", "away"])
     ap.add_argument("--bounces", type=int, default=BOUNCES, help="diagnostic only; the benchmark is 4")
     ap.add_argument("--inflight", type=int, default=0,
-                    help="frames whose trace stage may be on the GPU together (default: 4 on one GPU, 8 per rank otherwise)")
+                    help="trace launches that may be on the GPU together, one HIP stream each (default: 2 on one GPU, 3-4 per rank otherwise)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="consecutive frames per trace launch (vxrt_config.frames_per_launch; default: up to 16, fewer for short runs)")
     args = ap.parse_args()
     BOUNCES = args.bounces
 
@@ -111,15 +115,23 @@ def main():
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
     if args.inflight <= 0:
-        # a rank that owns 1/N of the rows has 1/N of the work per frame but the same longest tile: more frames in flight
-        args.inflight = 4 if world == 1 else 8
+        # A frame's longest tile is a serial chain of ~0.15-0.3 ms however few rows a rank owns, so a rank needs that much
+        # work in flight: 16 frames per launch, and the more launches overlapping the smaller its share of the frame
+        # (measured per rank with scripts/exp_rank_emulation.py: 2x16 / 3x16 / 3x16 / 4x16 for 1 / 2 / 4 / 8 ranks).
+        args.inflight = 2 if world == 1 else (3 if world <= 4 else 4)
+    if args.batch <= 0:
+        args.batch = 16
+        while args.batch > 1 and args.batch * args.inflight * 2 > max(args.steps, 1):   # short runs: keep the pipeline fed
+            args.batch //= 2
     from gpu_voxel_raytracer_amd import Camera, Context, TIMED, TRACE, scenes
 
     pos, mrgb, size = scenes.load_scene(SCENE)
-    cam = scenes.bench_camera(size) if args.view == "bench" else scenes.close_camera(size)
+    cam = scenes.close_camera(size) if args.view == "close" else scenes.bench_camera(size)
+    if args.view == "away":   # diagnostic: every primary ray misses (pure G-buffer write traffic)
+        cam = (cam[0], -cam[1], cam[2])
 
     ctx = Context(WIDTH, HEIGHT, device=device, max_bounces=BOUNCES, rank=rank, nranks=world, band_rows=16,
-                  frames_in_flight=args.inflight)
+                  frames_in_flight=args.inflight, frames_per_launch=args.batch)
     ctx.recreate_octree(pos, mrgb)
     ctx.camera = Camera(*cam)
 
@@ -152,14 +164,16 @@ def main():
 
     if rank == 0:
         # Roofline of the trace stage = trace_kernel (every pixel up to its second hit) + bounce_kernel (the paths still
-        # alive there, compacted), back to back on one stream; launch_ms is the HIP-event time around the pair
-        # (rocprofv3's two average durations add up to it).  With F frames in flight F such pairs overlap on the GPU,
-        # so a pair's own duration is ~F x the time the chip spends per frame:
-        # achieved = F x algorithmic bytes per frame / average pair duration.
-        launch_ms = kernel_ms / max(st.timed_frames, 1)
-        alg = algorithmic_bytes(local_px, BOUNCES, st.scene_bytes)
-        conc = max(1, min(args.inflight, args.steps))
-        achieved = conc * alg / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        # alive there, compacted), back to back on one stream, covering `frames_per_launch` consecutive frames;
+        # launch_ms is the HIP-event time around the pair (rocprofv3's two average durations add up to it).  With S
+        # launches in flight S such pairs overlap on the GPU, so a pair's own duration is ~S x the time the chip
+        # spends on it: achieved = S x algorithmic bytes per launch / average pair duration.
+        launches = max(st.timed_launches, 1)
+        launch_ms = kernel_ms / launches
+        frames_per_launch = st.timed_frames / launches
+        alg = algorithmic_bytes(local_px, BOUNCES, st.scene_bytes)       # per frame
+        conc = max(1, min(args.inflight, launches))
+        achieved = conc * frames_per_launch * alg / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         out = {
             "metric": "Mrays/s", "value": round(rays / elapsed / 1e6, 2), "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -167,14 +181,15 @@ def main():
             "config": {"workload": f"vox/{SCENE}.vox {WIDTH}x{HEIGHT}, 1 spp, {BOUNCES} bounces, trace stage only "
                                    f"(BASELINE configs[1]); camera '{args.view}' of SURVEY §8d; Uniforms::default()",
                        "parallelism": f"screen bands x{world} (16-row interleave, scene replicated)",
-                       "frames_in_flight": args.inflight,
+                       "launches_in_flight": args.inflight, "frames_per_launch": args.batch,
                        "rays_per_frame": rays // args.steps, "rays_per_pixel": round(rays / args.steps / (WIDTH * HEIGHT), 4),
                        "mpixels_per_s": round(WIDTH * HEIGHT * args.steps / elapsed / 1e6, 1)},
             "roofline": {"bound": "hbm", "kernel": "trace_kernel + bounce_kernel (one trace stage)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": measured_traffic() if (world == 1 and args.view == "bench" and BOUNCES == 4) else None,
+                         "traffic": measured_traffic(frames_per_launch) if (world == 1 and args.view == "bench" and BOUNCES == 4) else None,
                          "launch_ms": round(launch_ms, 4), "concurrent_launches": conc,
-                         "algorithmic_bytes_per_launch": alg,
+                         "frames_per_launch": round(frames_per_launch, 2),
+                         "algorithmic_bytes_per_launch": int(alg * frames_per_launch),
                          "achieved_wall_basis": round(alg * args.steps / elapsed / 1e9, 2)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -35,13 +35,23 @@ struct PathQueue {
     unsigned shard_capacity;  // records per shard
 };
 
+constexpr int kMaxBatch = 16;      // frames one trace launch can cover (vxrt_config.frames_per_launch)
+constexpr uint32_t kPixBits = 28;  // PathRec::pix = local pixel index | frame-in-batch << 28
+struct FrameOut {                  // the three voxels.comp outputs of one frame (a ring slot of the context)
+    float4* color;
+    float4* nd;
+    float4* albedo;
+};
+
 struct TraceArgs {
     const SvoRecord* svo;
     const int32_t* leaves;
     const float* noise;
-    float4* out_color;
+    float4* out_color;   // = out[0].*: the single-frame kernels (tracer 2 / 3) use these
     float4* out_nd;
     float4* out_albedo;
+    FrameOut out[kMaxBatch];  // trace_kernel / bounce_kernel: frame f of the launch's batch (frame_number + f) writes out[f]
+    int batch;                // frames in this launch, 1..kMaxBatch: block b renders frame b % batch of tile order[b / batch]
     unsigned long long* ray_counter;  // kRaySlots counters, 8 words apart
     const uint32_t* tile_order;       // monolithic kernel: block b renders 16x16 tile tile_order[b] (null: b)
     uint32_t* tile_cost;              // ... and records how long the tile took (shader clocks, max over its waves)

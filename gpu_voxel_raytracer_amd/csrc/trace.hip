@@ -40,7 +40,12 @@ __global__ __launch_bounds__(kBlock, VXRT_TRACE_WAVES) void trace_kernel(const T
     // geometry, and started last they would leave the chip idling behind a few long waves.
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     const unsigned tiles_x = unsigned(a.band.width + 15) / 16u;
-    const unsigned tile = a.tile_order ? a.tile_order[blockIdx.x] : blockIdx.x;
+    // a launch covers `batch` consecutive frames (same camera, frame numbers frame_number ..): the blocks of one tile
+    // position in all frames are neighbours in launch order, so longest-first holds across the whole batch
+    const unsigned batch = unsigned(a.batch);
+    const unsigned fb = blockIdx.x % batch, ord = blockIdx.x / batch;
+    const FrameOut fo = a.out[fb];
+    const unsigned tile = a.tile_order ? a.tile_order[ord] : ord;
     const int x = int(tile % tiles_x) * 16 + (wave & 1) * 8 + (lane & 7);
     const int lrow = int(tile / tiles_x) * 16 + (wave >> 1) * 8 + (lane >> 3);
     const int lband = lrow / a.band.band_rows;
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(kBlock, VXRT_TRACE_WAVES) void trace_kernel(const T
 
         Rng rng;
         rng.noise = a.noise;
-        rng.index = uint32_t(x) % 128u + (uint32_t(y) % 128u) * 128u + (a.frame_number % 512u) * kNoiseLayer;
+        rng.index = uint32_t(x) % 128u + (uint32_t(y) % 128u) * 128u + ((a.frame_number + fb) % 512u) * kNoiseLayer;
 
         const f3 sun_dir = ld3(a.sun_dir), sun_color = ld3(a.sun_color), sky = ld3(a.sky_color);
 
@@ -96,8 +101,8 @@ __global__ __launch_bounds__(kBlock, VXRT_TRACE_WAVES) void trace_kernel(const T
                     blend = splat3(1.0f);
                     float sun_power = vx_pow(vx_max(0.0f, dot3(d, ld3(a.neg_sun_dir_n))), a.sun_exponent);
                     sample = sample + (sky + sun_color * sun_power) * blend;
-                    a.out_nd[pix] = make_float4(kAlmostInfinity, kAlmostInfinity, kAlmostInfinity, -1.0f);
-                    a.out_albedo[pix] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(0xffffff));
+                    fo.nd[pix] = make_float4(kAlmostInfinity, kAlmostInfinity, kAlmostInfinity, -1.0f);
+                    fo.albedo[pix] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(0xffffff));
                 } else {
                     sample = sample + sky * blend;
                 }
@@ -114,16 +119,16 @@ __global__ __launch_bounds__(kBlock, VXRT_TRACE_WAVES) void trace_kernel(const T
                 rec.sample = sample;
                 rec.blend = blend;
                 rec.rng_index = rng.index;
-                rec.pix = uint32_t(pix);
+                rec.pix = uint32_t(pix) | fb << kPixBits;
                 to_tail = true;
                 break;
             }
             const f3 color = bounce == 0 ? splat3(1.0f) : node_color(hit.node);
             const f3 emit = node_emittance(hit.node, a.emit_strength);
             if (bounce == 0) {  // first-hit G-buffer                           voxels.comp:320-324,392-396
-                a.out_nd[pix] = make_float4(n.x, n.y, n.z, hit.time);
+                fo.nd[pix] = make_float4(n.x, n.y, n.z, hit.time);
                 f3 alb = (hit.node & kEmitBit) == 0 ? node_color(hit.node) : splat3(1.0f);
-                a.out_albedo[pix] = make_float4(alb.x, alb.y, alb.z, __int_as_float(hit.node));
+                fo.albedo[pix] = make_float4(alb.x, alb.y, alb.z, __int_as_float(hit.node));
             }
 
             if (rng.next() < a.specularity) {  // specular                     voxels.comp:326-334
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(kBlock, VXRT_TRACE_WAVES) void trace_kernel(const T
 
         if (!to_tail) {
             f3 out = sample / float(ambient_rays);  // voxels.comp:391
-            a.out_color[pix] = make_float4(out.x, out.y, out.z, 1.0f);
+            fo.color[pix] = make_float4(out.x, out.y, out.z, 1.0f);
         }
     }
     if (a.tail_from > 0) {
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(uint32_t* cost, uint32
 }  // namespace
 
 hipError_t launch_trace(const TraceArgs& a, hipStream_t s) {
-    dim3 grid(unsigned((a.band.width + 15) / 16) * unsigned((a.band.local_rows + 15) / 16));
+    dim3 grid(unsigned((a.band.width + 15) / 16) * unsigned((a.band.local_rows + 15) / 16) * unsigned(a.batch));
     size_t lds = size_t(a.stack_levels) * kBlock * sizeof(uint2);
     hipLaunchKernelGGL(trace_kernel, grid, dim3(kBlock), lds, s, a);
     return hipGetLastError();

@@ -87,7 +87,10 @@ struct vxrt_ctx {
     bool has_history = false;
     bool accum_is_sampled = true;  // the latest "accumulated" image is sampled_color (temporal never ran)
     int last = 0;                   // index of the most recently written accum image
-    uint64_t traced = 0;            // frames traced so far (selects the trace stream)
+    uint64_t traced = 0;            // frames traced so far
+    uint64_t trace_launches = 0;    // trace launches so far (selects the trace stream)
+    uint64_t timed_launches = 0;
+    int batch = 1;                  // vxrt_config.frames_per_launch
 
     // parameters
     vxrt_uniforms uniforms{};
@@ -178,7 +181,7 @@ int alloc_images(vxrt_ctx* c) {
     size_t bytes = image_bytes(c);
     if (bytes == 0) bytes = sizeof(float4);
     // inflight frames being traced + the frame in the post stages + the temporal history
-    c->ring.resize(size_t(c->inflight) + 2);
+    c->ring.resize(size_t(c->inflight) * size_t(c->batch) + 2);
     for (vxrt_ctx::Slot& sl : c->ring) {
         for (float4** p : {&sl.sampled_color, &sl.albedo, &sl.nd}) {
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), bytes));
@@ -194,7 +197,7 @@ int alloc_images(vxrt_ctx* c) {
         HIP_TRY(hipMemsetAsync(*p, 0, bytes, c->stream));
     }
     // path queues: every 8x8-pixel wave of the primary launch appends to shard (wave index % 64)
-    const size_t waves = size_t((c->band.width + 15) / 16) * size_t((c->band.local_rows + 15) / 16) * 4;
+    const size_t waves = size_t((c->band.width + 15) / 16) * size_t((c->band.local_rows + 15) / 16) * 4 * size_t(c->batch);
     c->shard_capacity = unsigned((waves + 63) / 64 * 64);
     if (c->trace_variant != 0) {
         c->queues.resize(size_t(c->inflight));
@@ -378,7 +381,7 @@ bool valid_ctx(const vxrt_ctx* c) {
 
 extern "C" {
 
-uint32_t vxrt_abi_version(void) { return 1; }
+uint32_t vxrt_abi_version(void) { return 2; }
 
 const char* vxrt_last_error(void) { return vxrt::last_error().c_str(); }
 
@@ -462,6 +465,9 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) {
     c->shade_blocks = (c->shade_blocks < 8 ? 8 : (c->shade_blocks > 2048 ? 2048 : c->shade_blocks) + 7) / 8 * 8;
     if (const char* v = getenv("VXRT_TRACE_BLOCKS")) c->trace_blocks = atoi(v);
     if (c->inflight < 1 || c->inflight > 16) { set_error("frames_in_flight must be 1..16"); return fail(VXRT_E_INVALID); }
+    c->batch = cfg->frames_per_launch == 0 ? 1 : int(cfg->frames_per_launch);
+    if (const char* v = getenv("VXRT_BATCH")) c->batch = atoi(v);
+    if (c->batch < 1 || c->batch > kMaxBatch) { set_error("frames_per_launch must be 1..16"); return fail(VXRT_E_INVALID); }
     c->trace_streams.assign(size_t(c->inflight), nullptr);
     if (c->inflight == 1) {
         c->trace_streams[0] = c->stream;
@@ -584,7 +590,9 @@ int vxrt_set_frame_number(vxrt_ctx* c, uint32_t frame_number) {
     return VXRT_OK;
 }
 
-int vxrt_render(vxrt_ctx* c, uint32_t flags) {
+namespace {
+
+int check_render(vxrt_ctx* c, uint32_t flags) {
     if (!valid_ctx(c)) return VXRT_E_INVALID;
     if ((flags & VXRT_ALL) == 0) { set_error("no stage selected"); return VXRT_E_INVALID; }
     if (!c->has_scene) { set_error("vxrt_render before any scene was set"); return VXRT_E_NOSCENE; }
@@ -597,117 +605,142 @@ int vxrt_render(vxrt_ctx* c, uint32_t flags) {
         set_error("multi-rank denoise: halo not imported for this frame/radius");
         return VXRT_E_INVALID;
     }
-    HIP_TRY(hipSetDevice(c->cfg.device));
-    const bool timed = (flags & VXRT_TIMED) != 0;
+    return VXRT_OK;
+}
 
-    if (flags & (VXRT_TRACE | VXRT_TEMPORAL)) {
-        // Context::update_bindings (src/context.rs:2136-2162): old <- current, current <- camera, frame_number + 1
-        if (flags & VXRT_TRACE) {
-            c->old_cam = c->cam;
-            CameraBasis basis = camera_axis_scaled(c->cam_dir, c->cam_fov, c->cfg.width, c->cfg.height);
-            c->cam = make_cam(c->cam_pos, basis);
-            for (int i = 0; i < 3; i++) {
-                c->uniforms.camera_origin[i] = c->cam.o[i]; c->uniforms.camera_right[i] = c->cam.r[i];
-                c->uniforms.camera_up[i] = c->cam.u[i]; c->uniforms.camera_forward[i] = c->cam.f[i];
-            }
-            c->uniforms.still_sample += 1;
-            c->uniforms.frame_number += 1;  // wrapping
-        }
+// Context::update_bindings for one frame (src/context.rs:2136-2162): old <- current, current <- camera, frame_number + 1
+void update_bindings(vxrt_ctx* c) {
+    c->old_cam = c->cam;
+    CameraBasis basis = camera_axis_scaled(c->cam_dir, c->cam_fov, c->cfg.width, c->cfg.height);
+    c->cam = make_cam(c->cam_pos, basis);
+    for (int i = 0; i < 3; i++) {
+        c->uniforms.camera_origin[i] = c->cam.o[i]; c->uniforms.camera_right[i] = c->cam.r[i];
+        c->uniforms.camera_up[i] = c->cam.u[i]; c->uniforms.camera_forward[i] = c->cam.f[i];
     }
+    c->uniforms.still_sample += 1;
+    c->uniforms.frame_number += 1;  // wrapping
+}
 
-    if (flags & VXRT_TRACE) {
-        const vxrt_uniforms& u = c->uniforms;
-        // next frame slot (never the temporal history) and the trace stream of this frame
-        int s = (c->slot + 1) % int(c->ring.size());
+// The trace stage of the next g frames (parameters at rest) as ONE launch of the tracer: g ring slots, frame numbers
+// frame_number+1 .. +g.  g > 1 only with the trace_kernel-based tracers (1 and 4).  slots[k] = ring slot of frame k;
+// *first_old = the "old" camera of the first of these frames (the later ones see the current camera as their old one).
+int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* first_old) {
+    const uint32_t first_frame_number = c->uniforms.frame_number + 1;
+    for (uint32_t k = 0; k < g; k++) {
+        update_bindings(c);
+        if (k == 0) *first_old = c->old_cam;
+    }
+    const vxrt_uniforms& u = c->uniforms;
+    // next frame slots (never the temporal history) and the trace stream of this launch
+    int s = c->slot;
+    for (uint32_t k = 0; k < g; k++) {
+        s = (s + 1) % int(c->ring.size());
         if (c->has_history && s == c->hist_slot) s = (s + 1) % int(c->ring.size());
-        const size_t lane = size_t(c->traced % uint64_t(c->inflight));
-        hipStream_t ts = c->trace_streams[lane];
-        vxrt_ctx::TileSchedule& sched = c->schedules[lane];
-        vxrt_ctx::Slot& slot = c->ring[size_t(s)];
-        if (slot.last_use_recorded) HIP_TRY(hipStreamWaitEvent(ts, slot.last_use, 0));
-
-        TraceArgs a;
-        a.svo = c->d_svo; a.leaves = c->d_leaves; a.noise = c->d_noise;
-        a.out_color = slot.sampled_color; a.out_nd = slot.nd; a.out_albedo = slot.albedo;
-        a.ray_counter = c->d_rays;
-        a.tile_order = (c->use_tile_order && sched.valid) ? sched.order : nullptr;
-        a.tile_cost = c->use_tile_order ? sched.cost : nullptr;
-        memcpy(a.root_center, c->root_center, sizeof a.root_center);
-        a.root_size = c->root_size;
-        a.band = c->band;
-        a.max_bounces = int(c->cfg.max_bounces);
-        a.frame_number = u.frame_number;
-        a.launch_index = 0;
-        a.stack_levels = c->depth < 1 ? 1 : int(c->depth);
-        a.cam = c->cam;
-        // voxels.comp:296 and the other per-frame constants, evaluated once with the same operations
-        f3 sun_dir = mk3(vx_cos(u.sun_yaw) * vx_cos(u.sun_pitch), -vx_sin(u.sun_pitch), vx_sin(u.sun_yaw) * vx_cos(u.sun_pitch));
-        f3 sun_n = norm3(sun_dir), neg_sun_n = norm3(-sun_dir);
-        f3 sun_color = u.sun_strength * mk3(u.sun_color[0], u.sun_color[1], u.sun_color[2]);
-        a.sun_dir[0] = sun_dir.x; a.sun_dir[1] = sun_dir.y; a.sun_dir[2] = sun_dir.z;
-        a.sun_dir_n[0] = sun_n.x; a.sun_dir_n[1] = sun_n.y; a.sun_dir_n[2] = sun_n.z;
-        a.neg_sun_dir_n[0] = neg_sun_n.x; a.neg_sun_dir_n[1] = neg_sun_n.y; a.neg_sun_dir_n[2] = neg_sun_n.z;
-        a.sun_color[0] = sun_color.x; a.sun_color[1] = sun_color.y; a.sun_color[2] = sun_color.z;
-        a.sky_color[0] = u.sky_color[0]; a.sky_color[1] = u.sky_color[1]; a.sky_color[2] = u.sky_color[2];
-        a.sun_exponent = 1.0f / (u.sun_size * u.sun_size);
-        a.sun_size = u.sun_size; a.sun_strength = u.sun_strength; a.emit_strength = u.emit_strength; a.specularity = u.specularity;
-        if (c->band.local_rows > 0) {
-            EventPair p;
-            if (timed) { p = take_pair(c, 0); HIP_TRY(hipEventRecord(p.a, ts)); }
-            a.tail = PathQueue{nullptr, nullptr, 0};
-            a.tail_zero = nullptr;
-            a.tail_from = 0;
-            if (c->trace_variant == 0 || c->trace_variant == 4) {
-                if (c->trace_variant == 4) {
-                    // count sets rotate as in launch_trace_wavefront: launch J reads set J%3, writes (J+1)%3, clears (J+2)%3
-                    vxrt_ctx::StreamQueues& sq = c->queues[lane];
-                    unsigned* sets[3] = {sq.counts3, sq.counts3 + 64 * 16, sq.counts3 + 2 * 64 * 16};
-                    const unsigned J = sq.launches;
-                    a.tail = PathQueue{sq.hitq[0], sets[(J + 1) % 3], c->shard_capacity};
-                    a.tail_zero = sets[(J + 2) % 3];
-                    a.tail_from = c->tail_from;
-                    HIP_TRY(launch_trace(a, ts));
-                    sq.launches = J + 1;
-                    PathQueue queues[2] = {{sq.hitq[0], nullptr, c->shard_capacity}, {sq.hitq[1], nullptr, c->shard_capacity}};
-                    HIP_TRY(launch_bounces(a, queues, sets, &sq.launches, c->trace_blocks, c->tail_split, c->tail_from, ts));
-                } else {
-                    HIP_TRY(launch_trace(a, ts));
-                }
-                if (timed) HIP_TRY(hipEventRecord(p.b, ts));
-                // Re-sort the tiles for this stream's coming frames from the costs just measured: after its first
-                // frame, then every 8th (costs keep accumulating as a running maximum in between; ~7 us per sort).
-                if (c->use_tile_order && (!sched.valid || sched.age >= 8)) {
-                    const unsigned tiles = unsigned((c->band.width + 15) / 16) * unsigned((c->band.local_rows + 15) / 16);
-                    HIP_TRY(launch_tile_order(sched.cost, sched.order, sched.last_cost, tiles, ts));
-                    sched.valid = true;
-                    sched.age = 0;
-                }
-                sched.age++;
-            } else {
-                vxrt_ctx::StreamQueues& sq = c->queues[lane];
-                PathQueue queues[2] = {{sq.hitq[0], nullptr, c->shard_capacity}, {sq.hitq[1], nullptr, c->shard_capacity}};
-                unsigned* sets[3] = {sq.counts3, sq.counts3 + 64 * 16, sq.counts3 + 2 * 64 * 16};
-                if (c->trace_variant == 2)
-                    HIP_TRY(launch_trace_wavefront(a, queues, sets, &sq.launches, c->trace_blocks, c->trace_split, ts));
-                else
-                    HIP_TRY(launch_trace_rayqueue(a, queues[0], sets, &sq.launches, sq.rq, c->shade_blocks, c->trace_blocks, c->rays_per_wave, ts));
-                if (timed) HIP_TRY(hipEventRecord(p.b, ts));
-            }
-            if (timed) c->pending.push_back(p);
-        }
-        HIP_TRY(hipEventRecord(slot.trace_done, ts));
-        HIP_TRY(hipEventRecord(slot.last_use, ts));  // until a later stage reads the slot, the trace is its last use
-        slot.last_use_recorded = true;
-        c->slot = s;
-        c->last_schedule = int(lane);
-        c->traced += 1;
-        c->frames += 1;
-        c->pixels += uint64_t(c->band.local_rows) * c->band.width;
-        if (timed) c->timed_frames += 1;
-        c->accum_is_sampled = true;
-        c->halo_valid = false;
+        slots[k] = s;
+    }
+    const size_t lane = size_t(c->trace_launches % uint64_t(c->inflight));
+    hipStream_t ts = c->trace_streams[lane];
+    vxrt_ctx::TileSchedule& sched = c->schedules[lane];
+    for (uint32_t k = 0; k < g; k++) {
+        vxrt_ctx::Slot& sl = c->ring[size_t(slots[k])];
+        if (sl.last_use_recorded) HIP_TRY(hipStreamWaitEvent(ts, sl.last_use, 0));
     }
 
+    TraceArgs a;
+    a.svo = c->d_svo; a.leaves = c->d_leaves; a.noise = c->d_noise;
+    for (uint32_t k = 0; k < g; k++) {
+        const vxrt_ctx::Slot& sl = c->ring[size_t(slots[k])];
+        a.out[k] = FrameOut{sl.sampled_color, sl.nd, sl.albedo};
+    }
+    a.out_color = a.out[0].color; a.out_nd = a.out[0].nd; a.out_albedo = a.out[0].albedo;
+    a.batch = int(g);
+    a.ray_counter = c->d_rays;
+    a.tile_order = (c->use_tile_order && sched.valid) ? sched.order : nullptr;
+    a.tile_cost = c->use_tile_order ? sched.cost : nullptr;
+    memcpy(a.root_center, c->root_center, sizeof a.root_center);
+    a.root_size = c->root_size;
+    a.band = c->band;
+    a.max_bounces = int(c->cfg.max_bounces);
+    a.frame_number = first_frame_number;
+    a.launch_index = 0;
+    a.stack_levels = c->depth < 1 ? 1 : int(c->depth);
+    a.cam = c->cam;
+    // voxels.comp:296 and the other per-frame constants, evaluated once with the same operations
+    f3 sun_dir = mk3(vx_cos(u.sun_yaw) * vx_cos(u.sun_pitch), -vx_sin(u.sun_pitch), vx_sin(u.sun_yaw) * vx_cos(u.sun_pitch));
+    f3 sun_n = norm3(sun_dir), neg_sun_n = norm3(-sun_dir);
+    f3 sun_color = u.sun_strength * mk3(u.sun_color[0], u.sun_color[1], u.sun_color[2]);
+    a.sun_dir[0] = sun_dir.x; a.sun_dir[1] = sun_dir.y; a.sun_dir[2] = sun_dir.z;
+    a.sun_dir_n[0] = sun_n.x; a.sun_dir_n[1] = sun_n.y; a.sun_dir_n[2] = sun_n.z;
+    a.neg_sun_dir_n[0] = neg_sun_n.x; a.neg_sun_dir_n[1] = neg_sun_n.y; a.neg_sun_dir_n[2] = neg_sun_n.z;
+    a.sun_color[0] = sun_color.x; a.sun_color[1] = sun_color.y; a.sun_color[2] = sun_color.z;
+    a.sky_color[0] = u.sky_color[0]; a.sky_color[1] = u.sky_color[1]; a.sky_color[2] = u.sky_color[2];
+    a.sun_exponent = 1.0f / (u.sun_size * u.sun_size);
+    a.sun_size = u.sun_size; a.sun_strength = u.sun_strength; a.emit_strength = u.emit_strength; a.specularity = u.specularity;
+    if (c->band.local_rows > 0) {
+        EventPair p;
+        if (timed) { p = take_pair(c, 0); HIP_TRY(hipEventRecord(p.a, ts)); }
+        a.tail = PathQueue{nullptr, nullptr, 0};
+        a.tail_zero = nullptr;
+        a.tail_from = 0;
+        if (c->trace_variant == 0 || c->trace_variant == 4) {
+            if (c->trace_variant == 4) {
+                // count sets rotate as in launch_trace_wavefront: launch J reads set J%3, writes (J+1)%3, clears (J+2)%3
+                vxrt_ctx::StreamQueues& sq = c->queues[lane];
+                unsigned* sets[3] = {sq.counts3, sq.counts3 + 64 * 16, sq.counts3 + 2 * 64 * 16};
+                const unsigned J = sq.launches;
+                a.tail = PathQueue{sq.hitq[0], sets[(J + 1) % 3], c->shard_capacity};
+                a.tail_zero = sets[(J + 2) % 3];
+                a.tail_from = c->tail_from;
+                HIP_TRY(launch_trace(a, ts));
+                sq.launches = J + 1;
+                PathQueue queues[2] = {{sq.hitq[0], nullptr, c->shard_capacity}, {sq.hitq[1], nullptr, c->shard_capacity}};
+                HIP_TRY(launch_bounces(a, queues, sets, &sq.launches, c->trace_blocks, c->tail_split, c->tail_from, ts));
+            } else {
+                HIP_TRY(launch_trace(a, ts));
+            }
+            if (timed) HIP_TRY(hipEventRecord(p.b, ts));
+            // Re-sort the tiles for this stream's coming frames from the costs just measured: after its first
+            // frame, then every 8th (costs keep accumulating as a running maximum in between; ~7 us per sort).
+            if (c->use_tile_order && (!sched.valid || sched.age >= 8)) {
+                const unsigned tiles = unsigned((c->band.width + 15) / 16) * unsigned((c->band.local_rows + 15) / 16);
+                HIP_TRY(launch_tile_order(sched.cost, sched.order, sched.last_cost, tiles, ts));
+                sched.valid = true;
+                sched.age = 0;
+            }
+            sched.age++;
+        } else {
+            vxrt_ctx::StreamQueues& sq = c->queues[lane];
+            PathQueue queues[2] = {{sq.hitq[0], nullptr, c->shard_capacity}, {sq.hitq[1], nullptr, c->shard_capacity}};
+            unsigned* sets[3] = {sq.counts3, sq.counts3 + 64 * 16, sq.counts3 + 2 * 64 * 16};
+            if (c->trace_variant == 2)
+                HIP_TRY(launch_trace_wavefront(a, queues, sets, &sq.launches, c->trace_blocks, c->trace_split, ts));
+            else
+                HIP_TRY(launch_trace_rayqueue(a, queues[0], sets, &sq.launches, sq.rq, c->shade_blocks, c->trace_blocks, c->rays_per_wave, ts));
+            if (timed) HIP_TRY(hipEventRecord(p.b, ts));
+        }
+        if (timed) c->pending.push_back(p);
+    }
+    for (uint32_t k = 0; k < g; k++) {
+        vxrt_ctx::Slot& sl = c->ring[size_t(slots[k])];
+        HIP_TRY(hipEventRecord(sl.trace_done, ts));
+        HIP_TRY(hipEventRecord(sl.last_use, ts));  // until a later stage reads the slot, the trace is its last use
+        sl.last_use_recorded = true;
+    }
+    c->slot = slots[g - 1];
+    c->last_schedule = int(lane);
+    c->trace_launches += 1;
+    c->traced += g;
+    c->frames += g;
+    c->pixels += uint64_t(g) * uint64_t(c->band.local_rows) * c->band.width;
+    if (timed) { c->timed_frames += g; c->timed_launches += 1; }
+    c->accum_is_sampled = true;
+    c->halo_valid = false;
+    return VXRT_OK;
+}
+
+// temporal / denoise of the frame in ring slot c->slot, in the reference's order (src/context.rs:2028-2043)
+int post_stages(vxrt_ctx* c, uint32_t flags, bool timed) {
+    const bool multi = c->band.nranks > 1;
     vxrt_ctx::Slot& cur = c->ring[size_t(c->slot)];
     const bool post = (flags & (VXRT_TEMPORAL | VXRT_DENOISE)) != 0;
     if (post && c->traced > 0) HIP_TRY(hipStreamWaitEvent(c->stream, cur.trace_done, 0));
@@ -749,7 +782,6 @@ int vxrt_render(vxrt_ctx* c, uint32_t flags) {
         c->hist_slot = c->slot;
         c->has_history = true;
     }
-    if (flags & VXRT_TRACE) c->old_cam_valid = true;  // the next frame's "old" camera is this frame's
 
     if ((flags & VXRT_DENOISE) && !fused_denoise) {
         DenoiseArgs a;
@@ -778,9 +810,49 @@ int vxrt_render(vxrt_ctx* c, uint32_t flags) {
     return VXRT_OK;
 }
 
+}  // namespace
+
+int vxrt_render(vxrt_ctx* c, uint32_t flags) {
+    if (int rc = check_render(c, flags)) return rc;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const bool timed = (flags & VXRT_TIMED) != 0;
+    if (flags & VXRT_TRACE) {
+        int slot = 0;
+        Cam first_old;
+        if (int rc = trace_frames(c, 1, timed, &slot, &first_old)) return rc;
+    }
+    if (int rc = post_stages(c, flags, timed)) return rc;
+    if (flags & VXRT_TRACE) c->old_cam_valid = true;  // the next frame's "old" camera is this frame's
+    return VXRT_OK;
+}
+
+// `count` frames with the parameters at rest.  With vxrt_config.frames_per_launch = B > 1 the trace stage of up to B
+// consecutive frames is one launch (see trace_frames); temporal / denoise then run per frame, in frame order.
 int vxrt_render_frames(vxrt_ctx* c, uint32_t flags, uint32_t count) {
-    for (uint32_t i = 0; i < count; i++)
-        if (int rc = vxrt_render(c, flags)) return rc;
+    if (int rc = check_render(c, flags)) return rc;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const bool timed = (flags & VXRT_TIMED) != 0;
+    const uint32_t batch = (flags & VXRT_TRACE) && (c->trace_variant == 0 || c->trace_variant == 4) ? uint32_t(c->batch) : 1u;
+    if (batch <= 1) {
+        for (uint32_t i = 0; i < count; i++)
+            if (int rc = vxrt_render(c, flags)) return rc;
+        return VXRT_OK;
+    }
+    for (uint32_t done = 0; done < count;) {
+        const uint32_t g = count - done < batch ? count - done : batch;
+        int slots[kMaxBatch];
+        Cam first_old;
+        if (int rc = trace_frames(c, g, timed, slots, &first_old)) return rc;
+        const Cam at_rest = c->cam;
+        for (uint32_t k = 0; k < g; k++) {
+            c->slot = slots[k];
+            c->old_cam = k == 0 ? first_old : at_rest;
+            if (int rc = post_stages(c, flags, timed)) return rc;
+            c->old_cam_valid = true;
+        }
+        c->old_cam = g > 1 ? at_rest : first_old;
+        done += g;
+    }
     return VXRT_OK;
 }
 
@@ -850,6 +922,7 @@ int vxrt_get_stats(vxrt_ctx* c, vxrt_stats* out) {
     out->temporal_ms = c->ms[1];
     out->denoise_ms = c->ms[2];
     out->timed_frames = c->timed_frames;
+    out->timed_launches = c->timed_launches;
     out->scene_bytes = c->svo_count * sizeof(SvoRecord) + c->leaf_count * sizeof(int32_t);
     out->noise_bytes = kNoiseCount * sizeof(float);
     out->local_rows = uint32_t(c->band.local_rows);
@@ -865,7 +938,7 @@ int vxrt_reset_stats(vxrt_ctx* c) {
     // non-blocking trace streams nor guaranteed to have finished when it returns
     HIP_TRY(hipMemsetAsync(c->d_rays, 0, kRaySlots * 64, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->frames = c->pixels = c->timed_frames = 0;
+    c->frames = c->pixels = c->timed_frames = c->timed_launches = 0;
     c->ms[0] = c->ms[1] = c->ms[2] = 0.0;
     return VXRT_OK;
 }

@@ -88,13 +88,14 @@ class DenoiseUniforms(C.Structure):
 class Config(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("device", C.c_int32), ("max_bounces", C.c_uint32),
                 ("noise_seed", C.c_uint32), ("noise", C.c_void_p), ("rank", C.c_uint32), ("nranks", C.c_uint32),
-                ("band_rows", C.c_uint32), ("frames_in_flight", C.c_uint32), ("tracer", C.c_uint32)]
+                ("band_rows", C.c_uint32), ("frames_in_flight", C.c_uint32), ("tracer", C.c_uint32),
+                ("frames_per_launch", C.c_uint32)]
 
 
 class Stats(C.Structure):
     _fields_ = [("frames", C.c_uint64), ("rays", C.c_uint64), ("pixels", C.c_uint64), ("trace_ms", C.c_double),
                 ("temporal_ms", C.c_double), ("denoise_ms", C.c_double), ("timed_frames", C.c_uint64),
-                ("scene_bytes", C.c_uint64), ("noise_bytes", C.c_uint64), ("local_rows", C.c_uint32),
+                ("timed_launches", C.c_uint64), ("scene_bytes", C.c_uint64), ("noise_bytes", C.c_uint64), ("local_rows", C.c_uint32),
                 ("octree_depth", C.c_uint32), ("octree_nodes", C.c_uint64)]
 
 
@@ -261,12 +262,12 @@ class Context:
     """
 
     def __init__(self, width, height, device=0, max_bounces=3, noise=None, noise_seed=DEFAULT_NOISE_SEED, rank=0,
-                 nranks=1, band_rows=16, frames_in_flight=1, tracer=0):
+                 nranks=1, band_rows=16, frames_in_flight=1, tracer=0, frames_per_launch=1):
         self._h = C.c_void_p()
         self.width, self.height = int(width), int(height)
         self.camera = Camera()
         cfg = Config(self.width, self.height, int(device), int(max_bounces), int(noise_seed), None, int(rank),
-                     int(nranks), int(band_rows), int(frames_in_flight), int(tracer))
+                     int(nranks), int(band_rows), int(frames_in_flight), int(tracer), int(frames_per_launch))
         keep = None
         if noise is not None:
             keep = np.ascontiguousarray(noise, np.float32)

@@ -96,7 +96,7 @@ typedef struct vxrt_config {
     uint32_t band_rows;       /* ... where band b = rows [b*band_rows, (b+1)*band_rows); 0 -> 16.       */
                               /* nranks = 0 or 1 -> the whole frame                                     */
     uint32_t frames_in_flight;/* 0/1: every stage of a frame runs in submission order on one stream (the
-                                 reference's single queue).  F = 2..8: the TRACE stage of up to F consecutive
+                                 reference's single queue).  F = 2..16: the TRACE stage of up to F consecutive
                                  frames may run concurrently (one HIP stream each, ring of F+2 G-buffer slots);
                                  temporal/denoise still run in frame order.  Results are identical.       */
     uint32_t tracer;          /* scheduling of the trace stage; every choice gives bit-identical images:
@@ -106,6 +106,11 @@ typedef struct vxrt_config {
                                  ray by ray), 4 monolithic head + compacted tail (the monolithic kernel follows a
                                  path up to its second hit; the paths still alive there — about a third of a
                                  geometry tile's lanes — are queued and finished by a dense launch).          */
+    uint32_t frames_per_launch;/* 0/1: one trace launch per frame.  B = 2..16: vxrt_render_frames (parameters at rest)
+                                 traces up to B consecutive frames with ONE launch of the tracer (tracers 1 and 4;
+                                 B ring slots, frame numbers n+1..n+B, longest tile first across the whole batch);
+                                 temporal / denoise still run per frame in frame order.  Results are identical.
+                                 Up to frames_in_flight such launches overlap (one stream each).             */
 } vxrt_config;
 
 typedef enum vxrt_image {
@@ -132,6 +137,7 @@ typedef struct vxrt_stats {
     double temporal_ms;
     double denoise_ms;
     uint64_t timed_frames;
+    uint64_t timed_launches;  /* trace launches behind trace_ms (= timed_frames unless frames_per_launch > 1)   */
     uint64_t scene_bytes;     /* device bytes of the scene (octree) and of the noise table              */
     uint64_t noise_bytes;
     uint32_t local_rows;      /* rows owned by this context                                             */

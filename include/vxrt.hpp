@@ -122,12 +122,12 @@ class Context {
     DenoiseUniforms denoise_uniforms;
 
     Context(uint32_t width, uint32_t height, uint32_t max_bounces = 3, int device = 0, uint32_t frames_in_flight = 1,
-            uint32_t rank = 0, uint32_t nranks = 1)
+            uint32_t rank = 0, uint32_t nranks = 1, uint32_t frames_per_launch = 1)
         : width_(width), height_(height) {
         vxrt_config cfg{};
         cfg.width = width; cfg.height = height; cfg.device = device; cfg.max_bounces = max_bounces;
         cfg.noise_seed = 0x5EED0001u; cfg.noise = nullptr; cfg.rank = rank; cfg.nranks = nranks; cfg.band_rows = 16;
-        cfg.frames_in_flight = frames_in_flight; cfg.tracer = 0;
+        cfg.frames_in_flight = frames_in_flight; cfg.tracer = 0; cfg.frames_per_launch = frames_per_launch;
         check(vxrt_create(&cfg, &ctx_), "vxrt_create");
     }
     ~Context() { vxrt_destroy(ctx_); }
@@ -169,6 +169,14 @@ class Context {
         check(vxrt_set_temporal(ctx_, &temporal_uniforms), "vxrt_set_temporal");
         check(vxrt_set_denoise(ctx_, &denoise_uniforms), "vxrt_set_denoise");
         check(vxrt_render(ctx_, flags), "vxrt_render");
+    }
+    // `count` frames with the camera and parameters at rest (one trace launch per frames_per_launch frames)
+    void render_frames(uint32_t flags, uint32_t count) {
+        check(vxrt_set_camera(ctx_, camera.position.data(), camera.direction.data(), camera.fov), "vxrt_set_camera");
+        check(vxrt_set_scene_params(ctx_, &uniforms), "vxrt_set_scene_params");
+        check(vxrt_set_temporal(ctx_, &temporal_uniforms), "vxrt_set_temporal");
+        check(vxrt_set_denoise(ctx_, &denoise_uniforms), "vxrt_set_denoise");
+        check(vxrt_render_frames(ctx_, flags, count), "vxrt_render_frames");
     }
     void sync() { check(vxrt_sync(ctx_), "vxrt_sync"); }
     std::vector<float> read(vxrt_image which) {

@@ -195,6 +195,43 @@ def test_frames_in_flight_give_identical_frames(O, H, scenes, noise, inflight):
         assert not np.array_equal(hist, ctx.read(3))
 
 
+@pytest.mark.parametrize("batch,inflight,tracer", [(2, 1, 0), (4, 2, 0), (5, 3, 1), (16, 1, 0)])
+def test_frames_per_launch_give_identical_frames(O, H, scenes, noise, batch, inflight, tracer):
+    """frames_per_launch > 1: vxrt_render_frames traces up to B consecutive frames (camera at rest) with one launch of the
+    tracer; temporal / denoise still run per frame.  Every image after every call must equal the unbatched pipeline's, which the
+    tests above pin to the oracle — including a camera move between calls (the first frame of a batch sees the old camera)."""
+    from gpu_voxel_raytracer_amd import ALL, TRACE, Camera, Context
+    w, h, bounces, radius = 144, 96, 4, 2
+    pos, mrgb, size = scenes.load_scene("castle")
+    p0, d0, fov = scenes.close_camera(size)
+    with Context(w, h, max_bounces=bounces, noise=noise) as one, \
+            Context(w, h, max_bounces=bounces, noise=noise, frames_in_flight=inflight, frames_per_launch=batch, tracer=tracer) as many:
+        for ctx in (one, many):
+            ctx.recreate_octree(pos, mrgb)
+            ctx.denoise_uniforms.radius = radius
+        step = 0
+        for flags, count in ((ALL, 1), (ALL, 3), (ALL, batch), (TRACE, 2 * batch + 1), (ALL, batch + 2), (ALL, 7)):
+            step += 1
+            cam = Camera(p0 + np.float32(0.03 * step) * np.array([1, 0, 0.3], np.float32), d0, fov)
+            for ctx in (one, many):
+                ctx.camera = cam
+                ctx.render_frames(flags, count)
+            for img, label in zip(range(5), ("colour", "nd", "albedo", "accum", "denoised")):
+                assert_bits_equal(many.read(img), one.read(img), f"{label} after call {step} ({count} frames), batch {batch}")
+            assert many.stats().rays == one.stats().rays and many.stats().frames == one.stats().frames
+    # the last frame of a batch against the oracle directly (frame numbering inside a launch)
+    u = O.Uniforms.default()
+    u.set_camera(p0, O.camera_axis_scaled(p0, d0, fov, w, h))
+    with Context(w, h, max_bounces=bounces, noise=noise, frames_per_launch=batch, tracer=tracer) as ctx:
+        ctx.recreate_octree(pos, mrgb)
+        ctx.camera = Camera(p0, d0, fov)
+        ctx.render_frames(TRACE, batch)
+        u.frame_number = batch
+        ref = O.trace(O.create_octree(pos, mrgb), noise, u, w, h, bounces, crop=(0, 0, w, h))
+        for img in range(3):
+            assert_bits_equal(ctx.read(img), ref[img], f"image {img} of frame {batch} of one launch")
+
+
 def test_headless_frame_loop(H, scenes, tmp_path):
     """the headless driver renders a camera path and writes what the reference would display."""
     from gpu_voxel_raytracer_amd import frame_loop
