@@ -132,6 +132,8 @@ hipError_t launch_trace_wavefront(const TraceArgs& a, const PathQueue queues[2],
 // bounce_kernel launches for path segments from.. of the paths queued in queues[0] (tracer 2 and the tail of tracer 4)
 hipError_t launch_bounces(const TraceArgs& a, const PathQueue queues[2], unsigned* count_sets[3], unsigned* launch_counter, int blocks,
                           unsigned split_mask, int from, hipStream_t s);
+// tracer 5: path_kernel (trace_paths.hip) follows the paths queued in `in` to their end, refilling each lane with a new path
+hipError_t launch_paths(const TraceArgs& a, const PathQueue& in, unsigned* zero, int first_bounce, int blocks, hipStream_t s);
 hipError_t launch_temporal(const TemporalArgs& a, hipStream_t s);
 hipError_t launch_denoise(const DenoiseArgs& a, hipStream_t s);
 hipError_t launch_noise_fill(float* dst, uint32_t seed, size_t n, hipStream_t s);

@@ -206,7 +206,6 @@ __global__ __launch_bounds__(kBlock, VXRT_BOUNCE_WAVES) void bounce_kernel(const
 // blockIdx % 8 (block-wide prefix through LDS), so trace waves can split the rays evenly without a scan.
 // The per-path operation order is that of voxels.comp, the results are bit-identical to trace_kernel's.
 // ------------------------------------------------------------------------------------------------------
-constexpr unsigned kFlagSun = 1u, kFlagBounce = 2u;
 #ifndef VXRT_REFILL_LANES
 #define VXRT_REFILL_LANES 16
 #endif
@@ -250,49 +249,6 @@ __device__ __forceinline__ unsigned dense_append(const RayQueue& q, int stage, b
     const unsigned before = wave == 0 ? 0u : (wave == 1 ? c0 : (wave == 2 ? c0 + c1 : c0 + c1 + c2));
     const unsigned rank = __builtin_amdgcn_mbcnt_hi(unsigned(m >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(m), 0u));
     return seg * q.seg_capacity + base + before + rank;
-}
-
-struct Shaded {  // what shading a hit produces
-    f3 sample, blend, pend_sun, pend_emit, origin, sun_dir, bounce_dir;
-    uint32_t ambient_rays, flags;
-};
-
-// voxels.comp:314-371 for a hit at path segment `bounce` — everything between two cast_ray calls.
-__device__ __forceinline__ Shaded shade_hit(const TraceArgs& a, int bounce, f3 hit_pos, f3 dir, f3 n, int32_t node, f3 sample, f3 blend,
-                                            uint32_t ambient_rays, Rng& rng, f3 sun_dir, f3 sun_color) {
-    Shaded r;
-    const f3 color = bounce == 0 ? splat3(1.0f) : node_color(node);   // voxels.comp:317
-    const f3 emit = node_emittance(node, a.emit_strength);
-    r.origin = hit_pos + 1e-5f * n;                                    // voxels.comp:333,353,370
-    r.pend_sun = r.pend_emit = r.sun_dir = splat3(0.0f);
-    r.flags = bounce + 1 < a.max_bounces ? kFlagBounce : 0u;
-    if (rng.next() < a.specularity) {  // specular                     voxels.comp:326-334
-        r.bounce_dir = norm3(reflect3(dir, n));
-        sample = sample + emit * blend;
-        blend = blend * ((2.0f * color) * dot3(r.bounce_dir, n));
-    } else if (a.sun_strength > 0.0f) {  // diffuse + sun sample         voxels.comp:339-371
-        float r0 = rng.next(), r1 = rng.next(), r2 = rng.next();
-        f3 up_dir = norm3(cross3(mk3(r0, r1, r2), sun_dir));
-        f3 right_dir = norm3(cross3(sun_dir, up_dir));
-        float dx = 2.0f * rng.next() - 1.0f;
-        float dy = 2.0f * rng.next() - 1.0f;
-        f3 light_dir = ld3(a.sun_dir_n) + (dx * right_dir + dy * up_dir) * a.sun_size;
-        r.sun_dir = norm3(-light_dir);
-        ambient_rays++;
-        r.pend_sun = ((sun_color * color) * blend) * vx_max(0.0f, dot3(n, r.sun_dir));
-        r.bounce_dir = random_hemisphere(n, rng);
-        r.pend_emit = emit * blend;
-        blend = blend * (color * dot3(n, r.bounce_dir));
-        r.flags |= kFlagSun;
-    } else {  // diffuse, sun switched off
-        r.bounce_dir = random_hemisphere(n, rng);
-        sample = sample + emit * blend;
-        blend = blend * (color * dot3(n, r.bounce_dir));
-    }
-    r.sample = sample;
-    r.blend = blend;
-    r.ambient_rays = ambient_rays;
-    return r;
 }
 
 // kFirst: paths come from primary_kernel's sharded hit queue (hit already resolved); otherwise from stage-1.

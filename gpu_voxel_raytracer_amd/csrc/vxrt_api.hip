@@ -129,6 +129,7 @@ struct vxrt_ctx {
     int last_schedule = 0;
     int use_tile_order = 1;
     int trace_blocks = 2048;
+    int path_blocks = 512;  // tracer 5: blocks of path_kernel (each wave takes an equal range of the queue, >= 512 paths)
     int tail_from = 1;  // tracer 4: the hit number at which live paths move to the compacted launches
     unsigned tail_split = 0;  // ... bit k: the tail compacts again and starts a new launch at path segment k
     unsigned trace_split = 0x1;  // bit k: compact live paths and start a new launch at path segment k
@@ -451,12 +452,13 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) {
     // 0, 2, 3, 4).  Measured on MI355X with frames in flight (menger 1080p 4 bounces / monu10 4K 8 bounces, ms per frame):
     // tracer 1: 0.219 / 0.52-1.53, tracer 3: 0.275 / 0.82-1.10, tracer 4: 0.175 / 0.54-0.94 -> auto = 4 whenever a path
     // can have a second hit, with one more compaction at path segment 3 from 6 bounces on.
-    if (cfg->tracer > 4) { set_error("tracer must be 0..4"); return fail(VXRT_E_INVALID); }
+    if (cfg->tracer > 5) { set_error("tracer must be 0..5"); return fail(VXRT_E_INVALID); }
     c->trace_variant = cfg->tracer == 0 ? 4 : (cfg->tracer == 1 ? 0 : int(cfg->tracer));
     c->tail_split = cfg->max_bounces >= 6 ? 0x8u : 0u;
     if (const char* v = getenv("VXRT_TRACE_VARIANT")) c->trace_variant = atoi(v);  // A/B override for benchmarks and tests
-    if (c->trace_variant != 2 && c->trace_variant != 3 && c->trace_variant != 4) c->trace_variant = 0;
-    if (c->trace_variant == 4 && cfg->max_bounces < 2) c->trace_variant = 0;  // no tail to compact
+    if (c->trace_variant != 2 && c->trace_variant != 3 && c->trace_variant != 4 && c->trace_variant != 5) c->trace_variant = 0;
+    if (c->trace_variant >= 4 && cfg->max_bounces < 2) c->trace_variant = 0;  // no tail to compact
+    if (const char* v = getenv("VXRT_PATH_BLOCKS")) c->path_blocks = atoi(v);
     if (const char* v = getenv("VXRT_TAIL_FROM")) c->tail_from = atoi(v);
     if (c->tail_from < 1 || c->tail_from >= int(cfg->max_bounces)) c->tail_from = 1;
     if (const char* v = getenv("VXRT_TAIL_SPLIT")) c->tail_split = unsigned(strtoul(v, nullptr, 0));
@@ -682,8 +684,8 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* first_old
         a.tail = PathQueue{nullptr, nullptr, 0};
         a.tail_zero = nullptr;
         a.tail_from = 0;
-        if (c->trace_variant == 0 || c->trace_variant == 4) {
-            if (c->trace_variant == 4) {
+        if (c->trace_variant == 0 || c->trace_variant >= 4) {
+            if (c->trace_variant >= 4) {
                 // count sets rotate as in launch_trace_wavefront: launch J reads set J%3, writes (J+1)%3, clears (J+2)%3
                 vxrt_ctx::StreamQueues& sq = c->queues[lane];
                 unsigned* sets[3] = {sq.counts3, sq.counts3 + 64 * 16, sq.counts3 + 2 * 64 * 16};
@@ -693,8 +695,13 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* first_old
                 a.tail_from = c->tail_from;
                 HIP_TRY(launch_trace(a, ts));
                 sq.launches = J + 1;
-                PathQueue queues[2] = {{sq.hitq[0], nullptr, c->shard_capacity}, {sq.hitq[1], nullptr, c->shard_capacity}};
-                HIP_TRY(launch_bounces(a, queues, sets, &sq.launches, c->trace_blocks, c->tail_split, c->tail_from, ts));
+                if (c->trace_variant == 5) {
+                    HIP_TRY(launch_paths(a, a.tail, sets[J % 3], c->tail_from, c->path_blocks, ts));
+                    sq.launches = J + 2;
+                } else {
+                    PathQueue queues[2] = {{sq.hitq[0], nullptr, c->shard_capacity}, {sq.hitq[1], nullptr, c->shard_capacity}};
+                    HIP_TRY(launch_bounces(a, queues, sets, &sq.launches, c->trace_blocks, c->tail_split, c->tail_from, ts));
+                }
             } else {
                 HIP_TRY(launch_trace(a, ts));
             }
@@ -832,7 +839,7 @@ int vxrt_render_frames(vxrt_ctx* c, uint32_t flags, uint32_t count) {
     if (int rc = check_render(c, flags)) return rc;
     HIP_TRY(hipSetDevice(c->cfg.device));
     const bool timed = (flags & VXRT_TIMED) != 0;
-    const uint32_t batch = (flags & VXRT_TRACE) && (c->trace_variant == 0 || c->trace_variant == 4) ? uint32_t(c->batch) : 1u;
+    const uint32_t batch = (flags & VXRT_TRACE) && (c->trace_variant == 0 || c->trace_variant >= 4) ? uint32_t(c->batch) : 1u;
     if (batch <= 1) {
         for (uint32_t i = 0; i < count; i++)
             if (int rc = vxrt_render(c, flags)) return rc;

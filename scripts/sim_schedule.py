@@ -146,3 +146,74 @@ def hybrid(view="bench", split_round=3):
     full = rays.max(axis=1).sum() * C_STEP + (rays > 0).any(axis=1).sum() * C_SHADE
     print(f"view {view} split at round {split_round}: {n} paths survive; monolithic {full / 1e6:.1f} M, hybrid {head_cost / 1e6:.1f} + {tail_cost / 1e6:.1f} "
           f"= {(head_cost + tail_cost) / 1e6:.1f} M wave-instr ({(head_cost + tail_cost) / full:.3f} x)")
+
+
+def tail_refill(view="bench", split_round=3, ranges=(256, 1024), thresholds=(8, 16, 24, 32), c_small=90.0, sample_waves=300):
+    """The compacted tail with per-lane refill: a wave owns `rng` consecutive queued paths; a lane whose path ended takes the
+    next one; the advance block (shade a hit / start the bounce ray after a sun ray / finish) runs when >= T lanes wait for it
+    or nobody walks.  Cost of an advance: C_SHADE if a lane in it shades, else c_small."""
+    st = steps_for(view=view)
+    t = tiles_of(st)
+    rays = t[:, :, 1:]
+    alive = rays[:, :, split_round] > 0
+    paths = rays[alive][:, split_round:].astype(np.int64)     # [n, rounds]: sun, bounce, sun, bounce, ...
+    n = len(paths)
+    sync = paths_sync_cost(paths)
+    print(f"{n} tail paths; lock-step chunks of 64: {sync / 1e6:.1f} M; dense bound: "
+          f"{(paths.sum() / 64 * C_STEP + (paths > 0).sum() / 64 * (C_SHADE + c_small) / 2) / 1e6:.1f} M wave-instr")
+    rs = np.random.default_rng(2)
+    for rng in ranges:
+        nw = n // rng
+        pick = rs.choice(nw, size=min(sample_waves, nw), replace=False)
+        for T in thresholds:
+            total = 0.0
+            for w in pick:
+                total += refill_wave_cost(paths[w * rng:(w + 1) * rng], T, c_small)
+            print(f"  range {rng:5d} T {T:2d}: {total / len(pick) * nw / 1e6:6.1f} M wave-instr")
+
+
+def paths_sync_cost(paths):
+    n = len(paths)
+    pad = (-n) % 64
+    p = np.concatenate([paths, np.zeros((pad, paths.shape[1]), paths.dtype)]).reshape(-1, 64, paths.shape[1])
+    return p.max(axis=1).sum() * C_STEP + (p > 0).any(axis=1).sum() * C_SHADE
+
+
+def refill_wave_cost(paths, T, c_small):
+    npaths, nr = paths.shape
+    nxt = 0
+    path = -np.ones(64, np.int64)       # path index per lane
+    ray = np.zeros(64, np.int64)        # index of the lane's current ray
+    left = np.zeros(64, np.int64)
+    state = np.zeros(64, np.int64)      # 0 idle, 1 walking, 2 waiting for the advance block
+    cost = 0.0
+    while True:
+        walking = state == 1
+        if walking.any():
+            left[walking] -= 1
+            cost += C_STEP
+            fin = walking & (left <= 0)
+            state[fin] = 2
+        idle = state == 0
+        want = (state == 2).sum() + (min(idle.sum(), npaths - nxt))
+        if want > 0 and (want >= T or not (state == 1).any()):
+            shades = False
+            for l in range(64):
+                if state[l] == 0 and nxt < npaths:
+                    path[l] = nxt; nxt += 1; ray[l] = 0; shades = True          # new path: shade its hit, start the sun ray
+                    left[l] = paths[path[l], 0]; state[l] = 1
+                elif state[l] == 2:
+                    ray[l] += 1
+                    if ray[l] >= nr or paths[path[l], ray[l]] == 0:
+                        state[l] = 0                                             # path finished (written out)
+                        if nxt < npaths:
+                            path[l] = nxt; nxt += 1; ray[l] = 0; shades = True
+                            left[l] = paths[path[l], 0]; state[l] = 1
+                    else:
+                        if ray[l] % 2 == 0:
+                            shades = True                                        # a bounce ray hit: shade, start the sun ray
+                        left[l] = paths[path[l], ray[l]]; state[l] = 1
+            cost += C_SHADE if shades else c_small
+        if nxt >= npaths and not (state != 0).any():
+            break
+    return cost

@@ -147,6 +147,9 @@ def test_full_size_bench_config_crops(O, H, scenes, noise):
     {"VXRT_TRACE_VARIANT": "4", "VXRT_TAIL_FROM": "2", "VXRT_INFLIGHT": "4"},           # ... tail from hit 2, frames in flight
     {"VXRT_TRACE_VARIANT": "4", "VXRT_TRACE_BLOCKS": "16", "VXRT_TILE_ORDER": "0"},     # ... few tail waves, raster tile order
     {"VXRT_TRACE_VARIANT": "4", "VXRT_TAIL_SPLIT": "0xc", "VXRT_INFLIGHT": "3"},        # ... tail compacted again at segments 2 and 3
+    {"VXRT_TRACE_VARIANT": "5"},                                                        # monolithic head + path_kernel (lanes refilled path by path)
+    {"VXRT_TRACE_VARIANT": "5", "VXRT_PATH_BLOCKS": "1", "VXRT_INFLIGHT": "2"},         # ... four waves take the whole queue: many refills per lane
+    {"VXRT_TRACE_VARIANT": "5", "VXRT_TAIL_FROM": "2", "VXRT_BATCH": "4"},              # ... tail from hit 2 (the API calls here are single frames)
 ])
 def test_every_trace_variant_is_bit_exact(O, H, scenes, noise, monkeypatch, env):
     """The scheduling variants of the tracer (read from the environment when a context is created) change
@@ -289,7 +292,7 @@ def test_tracer_field_of_the_config(O, H, scenes, noise):
     pos, mrgb, size = scenes.load_scene("castle")
     cam = scenes.close_camera(size)
     imgs = []
-    for tracer, bounces in ((0, 8), (1, 8), (2, 8), (3, 8), (4, 8)):
+    for tracer, bounces in ((0, 8), (1, 8), (2, 8), (3, 8), (4, 8), (5, 8)):
         with Context(128, 80, max_bounces=bounces, noise=noise, tracer=tracer) as ctx:
             ctx.recreate_octree(pos, mrgb)
             ctx.camera = Camera(*cam)
