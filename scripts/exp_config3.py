@@ -23,5 +23,5 @@ for view in ("bench", "close"):
             px = W * H
             t, tm, dn = st.trace_ms / n, st.temporal_ms / n, st.denoise_ms / n
             print(f"{name} {view} r={radius}: trace {t*1e3:8.1f} us ({st.rays / n / (t * 1e-3) / 1e9:.2f} Gray/s, {st.rays / n / px:.2f} rays/px) | "
-                  f"temporal {tm*1e3:7.1f} us ({80 * px / (tm * 1e-3) / 1e9:7.0f} GB/s of 80 B/px) | denoise {dn*1e3:8.1f} us ({64 * px / (dn * 1e-3) / 1e9:7.0f} GB/s of 64 B/px) | "
-                  f"frame {(t + tm + dn):.3f} ms")
+                  f"temporal {tm*1e3:7.1f} us ({80 * px / (tm * 1e-3) / 1e9:7.0f} GB/s of 80 B/px) | denoise {dn*1e3:8.1f} us" + (f" ({64 * px / (dn * 1e-3) / 1e9:7.0f} GB/s of 64 B/px) | " if dn > 0 else " (fused into temporal) | ")
+                  + f"frame {(t + tm + dn):.3f} ms")
