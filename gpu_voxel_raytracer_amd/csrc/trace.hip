@@ -101,8 +101,8 @@ __global__ __launch_bounds__(kBlock, VXRT_TRACE_WAVES) void trace_kernel(const T
                     blend = splat3(1.0f);
                     float sun_power = vx_pow(vx_max(0.0f, dot3(d, ld3(a.neg_sun_dir_n))), a.sun_exponent);
                     sample = sample + (sky + sun_color * sun_power) * blend;
-                    fo.nd[pix] = make_float4(kAlmostInfinity, kAlmostInfinity, kAlmostInfinity, -1.0f);
-                    fo.albedo[pix] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(0xffffff));
+                    store_out(fo.nd + pix, make_float4(kAlmostInfinity, kAlmostInfinity, kAlmostInfinity, -1.0f));
+                    store_out(fo.albedo + pix, make_float4(1.0f, 1.0f, 1.0f, __int_as_float(0xffffff)));
                 } else {
                     sample = sample + sky * blend;
                 }
@@ -126,9 +126,9 @@ __global__ __launch_bounds__(kBlock, VXRT_TRACE_WAVES) void trace_kernel(const T
             const f3 color = bounce == 0 ? splat3(1.0f) : node_color(hit.node);
             const f3 emit = node_emittance(hit.node, a.emit_strength);
             if (bounce == 0) {  // first-hit G-buffer                           voxels.comp:320-324,392-396
-                fo.nd[pix] = make_float4(n.x, n.y, n.z, hit.time);
+                store_out(fo.nd + pix, make_float4(n.x, n.y, n.z, hit.time));
                 f3 alb = (hit.node & kEmitBit) == 0 ? node_color(hit.node) : splat3(1.0f);
-                fo.albedo[pix] = make_float4(alb.x, alb.y, alb.z, __int_as_float(hit.node));
+                store_out(fo.albedo + pix, make_float4(alb.x, alb.y, alb.z, __int_as_float(hit.node)));
             }
 
             if (rng.next() < a.specularity) {  // specular                     voxels.comp:326-334
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kBlock, VXRT_TRACE_WAVES) void trace_kernel(const T
 
         if (!to_tail) {
             f3 out = sample / float(ambient_rays);  // voxels.comp:391
-            fo.color[pix] = make_float4(out.x, out.y, out.z, 1.0f);
+            store_out(fo.color + pix, make_float4(out.x, out.y, out.z, 1.0f));
         }
     }
     if (a.tail_from > 0) {

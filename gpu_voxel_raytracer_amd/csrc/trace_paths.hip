@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kBlock, VXRT_PATH_WAVES) void path_kernel(const Tra
         // 4. finish paths: voxels.comp:391
         if (finish) {
             const f3 outc = sample / float(ambient_rays);
-            a.out[pix >> kPixBits].color[pix & ((1u << kPixBits) - 1u)] = make_float4(outc.x, outc.y, outc.z, 1.0f);
+            store_out(a.out[pix >> kPixBits].color + (pix & ((1u << kPixBits) - 1u)), make_float4(outc.x, outc.y, outc.z, 1.0f));
             phase = kIdle;
         }
         // 5. start the next ray: the sun ray of a fresh hit, else the bounce ray

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kBlock, VXRT_BOUNCE_WAVES) void bounce_kernel(const
                 }
                 if (finished) {
                     f3 outc = sample / float(ambient_rays);                                   // voxels.comp:391
-                    a.out[rec.pix >> kPixBits].color[rec.pix & ((1u << kPixBits) - 1u)] = make_float4(outc.x, outc.y, outc.z, 1.0f);
+                    store_out(a.out[rec.pix >> kPixBits].color + (rec.pix & ((1u << kPixBits) - 1u)), make_float4(outc.x, outc.y, outc.z, 1.0f));
                     break;
                 }
                 if (bounce == last_bounce) {
