@@ -53,7 +53,7 @@ def measured_traffic(frames_per_launch):
         return None
 
 
-def cpu_baseline(pos, mrgb, cam, target_seconds=12.0):
+def cpu_baseline(pos, mrgb, cam, target_seconds=float(os.environ.get("VXRT_BENCH_CPU_SECONDS", "12"))):
     """The CPU oracle (restatement of shaders/voxels.comp, oracle/oshaders.cpp) timed on this host's cores on
     whole frames of the same workload: a reported baseline, not the target."""
     from oracle import oracle as O

@@ -274,3 +274,27 @@ def test_cpp_host_driver_matches_python_host(H, scenes, tmp_path):
     assert open(ppm, "rb").read(len(header)) == header and os.path.getsize(ppm) == len(header) + w * h * 3
     bad = subprocess.run([tool, "/nonexistent.vox", "64", "64", "1", "3", "0", ppm], capture_output=True, text=True)
     assert bad.returncode == 1 and "cannot open" in bad.stderr
+
+
+def test_bench_contract_line():
+    """bench.py's one JSON line (the driver's contract): metric, value, config.workload, roofline and cpu_baseline objects."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "48", "--warmup", "8"], capture_output=True, text=True,
+                         timeout=600, env={**os.environ, "VXRT_BENCH_CPU_SECONDS": "2"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["metric"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 48 and d["warmup"] == 8 and d["vs_baseline"] is None
+    assert d["value"] > 1000.0 and abs(d["value"] * d["ms_per_step"] * 1e3 - d["config"]["rays_per_frame"]) < 0.01 * d["config"]["rays_per_frame"]
+    assert "menger" in d["config"]["workload"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mrays/s" and "frames" in c["sample"]
