@@ -89,6 +89,10 @@ struct TemporalArgs {
     float inv[12];  // affine inverse of the old camera matrix (temporal.comp:75-82), rows + translation
     float sample_blending, maximum_blending, blending_distance_cutoff;
     int has_history;
+    // multi-rank: the denoise halo imported for the previous frame holds the neighbours' rows of exactly this history
+    // (accumulated colour and normal/depth, `halo_radius` rows beyond each band edge); null: such rows are a disocclusion
+    const float4* halo;
+    int halo_radius;
     // fused denoise for radius 0 (the reference's default): out = mix(c, albedo * c, albedo_factor) of the blended colour
     const float4* albedo;   // null: no fusion
     float4* denoised;

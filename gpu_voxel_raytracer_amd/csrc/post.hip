@@ -35,20 +35,42 @@ __device__ __forceinline__ int frame_row(const BandMap& b, int lrow) {
     return (lband * b.nranks + b.rank) * b.band_rows + (lrow - lband * b.band_rows);
 }
 
+// One image of the temporal history as this rank can see it: its own rows, plus — when the denoise halo of the previous
+// frame is still there — `r` rows beyond each of its band edges (layout of DenoiseArgs::halo: [(local band, side)][row][image][x],
+// images 0 = accumulated colour, 1 = normal/depth).
+struct HistoryRows {
+    const float4* img;
+    const float4* halo;
+    int image, r;
+};
+// frame row y of the history, or null when this rank cannot see it
+__device__ __forceinline__ const float4* history_row(const BandMap& b, const HistoryRows& hs, int y) {
+    const int l = local_row(b, y);
+    if (l >= 0) return hs.img + size_t(l) * b.width;
+    if (hs.halo == nullptr) return nullptr;
+    const int band = y / b.band_rows, off = y - band * b.band_rows;
+    if (band >= 1 && (band - 1) % b.nranks == b.rank && off < hs.r)               // just below one of this rank's bands
+        return hs.halo + (size_t((((band - 1) / b.nranks) * 2 + 1) * hs.r + off) * 3 + hs.image) * b.width;
+    if ((band + 1) % b.nranks == b.rank && off >= b.band_rows - hs.r)             // just above one
+        return hs.halo + (size_t((((band + 1) / b.nranks) * 2 + 0) * hs.r + (off - (b.band_rows - hs.r))) * 3 + hs.image) * b.width;
+    return nullptr;
+}
+
 // texture() through the reference's Linear / ClampToEdge sampler (src/context.rs:980-989): bilinear,
-// weights quantised to 8 fractional bits (oracle U4).  A row another rank owns makes the lookup fail.
-__device__ __forceinline__ bool sample_bilinear(const float4* img, const BandMap& b, float u, float v, float4& out) {
+// weights quantised to 8 fractional bits (oracle U4).  A row this rank cannot see makes the lookup fail.
+__device__ __forceinline__ bool sample_bilinear(const HistoryRows& hs, const BandMap& b, float u, float v, float4& out) {
     float fx = u * float(b.width) - 0.5f, fy = v * float(b.height) - 0.5f;
     float x0f = vx_floor(fx), y0f = vx_floor(fy);
     float ax = vx_floor((fx - x0f) * 256.0f + 0.5f) / 256.0f, ay = vx_floor((fy - y0f) * 256.0f + 0.5f) / 256.0f;
     int x0 = min(max(vx_f2i(x0f), -2), b.width), y0 = min(max(vx_f2i(y0f), -2), b.height);
     int xa = min(max(x0, 0), b.width - 1), xb = min(max(x0 + 1, 0), b.width - 1);
     int ya = min(max(y0, 0), b.height - 1), yb = min(max(y0 + 1, 0), b.height - 1);
-    // a texel whose quantised weight is 0 is not read: only rows with a non-zero weight must be local
-    int la = ay == 1.0f ? 0 : local_row(b, ya), lb = ay == 0.0f ? 0 : local_row(b, yb);
-    if (la < 0 || lb < 0) return false;
-    float4 t00 = img[size_t(la) * b.width + xa], t10 = img[size_t(la) * b.width + xb];
-    float4 t01 = img[size_t(lb) * b.width + xa], t11 = img[size_t(lb) * b.width + xb];
+    // a texel whose quantised weight is 0 is not read: only rows with a non-zero weight must be visible
+    const float4* ra = ay == 1.0f ? hs.img : history_row(b, hs, ya);
+    const float4* rb = ay == 0.0f ? hs.img : history_row(b, hs, yb);
+    if (ra == nullptr || rb == nullptr) return false;
+    float4 t00 = ra[xa], t10 = ra[xb];
+    float4 t01 = rb[xa], t11 = rb[xb];
     const float* p00 = &t00.x; const float* p10 = &t10.x; const float* p01 = &t01.x; const float* p11 = &t11.x;
     float* o = &out.x;
     for (int k = 0; k < 4; k++) {
@@ -86,14 +108,15 @@ __global__ __launch_bounds__(256) void temporal_kernel(const TemporalArgs a) {
         float tv = (sy + -0.5f) * (-1.0f / float(a.band.height));
         if (0.0f <= tu && tu <= 1.0f && 0.0f <= tv && tv <= 1.0f) {
             float4 old_nd;
-            if (sample_bilinear(a.old_nd, a.band, tu, tv, old_nd)) {
+            const HistoryRows nd_rows{a.old_nd, a.halo, 1, a.halo_radius}, color_rows{a.old_color, a.halo, 0, a.halo_radius};
+            if (sample_bilinear(nd_rows, a.band, tu, tv, old_nd)) {
                 f3 old_dir = norm3((float(vx_f2i(sx + 0.5f)) * ld3(a.old_cam.r) + float(vx_f2i(sy - 0.5f)) * ld3(a.old_cam.u)) + ld3(a.old_cam.f));
                 f3 old_position = ld3(a.old_cam.o) + old_nd.w * old_dir;
                 f3 camera_dir = norm3(cam_o - world_pos);
                 float bias = vx_max(0.0f, dot3(camera_dir, normal));
                 float dist = len3(old_position - world_pos);
                 if (dist < (bias * a.blending_distance_cutoff) * depth) {
-                    sample_bilinear(a.old_color, a.band, tu, tv, old_color);
+                    sample_bilinear(color_rows, a.band, tu, tv, old_color);
                     blending = old_color.w;
                 }
             }

@@ -83,6 +83,9 @@ struct vxrt_ctx {
     float4* halo = nullptr;  // rows of neighbouring ranks for the denoise window
     uint32_t halo_radius = 0;
     bool halo_valid = false;
+    uint64_t temporal_count = 0;       // temporal stages run so far ...
+    uint64_t halo_epoch = ~0ull;       // ... and its value when the halo was last imported: equal -> the halo holds the
+                                       // neighbours' rows of the current temporal history
     int cur = 0;             // accum[cur] is written by the next temporal stage, accum[cur^1] is the history
     bool has_history = false;
     bool accum_is_sampled = true;  // the latest "accumulated" image is sampled_color (temporal never ran)
@@ -763,6 +766,10 @@ int post_stages(vxrt_ctx* c, uint32_t flags, bool timed) {
         a.cam = c->cam;
         a.old_cam = c->old_cam;
         a.has_history = (c->has_history && c->old_cam_valid && c->hist_slot >= 0) ? 1 : 0;
+        const bool apron = multi && a.has_history && c->halo != nullptr && c->halo_radius >= 1 && c->halo_epoch == c->temporal_count;
+        a.halo = apron ? c->halo : nullptr;
+        a.halo_radius = apron ? int(c->halo_radius) : 0;
+        c->temporal_count += 1;
         memset(a.inv, 0, sizeof a.inv);
         if (a.has_history) affine_inverse(c->old_cam, a.inv);
         a.sample_blending = c->temporal.sample_blending;
@@ -1037,6 +1044,7 @@ int vxrt_halo_import(vxrt_ctx* c, const void* dev_from_prev, const void* dev_fro
     }
     c->halo_radius = uint32_t(r);
     c->halo_valid = true;
+    c->halo_epoch = c->temporal_count;
     return VXRT_OK;
 }
 

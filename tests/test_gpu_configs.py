@@ -1,0 +1,87 @@
+"""GPU parity at the sizes BASELINE.json names for configs 3 and 4 (config 2 at full size: test_gpu_trace.py /
+test_gpu_stress.py; config 5's scene generator: test_gpu_procedural.py).
+
+config 3: vox/monu10.vox at 3840x2160, 8 bounces, temporal + denoise on — two whole frames of the three-stage pipeline against the
+          oracle, bit-exact (frames batched into one trace launch; the oracle needs the box's host threads: ~10 s).
+config 4: vox/castle.vox at 3840x2160 dealt to 8 ranks in interleaved 16-row bands with the denoise halo exchange — the stitched
+          frame must equal the single-context frame bit for bit (the 8 contexts share this box's one GPU; the buffers RCCL would
+          carry are handed over directly, as in test_gpu_bands.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal
+from test_gpu_bands import hip
+from test_gpu_pipeline import OraclePipeline
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config3_full_size_pipeline(O, H, scenes, noise):
+    from gpu_voxel_raytracer_amd import ALL, Camera, Context
+    w, h, bounces, radius, frames = 3840, 2160, 8, 2, 2
+    ref = OraclePipeline(O, scenes, noise, "monu10", w, h, bounces, radius)
+    cam = scenes.bench_camera(ref.size)
+    pos, mrgb, _ = scenes.load_scene("monu10")
+    want = [ref.render(cam) for _ in range(frames)]
+    with Context(w, h, max_bounces=bounces, noise=noise, frames_per_launch=frames) as ctx:
+        ctx.recreate_octree(pos, mrgb)
+        ctx.camera = Camera(*cam)
+        ctx.denoise_uniforms.radius = radius
+        ctx.render_frames(ALL, frames)
+        for img, wimg, label in zip(range(5), want[-1], ("colour", "nd", "albedo", "accum", "denoised")):
+            assert_bits_equal(ctx.read(img), wimg, f"config 3 {label}")
+        got = ctx.read(4)
+    # BASELINE's stated tolerance as well (trivially met by equality, kept as the written bar)
+    assert np.sqrt(np.mean((got[..., :3].astype(np.float64) - want[-1][4][..., :3]) ** 2)) <= 1e-3
+
+
+def test_config4_eight_ranks_with_halo_at_4k(H, scenes, noise):
+    from gpu_voxel_raytracer_amd import ALL, DENOISE, TEMPORAL, TRACE, Camera, Context
+    w, h, bounces, radius, nranks = 3840, 2160, 4, 8, 8
+    pos, mrgb, size = scenes.load_scene("castle")
+    cam = Camera(*scenes.close_camera(size))
+    rt = hip()
+
+    def setup(ctx):
+        ctx.recreate_octree(pos, mrgb)
+        ctx.camera = cam
+        ctx.denoise_uniforms.radius = radius
+
+    with Context(w, h, max_bounces=bounces, noise=noise) as single:
+        setup(single)
+        ctxs = [Context(w, h, max_bounces=bounces, noise=noise, rank=r, nranks=nranks, band_rows=16) for r in range(nranks)]
+        try:
+            for c in ctxs:
+                setup(c)
+            rows = [c.local_rows() for c in ctxs]
+            for frame in range(2):
+                single.render(ALL)
+                for c in ctxs:
+                    c.render(TRACE | TEMPORAL)
+                nbytes = ctxs[0].halo_bytes()
+                bufs = {}
+                for r, c in enumerate(ctxs):
+                    p, n = C.c_void_p(), C.c_void_p()
+                    assert rt.hipMalloc(C.byref(p), nbytes) == 0 and rt.hipMalloc(C.byref(n), nbytes) == 0
+                    c.halo_export(p.value, n.value)
+                    bufs[r] = (p, n)
+                for r, c in enumerate(ctxs):
+                    c.halo_import(bufs[(r - 1) % nranks][1].value, bufs[(r + 1) % nranks][0].value)
+                    c.render_stage(DENOISE)
+                for c in ctxs:
+                    c.sync()
+                for p, n in bufs.values():
+                    rt.hipFree(p); rt.hipFree(n)
+            for img in (0, 3, 4):
+                want = single.read(img)
+                got = np.zeros_like(want)
+                for c, rr in zip(ctxs, rows):
+                    got[rr] = c.read(img)
+                assert_bits_equal(got, want, f"config 4 image {img}, 8 ranks at 4K")
+            assert sum(c.stats().rays for c in ctxs) == single.stats().rays
+            assert max(len(r) for r in rows) - min(len(r) for r in rows) <= 16
+        finally:
+            for c in ctxs:
+                c.close()
