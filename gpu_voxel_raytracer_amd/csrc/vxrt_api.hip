@@ -118,6 +118,10 @@ struct vxrt_ctx {
     // 0 = monolithic trace_kernel (all bounces in one launch; default), 2 = wavefront launches per path segment,
     // 3 = ray queues: shade / trace launches with per-lane ray refill
     int trace_variant = 0;
+    // tracer 0 (auto): scenes that do not fit the 256 MB Infinity Cache use the all-in-one kernel — compacting paths trades
+    // the locality of a tile's rays for lane utilisation, which loses once SVO gathers go to HBM (config 5, 5.6 GiB:
+    // 2.56 vs 3.39 ms per 4K frame)
+    bool auto_tracer = false;
     int shade_blocks = 1024;
     unsigned rays_per_wave = 256;  // ray-queue tracer: fewest rays a trace wave takes (more = better lane refill, fewer waves)
     // longest-tile-first scheduling of the monolithic kernel: cost of every 16x16 tile in the last frame -> order
@@ -457,6 +461,7 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) {
     // can have a second hit, with one more compaction at path segment 3 from 6 bounces on.
     if (cfg->tracer > 5) { set_error("tracer must be 0..5"); return fail(VXRT_E_INVALID); }
     c->trace_variant = cfg->tracer == 0 ? 4 : (cfg->tracer == 1 ? 0 : int(cfg->tracer));
+    c->auto_tracer = cfg->tracer == 0 && getenv("VXRT_TRACE_VARIANT") == nullptr;
     c->tail_split = cfg->max_bounces >= 6 ? 0x8u : 0u;
     if (const char* v = getenv("VXRT_TRACE_VARIANT")) c->trace_variant = atoi(v);  // A/B override for benchmarks and tests
     if (c->trace_variant != 2 && c->trace_variant != 3 && c->trace_variant != 4 && c->trace_variant != 5) c->trace_variant = 0;
@@ -687,8 +692,10 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* first_old
         a.tail = PathQueue{nullptr, nullptr, 0};
         a.tail_zero = nullptr;
         a.tail_from = 0;
-        if (c->trace_variant == 0 || c->trace_variant >= 4) {
-            if (c->trace_variant >= 4) {
+        const size_t scene_bytes = c->svo_count * sizeof(SvoRecord) + c->leaf_count * sizeof(int32_t);
+        const int variant = (c->auto_tracer && scene_bytes > (size_t(256) << 20)) ? 0 : c->trace_variant;
+        if (variant == 0 || variant >= 4) {
+            if (variant >= 4) {
                 // count sets rotate as in launch_trace_wavefront: launch J reads set J%3, writes (J+1)%3, clears (J+2)%3
                 vxrt_ctx::StreamQueues& sq = c->queues[lane];
                 unsigned* sets[3] = {sq.counts3, sq.counts3 + 64 * 16, sq.counts3 + 2 * 64 * 16};
