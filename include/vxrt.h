@@ -105,7 +105,8 @@ typedef struct vxrt_config {
                                  paths compacted in between), 3 ray queues (shade / trace launches, lanes refilled
                                  ray by ray), 4 monolithic head + compacted tail (the monolithic kernel follows a
                                  path up to its second hit; the paths still alive there — about a third of a
-                                 geometry tile's lanes — are queued and finished by a dense launch).          */
+                                 geometry tile's lanes — are queued and finished by a dense launch), 5 as 4 with
+                                 a tail whose lanes are refilled path by path (slower; kept for comparison).  */
     uint32_t frames_per_launch;/* 0/1: one trace launch per frame.  B = 2..16: vxrt_render_frames (parameters at rest)
                                  traces up to B consecutive frames with ONE launch of the tracer (tracers 1 and 4;
                                  B ring slots, frame numbers n+1..n+B, longest tile first across the whole batch);
