@@ -8,6 +8,8 @@
 #include <cstring>
 #include <fstream>
 #include <iterator>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -33,6 +35,12 @@ int hip_fail(hipError_t e, const char* what) {
     set_error(std::string(what) + ": " + hipGetErrorString(e));
     return VXRT_E_DEVICE;
 }
+// Nothing may unwind across the C boundary: every int-returning entry point is a function-try-block ending in this.
+#define VXRT_CATCH                                                                                                   \
+    catch (const std::bad_alloc&) { set_error("out of host memory"); return VXRT_E_INVALID; }                        \
+    catch (const std::exception& e) { set_error(std::string("internal error: ") + e.what()); return VXRT_E_INVALID; } \
+    catch (...) { set_error("internal error"); return VXRT_E_INVALID; }
+
 #define HIP_TRY(expr)                                   \
     do {                                                \
         hipError_t e_ = (expr);                         \
@@ -428,7 +436,7 @@ void vxrt_default_uniforms(vxrt_uniforms* u) {
 void vxrt_default_temporal(vxrt_temporal* t) { t->sample_blending = 0.5f; t->maximum_blending = 0.98f; t->blending_distance_cutoff = 1e-2f; }
 void vxrt_default_denoise(vxrt_denoise* d) { d->radius = 0; d->sigma_distance = 2.0f; d->sigma_range = 1.5f; d->albedo_factor = 1.0f; }
 
-int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) {
+int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) try {
     if (!cfg || !out) { set_error("null argument"); return VXRT_E_INVALID; }
     *out = nullptr;
     if (cfg->width == 0 || cfg->height == 0 || cfg->width > 65536 || cfg->height > 65536) { set_error("bad frame size"); return VXRT_E_INVALID; }
@@ -500,9 +508,9 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) {
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(hip_fail(hipGetLastError(), "sync"));
     *out = c;
     return VXRT_OK;
-}
+} VXRT_CATCH
 
-int vxrt_destroy(vxrt_ctx* c) {
+int vxrt_destroy(vxrt_ctx* c) try {
     if (!c) return VXRT_OK;
     (void)hipSetDevice(c->cfg.device);
     for (hipStream_t t : c->trace_streams) if (t) (void)hipStreamSynchronize(t);
@@ -518,9 +526,9 @@ int vxrt_destroy(vxrt_ctx* c) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return VXRT_OK;
-}
+} VXRT_CATCH
 
-int vxrt_resize(vxrt_ctx* c, uint32_t width, uint32_t height) {
+int vxrt_resize(vxrt_ctx* c, uint32_t width, uint32_t height) try {
     if (!valid_ctx(c)) return VXRT_E_INVALID;
     if (width == 0 || height == 0 || width > 65536 || height > 65536) { set_error("bad frame size"); return VXRT_E_INVALID; }
     HIP_TRY(hipSetDevice(c->cfg.device));
@@ -529,9 +537,9 @@ int vxrt_resize(vxrt_ctx* c, uint32_t width, uint32_t height) {
     c->cfg.height = height;
     set_band(c, width, height);
     return alloc_images(c);  // new zeroed images: the history is gone (src/context.rs:1440-1448)
-}
+} VXRT_CATCH
 
-int vxrt_set_voxels(vxrt_ctx* c, const int16_t (*pos)[3], const uint8_t (*mrgb)[4], size_t n) {
+int vxrt_set_voxels(vxrt_ctx* c, const int16_t (*pos)[3], const uint8_t (*mrgb)[4], size_t n) try {
     if (!valid_ctx(c)) return VXRT_E_INVALID;
     if (n != 0 && (!pos || !mrgb)) { set_error("null voxel arrays"); return VXRT_E_INVALID; }
     std::vector<Voxel> v(n);
@@ -540,65 +548,65 @@ int vxrt_set_voxels(vxrt_ctx* c, const int16_t (*pos)[3], const uint8_t (*mrgb)[
         v[i].m = mrgb[i][0]; v[i].r = mrgb[i][1]; v[i].g = mrgb[i][2]; v[i].b = mrgb[i][3];
     }
     return upload_scene(c, v.data(), n);
-}
+} VXRT_CATCH
 
-int vxrt_load_vox_memory(vxrt_ctx* c, const uint8_t* bytes, size_t len) {
+int vxrt_load_vox_memory(vxrt_ctx* c, const uint8_t* bytes, size_t len) try {
     if (!valid_ctx(c)) return VXRT_E_INVALID;
     if (!bytes) { set_error("null bytes"); return VXRT_E_INVALID; }
     VoxScene scene;
     if (int rc = decode_vox(bytes, len, &scene)) return rc;
     return upload_scene(c, scene.voxels.data(), scene.voxels.size());
-}
+} VXRT_CATCH
 
-int vxrt_load_vox(vxrt_ctx* c, const char* path) {
+int vxrt_load_vox(vxrt_ctx* c, const char* path) try {
     if (!valid_ctx(c)) return VXRT_E_INVALID;
     if (!path) { set_error("null path"); return VXRT_E_INVALID; }
     std::ifstream f(path, std::ios::binary);
     if (!f) { set_error(std::string("failed to read file: ") + path); return VXRT_E_IO; }
     std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
     return vxrt_load_vox_memory(c, bytes.data(), bytes.size());
-}
+} VXRT_CATCH
 
-int vxrt_set_camera(vxrt_ctx* c, const float position[3], const float direction[3], float fov) {
+int vxrt_set_camera(vxrt_ctx* c, const float position[3], const float direction[3], float fov) try {
     if (!valid_ctx(c)) return VXRT_E_INVALID;
     if (!position || !direction) { set_error("null camera vectors"); return VXRT_E_INVALID; }
     memcpy(c->cam_pos, position, sizeof c->cam_pos);
     memcpy(c->cam_dir, direction, sizeof c->cam_dir);
     c->cam_fov = fov;
     return VXRT_OK;
-}
+} VXRT_CATCH
 
-int vxrt_set_scene_params(vxrt_ctx* c, const vxrt_uniforms* u) {
+int vxrt_set_scene_params(vxrt_ctx* c, const vxrt_uniforms* u) try {
     if (!valid_ctx(c) || !u) { set_error("null argument"); return VXRT_E_INVALID; }
     uint32_t frame = c->uniforms.frame_number;
     c->uniforms = *u;
     c->uniforms.frame_number = frame;  // owned by the library, like update_bindings (src/context.rs:2152)
     return VXRT_OK;
-}
-int vxrt_set_temporal(vxrt_ctx* c, const vxrt_temporal* t) {
+} VXRT_CATCH
+int vxrt_set_temporal(vxrt_ctx* c, const vxrt_temporal* t) try {
     if (!valid_ctx(c) || !t) { set_error("null argument"); return VXRT_E_INVALID; }
     c->temporal = *t;
     return VXRT_OK;
-}
-int vxrt_set_denoise(vxrt_ctx* c, const vxrt_denoise* d) {
+} VXRT_CATCH
+int vxrt_set_denoise(vxrt_ctx* c, const vxrt_denoise* d) try {
     if (!valid_ctx(c) || !d) { set_error("null argument"); return VXRT_E_INVALID; }
     if (d->radius > 8) { set_error("denoise radius must be 0..8"); return VXRT_E_INVALID; }
     c->denoise = *d;
     return VXRT_OK;
-}
+} VXRT_CATCH
 
-int vxrt_reset_history(vxrt_ctx* c) {
+int vxrt_reset_history(vxrt_ctx* c) try {
     if (!valid_ctx(c)) return VXRT_E_INVALID;
     c->has_history = false;
     c->old_cam_valid = false;
     return VXRT_OK;
-}
+} VXRT_CATCH
 
-int vxrt_set_frame_number(vxrt_ctx* c, uint32_t frame_number) {
+int vxrt_set_frame_number(vxrt_ctx* c, uint32_t frame_number) try {
     if (!valid_ctx(c)) return VXRT_E_INVALID;
     c->uniforms.frame_number = frame_number;
     return VXRT_OK;
-}
+} VXRT_CATCH
 
 namespace {
 
@@ -833,7 +841,7 @@ int post_stages(vxrt_ctx* c, uint32_t flags, bool timed) {
 
 }  // namespace
 
-int vxrt_render(vxrt_ctx* c, uint32_t flags) {
+int vxrt_render(vxrt_ctx* c, uint32_t flags) try {
     if (int rc = check_render(c, flags)) return rc;
     HIP_TRY(hipSetDevice(c->cfg.device));
     const bool timed = (flags & VXRT_TIMED) != 0;
@@ -845,11 +853,11 @@ int vxrt_render(vxrt_ctx* c, uint32_t flags) {
     if (int rc = post_stages(c, flags, timed)) return rc;
     if (flags & VXRT_TRACE) c->old_cam_valid = true;  // the next frame's "old" camera is this frame's
     return VXRT_OK;
-}
+} VXRT_CATCH
 
 // `count` frames with the parameters at rest.  With vxrt_config.frames_per_launch = B > 1 the trace stage of up to B
 // consecutive frames is one launch (see trace_frames); temporal / denoise then run per frame, in frame order.
-int vxrt_render_frames(vxrt_ctx* c, uint32_t flags, uint32_t count) {
+int vxrt_render_frames(vxrt_ctx* c, uint32_t flags, uint32_t count) try {
     if (int rc = check_render(c, flags)) return rc;
     HIP_TRY(hipSetDevice(c->cfg.device));
     const bool timed = (flags & VXRT_TIMED) != 0;
@@ -875,14 +883,14 @@ int vxrt_render_frames(vxrt_ctx* c, uint32_t flags, uint32_t count) {
         done += g;
     }
     return VXRT_OK;
-}
+} VXRT_CATCH
 
-int vxrt_sync(vxrt_ctx* c) {
+int vxrt_sync(vxrt_ctx* c) try {
     if (!valid_ctx(c)) return VXRT_E_INVALID;
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = sync_all(c)) return rc;
     return resolve_events(c);
-}
+} VXRT_CATCH
 
 static float4* image_ptr(vxrt_ctx* c, vxrt_image which) {
     switch (which) {
@@ -895,7 +903,7 @@ static float4* image_ptr(vxrt_ctx* c, vxrt_image which) {
     }
 }
 
-int vxrt_read(vxrt_ctx* c, vxrt_image which, float* dst, size_t bytes) {
+int vxrt_read(vxrt_ctx* c, vxrt_image which, float* dst, size_t bytes) try {
     if (!valid_ctx(c)) return VXRT_E_INVALID;
     float4* src = image_ptr(c, which);
     if (!src || !dst) { set_error("bad image or null destination"); return VXRT_E_INVALID; }
@@ -904,18 +912,18 @@ int vxrt_read(vxrt_ctx* c, vxrt_image which, float* dst, size_t bytes) {
     if (int rc = sync_all(c)) return rc;
     if (bytes) HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return VXRT_OK;
-}
+} VXRT_CATCH
 
-int vxrt_device_image(vxrt_ctx* c, vxrt_image which, void** device_ptr, size_t* bytes) {
+int vxrt_device_image(vxrt_ctx* c, vxrt_image which, void** device_ptr, size_t* bytes) try {
     if (!valid_ctx(c) || !device_ptr) { set_error("null argument"); return VXRT_E_INVALID; }
     float4* src = image_ptr(c, which);
     if (!src) { set_error("bad image"); return VXRT_E_INVALID; }
     *device_ptr = src;
     if (bytes) *bytes = image_bytes(c);
     return VXRT_OK;
-}
+} VXRT_CATCH
 
-int vxrt_local_rows(const vxrt_ctx* c, uint32_t* count, uint32_t* rows) {
+int vxrt_local_rows(const vxrt_ctx* c, uint32_t* count, uint32_t* rows) try {
     if (!valid_ctx(c) || !count) { set_error("null argument"); return VXRT_E_INVALID; }
     const BandMap& b = c->band;
     uint32_t n = 0;
@@ -926,9 +934,9 @@ int vxrt_local_rows(const vxrt_ctx* c, uint32_t* count, uint32_t* rows) {
         }
     *count = n;
     return VXRT_OK;
-}
+} VXRT_CATCH
 
-int vxrt_get_stats(vxrt_ctx* c, vxrt_stats* out) {
+int vxrt_get_stats(vxrt_ctx* c, vxrt_stats* out) try {
     if (!valid_ctx(c) || !out) { set_error("null argument"); return VXRT_E_INVALID; }
     if (int rc = vxrt_sync(c)) return rc;
     std::vector<unsigned long long> slots(size_t(kRaySlots) * 8);
@@ -950,9 +958,9 @@ int vxrt_get_stats(vxrt_ctx* c, vxrt_stats* out) {
     out->octree_depth = c->depth;
     out->octree_nodes = c->svo_count;
     return VXRT_OK;
-}
+} VXRT_CATCH
 
-int vxrt_reset_stats(vxrt_ctx* c) {
+int vxrt_reset_stats(vxrt_ctx* c) try {
     if (!valid_ctx(c)) return VXRT_E_INVALID;
     if (int rc = vxrt_sync(c)) return rc;
     // on the context's own stream and waited for: a null-stream hipMemset is neither ordered against the
@@ -962,10 +970,10 @@ int vxrt_reset_stats(vxrt_ctx* c) {
     c->frames = c->pixels = c->timed_frames = c->timed_launches = 0;
     c->ms[0] = c->ms[1] = c->ms[2] = 0.0;
     return VXRT_OK;
-}
+} VXRT_CATCH
 
 // Diagnostics: shader-clock duration of every 16x16 tile in the last traced frame (monolithic kernel).
-int vxrt_debug_tile_costs(vxrt_ctx* c, uint32_t* out, size_t n) {
+int vxrt_debug_tile_costs(vxrt_ctx* c, uint32_t* out, size_t n) try {
     if (!valid_ctx(c) || !out) { set_error("null argument"); return VXRT_E_INVALID; }
     const size_t tiles = size_t((c->band.width + 15) / 16) * size_t((c->band.local_rows + 15) / 16);
     if (n != tiles || c->schedules.empty()) { set_error("tile count mismatch"); return VXRT_E_INVALID; }
@@ -973,7 +981,7 @@ int vxrt_debug_tile_costs(vxrt_ctx* c, uint32_t* out, size_t n) {
     if (int rc = sync_all(c)) return rc;
     HIP_TRY(hipMemcpy(out, c->schedules[size_t(c->last_schedule)].last_cost, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return VXRT_OK;
-}
+} VXRT_CATCH
 
 // ---- denoise halo ---------------------------------------------------------------------------------
 // Message to a neighbour: for each of ITS local bands j (up to max_bands), r rows x 3 images x width
@@ -983,13 +991,13 @@ static int max_bands(const BandMap& b) {
     return (bands + b.nranks - 1) / b.nranks;
 }
 
-int vxrt_halo_bytes(vxrt_ctx* c, size_t* bytes) {
+int vxrt_halo_bytes(vxrt_ctx* c, size_t* bytes) try {
     if (!valid_ctx(c) || !bytes) { set_error("null argument"); return VXRT_E_INVALID; }
     *bytes = size_t(max_bands(c->band)) * c->denoise.radius * 3 * c->band.width * sizeof(float4);
     return VXRT_OK;
-}
+} VXRT_CATCH
 
-int vxrt_halo_export(vxrt_ctx* c, void* dev_to_prev, void* dev_to_next) {
+int vxrt_halo_export(vxrt_ctx* c, void* dev_to_prev, void* dev_to_next) try {
     if (!valid_ctx(c)) return VXRT_E_INVALID;
     const BandMap& b = c->band;
     const int r = int(c->denoise.radius);
@@ -1026,9 +1034,9 @@ int vxrt_halo_export(vxrt_ctx* c, void* dev_to_prev, void* dev_to_next) {
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return VXRT_OK;
-}
+} VXRT_CATCH
 
-int vxrt_halo_import(vxrt_ctx* c, const void* dev_from_prev, const void* dev_from_next) {
+int vxrt_halo_import(vxrt_ctx* c, const void* dev_from_prev, const void* dev_from_next) try {
     if (!valid_ctx(c)) return VXRT_E_INVALID;
     const BandMap& b = c->band;
     const int r = int(c->denoise.radius);
@@ -1053,11 +1061,11 @@ int vxrt_halo_import(vxrt_ctx* c, const void* dev_from_prev, const void* dev_fro
     c->halo_valid = true;
     c->halo_epoch = c->temporal_count;
     return VXRT_OK;
-}
+} VXRT_CATCH
 
 // ---- host-only helpers -------------------------------------------------------------------------------
 int vxrt_vox_to_voxels(const uint8_t* bytes, size_t len, int16_t (*pos)[3], uint8_t (*mrgb)[4], size_t cap, size_t* n,
-                       uint32_t size_xyz[3]) {
+                       uint32_t size_xyz[3]) try {
     if (!bytes || !n) { set_error("null argument"); return VXRT_E_INVALID; }
     VoxScene scene;
     if (int rc = decode_vox(bytes, len, &scene)) return rc;
@@ -1069,10 +1077,10 @@ int vxrt_vox_to_voxels(const uint8_t* bytes, size_t len, int16_t (*pos)[3], uint
         if (mrgb) { mrgb[i][0] = v.m; mrgb[i][1] = v.r; mrgb[i][2] = v.g; mrgb[i][3] = v.b; }
     }
     return VXRT_OK;
-}
+} VXRT_CATCH
 
 int vxrt_build_octree(const int16_t (*pos)[3], const uint8_t (*mrgb)[4], size_t n, int32_t* words, size_t cap, size_t* n_words,
-                      uint32_t* depth) {
+                      uint32_t* depth) try {
     if (!n_words || (n != 0 && (!pos || !mrgb))) { set_error("null argument"); return VXRT_E_INVALID; }
     std::vector<Voxel> v(n);
     for (size_t i = 0; i < n; i++) {
@@ -1085,10 +1093,10 @@ int vxrt_build_octree(const int16_t (*pos)[3], const uint8_t (*mrgb)[4], size_t 
     if (depth) *depth = tree.depth;
     if (words && cap >= tree.words.size()) memcpy(words, tree.words.data(), tree.words.size() * sizeof(int32_t));
     return VXRT_OK;
-}
+} VXRT_CATCH
 
 int vxrt_camera_axis_scaled(const float position[3], const float direction[3], float fov, uint32_t width, uint32_t height,
-                            float right[3], float up[3], float forward_ray[3]) {
+                            float right[3], float up[3], float forward_ray[3]) try {
     (void)position;
     if (!direction || !right || !up || !forward_ray) { set_error("null argument"); return VXRT_E_INVALID; }
     CameraBasis b = camera_axis_scaled(direction, fov, width, height);
@@ -1096,16 +1104,16 @@ int vxrt_camera_axis_scaled(const float position[3], const float direction[3], f
     memcpy(up, b.up, sizeof b.up);
     memcpy(forward_ray, b.forward_ray, sizeof b.forward_ray);
     return VXRT_OK;
-}
+} VXRT_CATCH
 
-int vxrt_noise_table(uint32_t seed, float* out, size_t n) {
+int vxrt_noise_table(uint32_t seed, float* out, size_t n) try {
     if (!out) { set_error("null argument"); return VXRT_E_INVALID; }
     for (size_t i = 0; i < n; i++) out[i] = noise_value(seed, uint32_t(i));
     return VXRT_OK;
-}
+} VXRT_CATCH
 
 int vxrt_menger_voxels_ex(uint32_t level, uint32_t clip, const uint8_t mrgb[4], uint32_t emissive_period, int16_t (*pos)[3],
-                          uint8_t (*out_mrgb)[4], size_t cap, size_t* n) {
+                          uint8_t (*out_mrgb)[4], size_t cap, size_t* n) try {
     if (!n || !mrgb || level > 9) { set_error("bad argument"); return VXRT_E_INVALID; }
     uint32_t side = 1;
     for (uint32_t l = 0; l < level; l++) side *= 3;
@@ -1128,13 +1136,13 @@ int vxrt_menger_voxels_ex(uint32_t level, uint32_t clip, const uint8_t mrgb[4], 
                 }
     *n = count;
     return VXRT_OK;
-}
+} VXRT_CATCH
 
-int vxrt_menger_voxels(uint32_t level, const uint8_t mrgb[4], int16_t (*pos)[3], uint8_t (*out_mrgb)[4], size_t cap, size_t* n) {
+int vxrt_menger_voxels(uint32_t level, const uint8_t mrgb[4], int16_t (*pos)[3], uint8_t (*out_mrgb)[4], size_t cap, size_t* n) try {
     return vxrt_menger_voxels_ex(level, 0, mrgb, 0, pos, out_mrgb, cap, n);
-}
+} VXRT_CATCH
 
-int vxrt_set_menger(vxrt_ctx* c, uint32_t level, uint32_t clip, const uint8_t mrgb[4], uint32_t emissive_period) {
+int vxrt_set_menger(vxrt_ctx* c, uint32_t level, uint32_t clip, const uint8_t mrgb[4], uint32_t emissive_period) try {
     if (!valid_ctx(c)) return VXRT_E_INVALID;
     if (!mrgb) { set_error("null colour"); return VXRT_E_INVALID; }
     uint32_t side = 1;
@@ -1145,10 +1153,10 @@ int vxrt_set_menger(vxrt_ctx* c, uint32_t level, uint32_t clip, const uint8_t mr
     uint32_t depth = 0;
     if (int rc = build_menger_svo(level, clip, mrgb, emissive_period, &recs, &leaves, &depth)) return rc;
     return upload_svo(c, recs, leaves, depth);
-}
+} VXRT_CATCH
 
 // ---- blue noise (include/vxrt_bluenoise.h, csrc/noise.hip, csrc/noise_zip.cpp) ----------------------------------
-int vxrt_blue_noise(int32_t device, uint32_t seed, uint32_t size, uint32_t first_layer, uint32_t layers, float* out) {
+int vxrt_blue_noise(int32_t device, uint32_t seed, uint32_t size, uint32_t first_layer, uint32_t layers, float* out) try {
     if (!out || layers == 0) { set_error("null argument"); return VXRT_E_INVALID; }
     if (size < 16 || size > VXBN_MAX_SIZE || (size & (size - 1)) != 0) { set_error("blue-noise size must be a power of two in 16..128"); return VXRT_E_INVALID; }
     int ndev = 0;
@@ -1165,9 +1173,9 @@ int vxrt_blue_noise(int32_t device, uint32_t seed, uint32_t size, uint32_t first
     (void)hipFree(d);
     if (le != hipSuccess) return hip_fail(le, "blue noise");
     return VXRT_OK;
-}
+} VXRT_CATCH
 
-int vxrt_noise_zip_read(const char* path, float* out, size_t cap_floats, uint32_t* size, uint32_t* layers) {
+int vxrt_noise_zip_read(const char* path, float* out, size_t cap_floats, uint32_t* size, uint32_t* layers) try {
     if (!path || !size || !layers) { set_error("null argument"); return VXRT_E_INVALID; }
     std::vector<float> px;
     if (int rc = noise_zip_read(path, &px, size, layers)) return rc;
@@ -1176,24 +1184,24 @@ int vxrt_noise_zip_read(const char* path, float* out, size_t cap_floats, uint32_
         memcpy(out, px.data(), px.size() * sizeof(float));
     }
     return VXRT_OK;
-}
+} VXRT_CATCH
 
-int vxrt_noise_zip_write(const char* path, const float* table, uint32_t size, uint32_t layers) {
+int vxrt_noise_zip_write(const char* path, const float* table, uint32_t size, uint32_t layers) try {
     if (!path || !table) { set_error("null argument"); return VXRT_E_INVALID; }
     return noise_zip_write(path, table, size, layers);
-}
+} VXRT_CATCH
 
-int vxrt_set_noise(vxrt_ctx* c, const float* table) {
+int vxrt_set_noise(vxrt_ctx* c, const float* table) try {
     if (!c || !table) { set_error("null argument"); return VXRT_E_INVALID; }
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = vxrt_sync(c)) return rc;
     HIP_TRY(hipMemcpy(c->d_noise, table, kNoiseCount * sizeof(float), hipMemcpyHostToDevice));
     return VXRT_OK;
-}
+} VXRT_CATCH
 
 // ---- wider scene input (csrc/vox_scene.cpp) ------------------------------------------------------------------------
 int vxrt_vox_scene_to_voxels(const uint8_t* bytes, size_t len, uint32_t flags, int16_t (*pos)[3], uint8_t (*mrgb)[4], size_t cap,
-                             size_t* n, int32_t bounds_min[3], int32_t bounds_max[3]) {
+                             size_t* n, int32_t bounds_min[3], int32_t bounds_max[3]) try {
     if (!bytes || !n) { set_error("null argument"); return VXRT_E_INVALID; }
     if (flags & ~uint32_t(VXRT_VOX_ALL_MODELS | VXRT_VOX_LENIENT_MATERIALS | VXRT_VOX_REBASE)) { set_error("unknown flag"); return VXRT_E_INVALID; }
     VoxScene scene;
@@ -1210,9 +1218,9 @@ int vxrt_vox_scene_to_voxels(const uint8_t* bytes, size_t len, uint32_t flags, i
         if (mrgb) { mrgb[i][0] = v.m; mrgb[i][1] = v.r; mrgb[i][2] = v.g; mrgb[i][3] = v.b; }
     }
     return VXRT_OK;
-}
+} VXRT_CATCH
 
-int vxrt_default_scene_voxels(uint32_t seed, int16_t (*pos)[3], uint8_t (*mrgb)[4], size_t cap, size_t* n) {
+int vxrt_default_scene_voxels(uint32_t seed, int16_t (*pos)[3], uint8_t (*mrgb)[4], size_t cap, size_t* n) try {
     if (!n) { set_error("null argument"); return VXRT_E_INVALID; }
     std::vector<Voxel> voxels;
     default_scene(seed, &voxels);
@@ -1223,10 +1231,10 @@ int vxrt_default_scene_voxels(uint32_t seed, int16_t (*pos)[3], uint8_t (*mrgb)[
         if (mrgb) { mrgb[i][0] = v.m; mrgb[i][1] = v.r; mrgb[i][2] = v.g; mrgb[i][3] = v.b; }
     }
     return VXRT_OK;
-}
+} VXRT_CATCH
 
 // device-vs-host bit equality probe of include/vxrt_detmath.h (test hook; host arrays in and out)
-int vxrt_detmath_probe(int32_t device, int32_t fn, const float* x, const float* y, float* out, size_t n) {
+int vxrt_detmath_probe(int32_t device, int32_t fn, const float* x, const float* y, float* out, size_t n) try {
     if (!x || !y || !out) { set_error("null argument"); return VXRT_E_INVALID; }
     HIP_TRY(hipSetDevice(device));
     float *dx = nullptr, *dy = nullptr, *dout = nullptr;
@@ -1240,6 +1248,6 @@ int vxrt_detmath_probe(int32_t device, int32_t fn, const float* x, const float* 
     HIP_TRY(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
     (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
     return VXRT_OK;
-}
+} VXRT_CATCH
 
 }  // extern "C"

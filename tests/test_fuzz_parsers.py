@@ -1,0 +1,80 @@
+"""Robustness of the host-side decoders against damaged input (CPU only): mutated .vox files through both decoders and mutated
+blue-noise archives through the zip reader must come back with a status code — never crash, hang or over-read.  (The reference
+panics or returns anyhow errors on such input: src/vox.rs:262-283, src/context.rs:1042-1116.)"""
+import os
+import struct
+import zipfile
+
+import numpy as np
+import pytest
+
+from test_oracle_scene import make_vox
+from test_scene_extensions import ngrp, nshp, ntrn, raw_image, scene_file
+
+
+def mutations(data, rng, count):
+    data = bytearray(data)
+    for _ in range(count):
+        d = bytearray(data)
+        kind = rng.integers(5)
+        if kind == 0:      # flip bytes
+            for _ in range(int(rng.integers(1, 8))):
+                d[int(rng.integers(len(d)))] = int(rng.integers(256))
+        elif kind == 1:    # truncate
+            d = d[:int(rng.integers(len(d)))]
+        elif kind == 2:    # overwrite a u32 with an extreme value
+            at = int(rng.integers(max(len(d) - 4, 1)))
+            d[at:at + 4] = struct.pack("<I", int(rng.choice([0, 1, 0x7fffffff, 0x80000000, 0xffffffff, 0xfffffff0])))
+        elif kind == 3:    # duplicate a slice
+            a, b = sorted(int(v) for v in rng.integers(len(d), size=2))
+            d = d[:b] + d[a:b] + d[b:]
+        else:              # delete a slice
+            a, b = sorted(int(v) for v in rng.integers(len(d), size=2))
+            d = d[:a] + d[b:]
+        yield bytes(d)
+
+
+def test_vox_decoders_survive_damaged_files(H):
+    rng = np.random.default_rng(123)
+    model = ((5, 6, 7), [(x, (x * 3) % 6, (x * 5) % 7, 1 + x % 3) for x in range(5)])
+    graph = ntrn(0, 1) + ngrp(1, [2, 4]) + ntrn(2, 3, t=(3, -2, 1), r=4 | (1 << 4)) + nshp(3, [0]) + ntrn(4, 5, t=(-9, 0, 2)) + nshp(5, [1])
+    seeds = [make_vox(), make_vox(pack=2), scene_file([model, model], graph)]
+    ok = bad = 0
+    for seed in seeds:
+        for data in mutations(seed, rng, 400):
+            for decode in (lambda d: H.vox_to_voxels(d), lambda d: H.vox_scene_to_voxels(d, H.VOX_ALL_MODELS | H.VOX_LENIENT_MATERIALS),
+                           lambda d: H.vox_scene_to_voxels(d, H.VOX_ALL_MODELS | H.VOX_REBASE)):
+                try:
+                    pos, mrgb = decode(data)[:2]
+                    assert pos.shape[0] == mrgb.shape[0]
+                    ok += 1
+                except H.VxrtError as e:
+                    assert e.status < 0
+                    bad += 1
+    assert ok > 50 and bad > 500          # both outcomes occur; nothing else does
+
+
+def test_noise_zip_reader_survives_damaged_archives(H, tmp_path):
+    rng = np.random.default_rng(5)
+    table = rng.random((3, 16, 16), dtype=np.float32)
+    stored = str(tmp_path / "stored.zip")
+    H.save_blue_noise(stored, table, size=16)
+    deflated = str(tmp_path / "deflated.zip")
+    with zipfile.ZipFile(deflated, "w", zipfile.ZIP_DEFLATED) as z:
+        for i in range(3):
+            z.writestr("%d.raw" % i, raw_image(table[i]))
+    ok = bad = 0
+    for path in (stored, deflated):
+        seed = open(path, "rb").read()
+        for i, data in enumerate(mutations(seed, rng, 300)):
+            p = str(tmp_path / "m.zip")
+            with open(p, "wb") as f:
+                f.write(data)
+            try:
+                size, px = H.load_blue_noise(p)
+                assert px.size % (size * size) == 0
+                ok += 1
+            except H.VxrtError as e:
+                assert e.status in (H.E_NOISE, H.E_INVALID)
+                bad += 1
+    assert bad > 100 and ok + bad == 600
