@@ -138,6 +138,16 @@ hipError_t launch_bounces(const TraceArgs& a, const PathQueue queues[2], unsigne
                           unsigned split_mask, int from, hipStream_t s);
 // tracer 5: path_kernel (trace_paths.hip) follows the paths queued in `in` to their end, refilling each lane with a new path
 hipError_t launch_paths(const TraceArgs& a, const PathQueue& in, unsigned* zero, int first_bounce, int blocks, hipStream_t s);
+// "N samples per pixel" (SURVEY.md 8d): sum[p] (+)= frames[0][p] + ... + frames[count-1][p], added in that order;
+// first: sum starts from frames[0]; last: out[p] = sum[p] / float(total) is written as well.  One streaming pass.
+struct SppArgs {
+    const float4* frames[kMaxBatch];
+    float4* sum;
+    float4* out;
+    size_t pixels;
+    int count, first, last, total;
+};
+hipError_t launch_spp_accumulate(const SppArgs& a, hipStream_t s);
 hipError_t launch_temporal(const TemporalArgs& a, hipStream_t s);
 hipError_t launch_denoise(const DenoiseArgs& a, hipStream_t s);
 hipError_t launch_noise_fill(float* dst, uint32_t seed, size_t n, hipStream_t s);

@@ -252,6 +252,23 @@ __global__ __launch_bounds__(256) void denoise_kernel(const DenoiseArgs a) {
     a.output[pix] = make_float4(out.x, out.y, out.z, 1.0f);
 }
 
+// N samples per pixel = the mean of N consecutive trace frames, summed left to right in binary32 and divided once.
+__global__ __launch_bounds__(256) void spp_accumulate_kernel(const SppArgs a) {
+    const size_t p = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (p >= a.pixels) return;
+    float4 s = a.first ? a.frames[0][p] : a.sum[p];
+    for (int k = a.first ? 1 : 0; k < a.count; k++) {
+        const float4 c = a.frames[k][p];
+        s = make_float4(s.x + c.x, s.y + c.y, s.z + c.z, s.w + c.w);
+    }
+    if (a.last) {
+        const float n = float(a.total);
+        a.out[p] = make_float4(s.x / n, s.y / n, s.z / n, s.w / n);
+    } else {
+        a.sum[p] = s;
+    }
+}
+
 __global__ void detmath_probe_kernel(int fn, const float* x, const float* y, float* out, size_t n) {
     size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -293,6 +310,11 @@ hipError_t launch_denoise(const DenoiseArgs& a, hipStream_t s) {
     int tw = 16 + 2 * int(a.radius), taps = 2 * int(a.radius) + 1;
     size_t lds = size_t(tw) * tw * 32 + size_t(taps * taps + 3) / 4 * 16;
     hipLaunchKernelGGL(denoise_kernel, grid, dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_spp_accumulate(const SppArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(spp_accumulate_kernel, dim3(unsigned((a.pixels + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -88,6 +88,7 @@ struct vxrt_ctx {
     int hist_slot = -1;  // slot whose normal/depth pairs with accum[hist] as the temporal history
     float4* accum[2] = {nullptr, nullptr};
     float4* denoised = nullptr;
+    float4* spp_sum = nullptr;  // running sum of vxrt_render_spp (allocated on first use)
     float4* halo = nullptr;  // rows of neighbouring ranks for the denoise window
     uint32_t halo_radius = 0;
     bool halo_valid = false;
@@ -176,7 +177,7 @@ void free_images(vxrt_ctx* c) {
         if (sl.last_use) (void)hipEventDestroy(sl.last_use);
     }
     c->ring.clear();
-    float4** imgs[] = {&c->accum[0], &c->accum[1], &c->denoised, &c->halo};
+    float4** imgs[] = {&c->accum[0], &c->accum[1], &c->denoised, &c->halo, &c->spp_sum};
     for (float4** p : imgs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -882,6 +883,52 @@ int vxrt_render_frames(vxrt_ctx* c, uint32_t flags, uint32_t count) try {
         c->old_cam = g > 1 ? at_rest : first_old;
         done += g;
     }
+    return VXRT_OK;
+} VXRT_CATCH
+
+// One displayed frame of `spp` samples per pixel: `spp` consecutive trace frames with the parameters at rest
+// (frame_number advances by spp), their colours averaged — summed in frame order, divided once — into the last frame's slot,
+// then temporal / denoise once on that.  The first hit (normal/depth, albedo/node) is the same in every sample.
+int vxrt_render_spp(vxrt_ctx* c, uint32_t flags, uint32_t spp) try {
+    if (int rc = check_render(c, flags)) return rc;
+    if (!(flags & VXRT_TRACE) || spp == 0 || spp > 4096) { set_error("vxrt_render_spp needs VXRT_TRACE and 1 <= spp <= 4096"); return VXRT_E_INVALID; }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const bool timed = (flags & VXRT_TIMED) != 0;
+    const size_t pixels = size_t(c->band.local_rows) * c->band.width;
+    if (spp > 1 && c->spp_sum == nullptr && pixels > 0) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->spp_sum), pixels * sizeof(float4)));
+    const uint32_t batch = (c->trace_variant == 0 || c->trace_variant >= 4) ? uint32_t(c->batch) : 1u;
+    Cam first_old{};
+    for (uint32_t done = 0; done < spp;) {
+        const uint32_t g = spp - done < batch ? spp - done : batch;
+        int slots[kMaxBatch];
+        Cam old_of_group;
+        if (int rc = trace_frames(c, g, timed, slots, &old_of_group)) return rc;
+        if (done == 0) first_old = old_of_group;
+        if (spp > 1 && pixels > 0) {
+            SppArgs a{};
+            for (uint32_t k = 0; k < g; k++) {
+                vxrt_ctx::Slot& sl = c->ring[size_t(slots[k])];
+                HIP_TRY(hipStreamWaitEvent(c->stream, sl.trace_done, 0));
+                a.frames[k] = sl.sampled_color;
+            }
+            a.sum = c->spp_sum;
+            a.out = c->ring[size_t(slots[g - 1])].sampled_color;
+            a.pixels = pixels;
+            a.count = int(g); a.first = done == 0; a.last = done + g == spp; a.total = int(spp);
+            HIP_TRY(launch_spp_accumulate(a, c->stream));
+            for (uint32_t k = 0; k < g; k++) {  // the slots may be traced into again only after this pass has read them
+                vxrt_ctx::Slot& sl = c->ring[size_t(slots[k])];
+                HIP_TRY(hipEventRecord(sl.last_use, c->stream));
+                sl.last_use_recorded = true;
+            }
+        }
+        done += g;
+    }
+    const Cam at_rest = c->cam;
+    c->old_cam = first_old;
+    if (int rc = post_stages(c, flags, timed)) return rc;
+    c->old_cam_valid = true;
+    c->old_cam = spp > 1 ? at_rest : first_old;
     return VXRT_OK;
 } VXRT_CATCH
 

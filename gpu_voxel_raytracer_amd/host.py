@@ -356,6 +356,11 @@ class Context:
         self.update_bindings()
         _check(lib().vxrt_render_frames(self._h, C.c_uint32(flags), C.c_uint32(count)), "vxrt_render_frames")
 
+    def render_spp(self, flags, spp):
+        """One displayed frame of `spp` samples per pixel (vxrt_render_spp): spp trace frames averaged, then temporal / denoise."""
+        self.update_bindings()
+        _check(lib().vxrt_render_spp(self._h, C.c_uint32(flags), C.c_uint32(spp)), "vxrt_render_spp")
+
     def render_stage(self, flags):
         """vxrt_render without re-pushing parameters (multi-GPU: DENOISE after the halo exchange)."""
         _check(lib().vxrt_render(self._h, C.c_uint32(flags)), "vxrt_render")

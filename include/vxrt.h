@@ -175,6 +175,11 @@ void vxrt_default_denoise(vxrt_denoise* d);     /* DenoiseUniforms::default(),  
 int vxrt_render(vxrt_ctx* ctx, uint32_t flags);
 /* `count` consecutive frames with the parameters currently set (camera at rest): count x vxrt_render. */
 int vxrt_render_frames(vxrt_ctx* ctx, uint32_t flags, uint32_t count);
+/* One displayed frame of `spp` samples per pixel, as BASELINE's "N spp" is defined in SURVEY.md 8d: spp consecutive trace
+ * frames (frame_number advances by spp, parameters at rest) averaged with equal weights — binary32 sum in frame order,
+ * one division — then temporal / denoise (per flags) once on the average.  The reference itself takes one sample per
+ * pixel per frame (shaders/voxels.comp:305-391) and leaves accumulation to temporal.comp. */
+int vxrt_render_spp(vxrt_ctx* ctx, uint32_t flags, uint32_t spp);
 int vxrt_sync(vxrt_ctx* ctx);
 int vxrt_reset_history(vxrt_ctx* ctx);          /* still_sample = 0 path, src/context.rs:1424 */
 int vxrt_set_frame_number(vxrt_ctx* ctx, uint32_t frame_number); /* next render uses frame_number+1 */

@@ -178,6 +178,14 @@ class Context {
         check(vxrt_set_denoise(ctx_, &denoise_uniforms), "vxrt_set_denoise");
         check(vxrt_render_frames(ctx_, flags, count), "vxrt_render_frames");
     }
+    // one displayed frame of `spp` samples per pixel (vxrt_render_spp)
+    void render_spp(uint32_t flags, uint32_t spp) {
+        check(vxrt_set_camera(ctx_, camera.position.data(), camera.direction.data(), camera.fov), "vxrt_set_camera");
+        check(vxrt_set_scene_params(ctx_, &uniforms), "vxrt_set_scene_params");
+        check(vxrt_set_temporal(ctx_, &temporal_uniforms), "vxrt_set_temporal");
+        check(vxrt_set_denoise(ctx_, &denoise_uniforms), "vxrt_set_denoise");
+        check(vxrt_render_spp(ctx_, flags, spp), "vxrt_render_spp");
+    }
     void sync() { check(vxrt_sync(ctx_), "vxrt_sync"); }
     std::vector<float> read(vxrt_image which) {
         uint32_t rows = 0;

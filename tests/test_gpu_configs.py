@@ -1,9 +1,9 @@
 """GPU parity at the sizes BASELINE.json names for configs 3 and 4 (config 2 at full size: test_gpu_trace.py /
 test_gpu_stress.py; config 5's scene generator: test_gpu_procedural.py).
 
-config 3: vox/monu10.vox at 3840x2160, 8 bounces, temporal + denoise on — two whole frames of the three-stage pipeline against the
-          oracle, bit-exact (frames batched into one trace launch; the oracle needs the box's host threads: ~10 s).
-config 4: vox/castle.vox at 3840x2160 dealt to 8 ranks in interleaved 16-row bands with the denoise halo exchange — the stitched
+config 3: vox/monu10.vox at 3840x2160, 4 spp, 8 bounces, temporal + denoise on — two displayed frames (8 trace frames) of the
+          three-stage pipeline against the oracle, bit-exact (4 samples per trace launch; the oracle needs the box's host threads).
+config 4: vox/castle.vox at 3840x2160, 4 spp, dealt to 8 ranks in interleaved 16-row bands with the denoise halo exchange — the stitched
           frame must equal the single-context frame bit for bit (the 8 contexts share this box's one GPU; the buffers RCCL would
           carry are handed over directly, as in test_gpu_bands.py)."""
 import ctypes as C
@@ -13,23 +13,41 @@ import pytest
 
 from conftest import assert_bits_equal
 from test_gpu_bands import hip
-from test_gpu_pipeline import OraclePipeline
 
 pytestmark = pytest.mark.gpu
 
 
 def test_config3_full_size_pipeline(O, H, scenes, noise):
     from gpu_voxel_raytracer_amd import ALL, Camera, Context
-    w, h, bounces, radius, frames = 3840, 2160, 8, 2, 2
-    ref = OraclePipeline(O, scenes, noise, "monu10", w, h, bounces, radius)
-    cam = scenes.bench_camera(ref.size)
-    pos, mrgb, _ = scenes.load_scene("monu10")
-    want = [ref.render(cam) for _ in range(frames)]
-    with Context(w, h, max_bounces=bounces, noise=noise, frames_per_launch=frames) as ctx:
+    w, h, bounces, radius, spp, shown = 3840, 2160, 8, 2, 4, 2
+    pos, mrgb, size = scenes.load_scene("monu10")
+    cam = scenes.bench_camera(size)
+    octree = O.create_octree(pos, mrgb)
+    u = O.Uniforms.default()
+    u.set_camera(cam[0], O.camera_axis_scaled(cam[0], cam[1], cam[2], w, h))
+    cam16 = u.camera16()
+    du = O.Denoise.default()
+    du.radius = radius
+    old_c, old_nd, frame = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32), 0
+    want = []
+    for k in range(shown):
+        total = None
+        for _ in range(spp):
+            frame += 1
+            u.frame_number = frame
+            color, nd, alb, _ = O.trace(octree, noise, u, w, h, bounces, crop=(0, 0, w, h))
+            total = color.copy() if total is None else (total + color).astype(np.float32)
+        mean = (total / np.float32(spp)).astype(np.float32)
+        accum = O.temporal(mean, nd, old_c, old_nd, cam16, cam16, O.Temporal.default(), k > 0)
+        den = O.denoise(accum, nd, alb, cam16, du)
+        old_c, old_nd = accum, nd
+        want.append((mean, nd, alb, accum, den))
+    with Context(w, h, max_bounces=bounces, noise=noise, frames_per_launch=spp) as ctx:
         ctx.recreate_octree(pos, mrgb)
         ctx.camera = Camera(*cam)
         ctx.denoise_uniforms.radius = radius
-        ctx.render_frames(ALL, frames)
+        for k in range(shown):
+            ctx.render_spp(ALL, spp)
         for img, wimg, label in zip(range(5), want[-1], ("colour", "nd", "albedo", "accum", "denoised")):
             assert_bits_equal(ctx.read(img), wimg, f"config 3 {label}")
         got = ctx.read(4)
@@ -57,9 +75,9 @@ def test_config4_eight_ranks_with_halo_at_4k(H, scenes, noise):
                 setup(c)
             rows = [c.local_rows() for c in ctxs]
             for frame in range(2):
-                single.render(ALL)
+                single.render_spp(ALL, 4)
                 for c in ctxs:
-                    c.render(TRACE | TEMPORAL)
+                    c.render_spp(TRACE | TEMPORAL, 4)
                 nbytes = ctxs[0].halo_bytes()
                 bufs = {}
                 for r, c in enumerate(ctxs):

@@ -298,3 +298,45 @@ def test_bench_contract_line():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mrays/s" and "frames" in c["sample"]
+
+
+@pytest.mark.parametrize("spp,batch,inflight", [(4, 1, 1), (4, 4, 2), (5, 2, 1), (16, 16, 2), (3, 16, 1)])
+def test_samples_per_pixel(O, H, scenes, noise, spp, batch, inflight):
+    """BASELINE's "N spp" (SURVEY 8d): N consecutive trace frames averaged with equal weights — binary32 sum in frame order, one
+    division — then temporal / denoise once.  Checked against the same arithmetic on the oracle's frames, two displayed frames."""
+    from gpu_voxel_raytracer_amd import ALL, Camera, Context
+    w, h, bounces, radius = 128, 80, 4, 2
+    pos, mrgb, size = scenes.load_scene("castle")
+    cam = scenes.close_camera(size)
+    octree = O.create_octree(pos, mrgb)
+    u = O.Uniforms.default()
+    u.set_camera(cam[0], O.camera_axis_scaled(cam[0], cam[1], cam[2], w, h))
+    cam16 = u.camera16()
+    du = O.Denoise.default()
+    du.radius = radius
+    old_c, old_nd, frame = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32), 0
+    with Context(w, h, max_bounces=bounces, noise=noise, frames_per_launch=batch, frames_in_flight=inflight) as ctx:
+        ctx.recreate_octree(pos, mrgb)
+        ctx.camera = Camera(*cam)
+        ctx.denoise_uniforms.radius = radius
+        for shown in range(2):
+            ctx.reset_stats()
+            ctx.render_spp(ALL, spp)
+            total, rays = None, 0
+            for _ in range(spp):
+                frame += 1
+                u.frame_number = frame
+                color, nd, alb, r = O.trace(octree, noise, u, w, h, bounces, crop=(0, 0, w, h))
+                total = color.copy() if total is None else (total + color).astype(np.float32)
+                rays += r
+            mean = (total / np.float32(spp)).astype(np.float32)
+            accum = O.temporal(mean, nd, old_c, old_nd, cam16, cam16, O.Temporal.default(), shown > 0)
+            den = O.denoise(accum, nd, alb, cam16, du)
+            old_c, old_nd = accum, nd
+            for img, want, label in ((0, mean, "mean colour"), (1, nd, "nd"), (2, alb, "albedo"), (3, accum, "accum"), (4, den, "denoised")):
+                assert_bits_equal(ctx.read(img), want, f"{label}, displayed frame {shown + 1}, {spp} spp")
+            assert ctx.stats().rays == rays and ctx.stats().frames == spp
+    with pytest.raises(H.VxrtError):
+        with Context(w, h) as ctx:
+            ctx.recreate_octree(pos, mrgb)
+            ctx.render_spp(ALL, 0)
