@@ -1,0 +1,47 @@
+"""BASELINE.json's configs 2-5 as literally defined, measured on ONE MI355X.  Configs 4 and 5 name 8 GPUs: a rank's
+band set is rendered alone on this GPU (what that rank would do on its own GPU, no halo transfer time) for two of the eight ranks.
+One "displayed frame" = `spp` trace frames averaged (vxrt_render_spp) + temporal + denoise where the config says so."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from gpu_voxel_raytracer_amd import ALL, TRACE, TEMPORAL, Camera, Context, scenes
+
+
+def run(label, w, h, bounces, spp, flags, radius, scene=None, menger=None, rank=0, nranks=1, cam=None, shown=12, batch=None, inflight=2):
+    batch = batch or min(spp, 16)
+    with Context(w, h, max_bounces=bounces, rank=rank, nranks=nranks, frames_per_launch=batch, frames_in_flight=inflight) as ctx:
+        if menger:
+            ctx.set_menger(*menger)
+        else:
+            pos, mrgb, size = scenes.load_scene(scene)
+            ctx.recreate_octree(pos, mrgb)
+            cam = cam or scenes.bench_camera(size)
+        ctx.camera = Camera(*cam)
+        ctx.denoise_uniforms.radius = radius
+        render = (lambda: ctx.render_spp(flags, spp)) if spp > 1 else (lambda: ctx.render_frames(flags, 16))
+        per_call = spp if spp > 1 else 16
+        for _ in range(3):
+            render()
+        ctx.sync(); ctx.reset_stats()
+        t0 = time.perf_counter()
+        for _ in range(shown):
+            render()
+        ctx.sync()
+        dt = (time.perf_counter() - t0) / shown
+        st = ctx.stats()
+        frames = shown * per_call
+        print(f"{label}: {dt * 1e3 / (1 if spp > 1 else 16):8.3f} ms per displayed frame ({spp} spp), {st.rays / frames / (w * h * (st.local_rows / h)):.2f} rays/px/sample, "
+              f"{st.rays / (dt * shown) / 1e9:6.2f} Gray/s on this GPU", flush=True)
+
+
+run("config 2  menger 1920x1080, 1 spp, 4 bounces, trace only", 1920, 1080, 4, 1, TRACE, 0, scene="menger", batch=16)
+for r in (2, 8):
+    run(f"config 3  monu10 3840x2160, 4 spp, 8 bounces, temporal + denoise r={r}", 3840, 2160, 8, 4, ALL, r, scene="monu10")
+for rank in (0, 5):
+    run(f"config 4  castle 3840x2160, 4 spp, 8 bounces, rank {rank} of 8 (trace + temporal; denoise needs the halo)", 3840, 2160, 8, 4,
+        TRACE | TEMPORAL, 2, scene="castle", rank=rank, nranks=8)
+ext = np.float32(1024)
+outside = (np.array([-0.9, 0.6, -1.2], np.float32) * ext + ext / 2, np.array([0.9, -0.6, 1.2], np.float32), 1.2217305)
+for rank in (0, 5):
+    run(f"config 5  2048^3 procedural Menger 7680x4320, 16 spp, 8 bounces, rank {rank} of 8 (trace + temporal)", 7680, 4320, 8, 16,
+        TRACE | TEMPORAL, 0, menger=(7, 2048, (0, 150, 170, 120), 8192), rank=rank, nranks=8, cam=outside, shown=4)
