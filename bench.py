@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=0,
                     help="trace launches that may be on the GPU together, one HIP stream each (default: 2 on one GPU, 3-4 per rank otherwise)")
     ap.add_argument("--batch", type=int, default=0,
-                    help="consecutive frames per trace launch (vxrt_config.frames_per_launch; default: up to 16, fewer for short runs)")
+                    help="consecutive frames per trace launch (vxrt_config.frames_per_launch; default: 16, 32 from 4 ranks on, fewer for short runs)")
     args = ap.parse_args()
     BOUNCES = args.bounces
 
@@ -116,11 +116,11 @@ def main():
 
     if args.inflight <= 0:
         # A frame's longest tile is a serial chain of ~0.15-0.3 ms however few rows a rank owns, so a rank needs that much
-        # work in flight: 16 frames per launch, and the more launches overlapping the smaller its share of the frame
-        # (measured per rank with scripts/exp_rank_emulation.py: 2x16 / 3x16 / 3x16 / 4x16 for 1 / 2 / 4 / 8 ranks).
+        # work in flight: 16-32 frames per launch, and the more launches overlapping the smaller its share of the frame
+        # (measured per rank with scripts/exp_rank_emulation.py: 2x16 / 3x16 / 3x32 / 4x32 for 1 / 2 / 4 / 8 ranks).
         args.inflight = 2 if world == 1 else (3 if world <= 4 else 4)
     if args.batch <= 0:
-        args.batch = 16
+        args.batch = 16 if world <= 2 else 32
         while args.batch > 1 and args.batch * args.inflight * 2 > max(args.steps, 1):   # short runs: keep the pipeline fed
             args.batch //= 2
     from gpu_voxel_raytracer_amd import Camera, Context, TIMED, TRACE, scenes

@@ -35,8 +35,8 @@ struct PathQueue {
     unsigned shard_capacity;  // records per shard
 };
 
-constexpr int kMaxBatch = 16;      // frames one trace launch can cover (vxrt_config.frames_per_launch)
-constexpr uint32_t kPixBits = 28;  // PathRec::pix = local pixel index | frame-in-batch << 28
+constexpr int kMaxBatch = 32;      // frames one trace launch can cover (vxrt_config.frames_per_launch)
+constexpr uint32_t kPixBits = 27;  // PathRec::pix = local pixel index (< 2^27) | frame-in-batch << 27
 struct FrameOut {                  // the three voxels.comp outputs of one frame (a ring slot of the context)
     float4* color;
     float4* nd;

@@ -197,6 +197,10 @@ int alloc_images(vxrt_ctx* c) {
     free_images(c);
     size_t bytes = image_bytes(c);
     if (bytes == 0) bytes = sizeof(float4);
+    if (size_t(c->band.local_rows) * size_t(c->band.width) >= (size_t(1) << kPixBits)) {
+        set_error("more than 2^27 pixels per context");  // the tail queue's records carry pixel index and frame-in-launch in one word
+        return VXRT_E_INVALID;
+    }
     // inflight frames being traced + the frame in the post stages + the temporal history
     c->ring.resize(size_t(c->inflight) * size_t(c->batch) + 2);
     for (vxrt_ctx::Slot& sl : c->ring) {
@@ -486,7 +490,7 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) try {
     if (c->inflight < 1 || c->inflight > 16) { set_error("frames_in_flight must be 1..16"); return fail(VXRT_E_INVALID); }
     c->batch = cfg->frames_per_launch == 0 ? 1 : int(cfg->frames_per_launch);
     if (const char* v = getenv("VXRT_BATCH")) c->batch = atoi(v);
-    if (c->batch < 1 || c->batch > kMaxBatch) { set_error("frames_per_launch must be 1..16"); return fail(VXRT_E_INVALID); }
+    if (c->batch < 1 || c->batch > kMaxBatch) { set_error("frames_per_launch must be 1..32"); return fail(VXRT_E_INVALID); }
     c->trace_streams.assign(size_t(c->inflight), nullptr);
     if (c->inflight == 1) {
         c->trace_streams[0] = c->stream;

@@ -107,7 +107,7 @@ typedef struct vxrt_config {
                                  path up to its second hit; the paths still alive there — about a third of a
                                  geometry tile's lanes — are queued and finished by a dense launch), 5 as 4 with
                                  a tail whose lanes are refilled path by path (slower; kept for comparison).  */
-    uint32_t frames_per_launch;/* 0/1: one trace launch per frame.  B = 2..16: vxrt_render_frames (parameters at rest)
+    uint32_t frames_per_launch;/* 0/1: one trace launch per frame.  B = 2..32: vxrt_render_frames (parameters at rest)
                                  traces up to B consecutive frames with ONE launch of the tracer (tracers 1 and 4;
                                  B ring slots, frame numbers n+1..n+B, longest tile first across the whole batch);
                                  temporal / denoise still run per frame in frame order.  Results are identical.
