@@ -124,7 +124,9 @@ struct RayQueue {
     unsigned seg_capacity;
 };
 
-hipError_t launch_trace(const TraceArgs& a, hipStream_t s);  // monolithic: one pixel per lane, all bounces
+hipError_t launch_trace(const TraceArgs& a, hipStream_t s);
+unsigned trace_tile_count(int width, int local_rows);  // blocks per frame of trace_kernel = entries of a tile schedule
+void trace_tile_dims(int* w, int* h);                  // pixels per block  // monolithic: one pixel per lane, all bounces
 // ray queues: primary_kernel, then shade / trace-rays launches per path segment with per-lane ray refill
 hipError_t launch_trace_rayqueue(const TraceArgs& a, const PathQueue& hits, unsigned* count_sets[3], unsigned* launch_counter,
                                  const RayQueue& q, int shade_blocks, int trace_blocks, unsigned min_rays_per_wave, hipStream_t s);

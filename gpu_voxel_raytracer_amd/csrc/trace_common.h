@@ -13,6 +13,10 @@ constexpr float kAlmostInfinity = 1073741824.0f;  // float(1 << 30)  voxels.comp
 constexpr int32_t kLeafBit = int32_t(0x80000000u);
 constexpr int32_t kEmitBit = 1 << 30;
 constexpr int kBlock = 256;
+#ifndef VXRT_STACK_STRIDE
+#define VXRT_STACK_STRIDE 256   // threads per block of the including kernel file = columns of the LDS stack
+#endif
+constexpr int kStackStride = VXRT_STACK_STRIDE;
 constexpr uint32_t kNoiseLayer = 128u * 128u;
 constexpr uint32_t kNoiseTotal = kNoiseLayer * 512u;
 
@@ -46,7 +50,7 @@ struct SceneView {
 };
 
 // cast_bounded_ray, voxels.comp:134-247.  `stack` points at this thread's column of the LDS stack
-// (entry l at stack[l * kBlock]).  On the iteration cap the shader returns true without writing the
+// (entry l at stack[l * kStackStride]).  On the iteration cap the shader returns true without writing the
 // normal; it is defined as 0 here (oracle U1).
 //
 // Shape of the loop (what differs from the shader's text, none of it changes a result):
@@ -114,7 +118,7 @@ __device__ __forceinline__ int walk_step(Walk& w, const SceneView& sc, float max
         uint2 raw;
         if (is_child) {  // descend: remember where to resume, fetch the child record   voxels.comp:205-214
             if (has_next) {
-                stack[w.lvl * kBlock] = make_uint2(w.rec.masks | next_octant << 16, w.rec.base);
+                stack[w.lvl * kStackStride] = make_uint2(w.rec.masks | next_octant << 16, w.rec.base);
                 w.has_next_mask |= 1u << w.lvl;
             }
             raw = *reinterpret_cast<const uint2*>(sc.svo + (w.rec.base + __popc(w.rec.masks & (bit - 1u))));
@@ -129,7 +133,7 @@ __device__ __forceinline__ int walk_step(Walk& w, const SceneView& sc, float max
             const uint32_t up = w.lvl - l;
             w.ix >>= up; w.iy >>= up; w.iz >>= up;
             w.lvl = l;
-            raw = stack[l * kBlock];
+            raw = stack[l * kStackStride];
             // consume the LDS read here: left alone, the compiler merges it with the descend branch's global
             // load into one flat_load (either address space), which is slower and waits on both counters
             asm volatile("" : "+v"(raw.x), "+v"(raw.y));
@@ -189,12 +193,12 @@ __device__ __forceinline__ int walk_step_uniform(Walk& w, const SceneView& sc, f
     const bool pop = move && !is_child;
 
     // memory operations, each under its lane predicate
-    if (descend && has_next) stack[w.lvl * kBlock] = make_uint2(w.rec.masks | next_octant << 16, w.rec.base);
+    if (descend && has_next) stack[w.lvl * kStackStride] = make_uint2(w.rec.masks | next_octant << 16, w.rec.base);
     const uint32_t l = 31u - uint32_t(__clz(int(w.has_next_mask | 1u)));
     uint2 raw = make_uint2(0u, 0u);
     if (descend) raw = *reinterpret_cast<const uint2*>(sc.svo + (w.rec.base + __popc(w.rec.masks & (bit - 1u))));
     if (pop) {
-        uint2 r = stack[l * kBlock];
+        uint2 r = stack[l * kStackStride];
         asm volatile("" : "+v"(r.x), "+v"(r.y));  // keep it an LDS read (no flat_load merge with the global load)
         raw = r;
     }
@@ -316,7 +320,7 @@ __device__ __forceinline__ int walkf_step(WalkF& w, const SceneView& sc, uint2* 
         uint2 raw;
         if (is_child) {  // voxels.comp:205-214
             if (has_next) {
-                stack[w.lvl * kBlock] = make_uint2(w.rec.masks | (w.octant ^ transition) << 16, w.rec.base);
+                stack[w.lvl * kStackStride] = make_uint2(w.rec.masks | (w.octant ^ transition) << 16, w.rec.base);
                 w.has_next_mask |= 1u << w.lvl;
             }
             raw = *reinterpret_cast<const uint2*>(sc.svo + (w.rec.base + __popc(w.rec.masks & (bit - 1u))));
@@ -331,7 +335,7 @@ __device__ __forceinline__ int walkf_step(WalkF& w, const SceneView& sc, uint2* 
             const uint32_t up = w.lvl - l;
             w.ix >>= up; w.iy >>= up; w.iz >>= up;
             w.lvl = l;
-            raw = stack[l * kBlock];
+            raw = stack[l * kStackStride];
             asm volatile("" : "+v"(raw.x), "+v"(raw.y));  // keep it an LDS read (see walk_step)
         }
         const float size = __builtin_ldexpf(sc.root_size, -int(w.lvl));

@@ -71,119 +71,6 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const TraceArgs a, cons
     count_rays(a.ray_counter, active ? 1u : 0u, lane);
 }
 
-#ifndef VXRT_BOUNCE_WAVES
-#define VXRT_BOUNCE_WAVES 5
-#endif
-__global__ __launch_bounds__(kBlock, VXRT_BOUNCE_WAVES) void bounce_kernel(const TraceArgs a, const PathQueue in, const PathQueue out, unsigned* zero,
-                                                        int first_bounce, int last_bounce) {
-    extern __shared__ uint2 lds_stack[];
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    zero_counts(zero, tid);
-    const SceneView sc = make_scene(a);
-    const f3 sun_dir = ld3(a.sun_dir), sun_color = ld3(a.sun_color), sky = ld3(a.sky_color);
-    uint2* stack = lds_stack + tid;
-
-    // chunk table: lane q owns shard q
-    const unsigned my_count = in.counts[lane * kCountStride];
-    const unsigned my_chunks = (my_count + 63u) / 64u;
-    unsigned incl = my_chunks;
-    for (int off = 1; off < 64; off <<= 1) {
-        unsigned v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
-    }
-    const unsigned total_chunks = __shfl(incl, 63, 64);
-    const unsigned total_waves = gridDim.x * 4u;
-    uint32_t rays = 0;
-
-    for (unsigned c = blockIdx.x * 4u + unsigned(wave); c < total_chunks; c += total_waves) {
-        const unsigned long long above = __ballot(incl > c);
-        const int q = __ffsll((long long)above) - 1;                       // shard that holds chunk c
-        const unsigned first = __shfl(incl - my_chunks, q, 64);           // chunks before shard q
-        const unsigned count_q = __shfl(my_count, q, 64);
-        const unsigned entry = (c - first) * 64u + unsigned(lane);
-        const bool valid = entry < count_q;
-
-        bool keep = false;
-        PathRec rec;
-        rec.node = 0; rec.normal_ambient = 0; rec.rng_index = 0; rec.pix = 0;
-        rec.hit_pos = rec.dir = rec.sample = rec.blend = splat3(0.0f);
-        if (valid) {
-            rec = load_rec(in.recs + (size_t(q) * in.shard_capacity + entry) * 4u);
-            Rng rng;
-            rng.noise = a.noise;
-            rng.index = rec.rng_index;
-            // Path segments first_bounce .. last_bounce run in this launch (lanes whose path ends simply idle);
-            // a path that is still alive after segment last_bounce goes to the next queue.
-            for (int bounce = first_bounce;; bounce++) {
-                const f3 n = mk3(unpack_axis(rec.normal_ambient & 3u), unpack_axis((rec.normal_ambient >> 2) & 3u), unpack_axis((rec.normal_ambient >> 4) & 3u));
-                uint32_t ambient_rays = rec.normal_ambient >> 8;
-                f3 sample = rec.sample, blend = rec.blend;
-                const f3 color = bounce == 0 ? splat3(1.0f) : node_color(rec.node);          // voxels.comp:317
-                const f3 emit = node_emittance(rec.node, a.emit_strength);
-                const f3 o = rec.hit_pos + 1e-5f * n;                                       // voxels.comp:333,353,370
-                f3 d;
-                if (rng.next() < a.specularity) {  // specular                              voxels.comp:326-334
-                    d = norm3(reflect3(rec.dir, n));
-                    sample = sample + emit * blend;
-                    blend = blend * ((2.0f * color) * dot3(d, n));
-                } else if (a.sun_strength > 0.0f) {  // diffuse + sun sample                  voxels.comp:339-371
-                    float r0 = rng.next(), r1 = rng.next(), r2 = rng.next();
-                    f3 up_dir = norm3(cross3(mk3(r0, r1, r2), sun_dir));
-                    f3 right_dir = norm3(cross3(sun_dir, up_dir));
-                    float dx = 2.0f * rng.next() - 1.0f;
-                    float dy = 2.0f * rng.next() - 1.0f;
-                    f3 light_dir = ld3(a.sun_dir_n) + (dx * right_dir + dy * up_dir) * a.sun_size;
-                    f3 to_light = norm3(-light_dir);
-                    ambient_rays++;
-                    RayHit sun_hit;
-                    rays++;
-                    if (!cast_ray(sc, o, to_light, kAlmostInfinity, stack, sun_hit))
-                        sample = sample + ((sun_color * color) * blend) * vx_max(0.0f, dot3(n, to_light));
-                    d = random_hemisphere(n, rng);
-                    sample = sample + emit * blend;
-                    blend = blend * (color * dot3(n, d));
-                } else {  // diffuse, sun switched off
-                    d = random_hemisphere(n, rng);
-                    sample = sample + emit * blend;
-                    blend = blend * (color * dot3(n, d));
-                }
-
-                bool finished = true;
-                if (bounce + 1 < a.max_bounces) {  // next path segment                        voxels.comp:309-313
-                    RayHit hit;
-                    rays++;
-                    if (cast_ray(sc, o, d, kAlmostInfinity, stack, hit)) {
-                        const f3 hn = hit.normal;
-                        rec.hit_pos = o + d * hit.time;
-                        rec.node = hit.node;
-                        rec.dir = d;
-                        rec.normal_ambient = pack_axis(hn.x) | pack_axis(hn.y) << 2 | pack_axis(hn.z) << 4 | ambient_rays << 8;
-                        rec.sample = sample;
-                        rec.blend = blend;
-                        finished = false;
-                    } else {
-                        sample = sample + sky * blend;                                        // voxels.comp:384
-                    }
-                }
-                if (finished) {
-                    f3 outc = sample / float(ambient_rays);                                   // voxels.comp:391
-                    store_out(a.out[rec.pix >> kPixBits].color + (rec.pix & ((1u << kPixBits) - 1u)), make_float4(outc.x, outc.y, outc.z, 1.0f));
-                    break;
-                }
-                if (bounce == last_bounce) {
-                    rec.rng_index = rng.index;
-                    keep = true;
-                    break;
-                }
-            }
-        }
-        queue_append(out, c % kShards, keep, rec, lane);
-    }
-    count_rays(a.ray_counter, rays, lane);
-}
-
-
 // ------------------------------------------------------------------------------------------------------
 // Ray-queue variant: shading and traversal in separate launches, rays traced by persistent waves that
 // REFILL EACH LANE as soon as its ray ends.
@@ -446,30 +333,6 @@ __global__ __launch_bounds__(kBlock) void trace_rays_kernel(const TraceArgs a, c
 }
 
 }  // namespace
-
-// bounce_kernel launches for the path segments from..max_bounces-1 of the paths in queues[0] (written by launch J-1 with
-// count set J%3).  Bit k of split_mask set: a new launch (with compaction of the live paths) starts at path segment k.
-// Launch J reads count set J%3, writes (J+1)%3 and clears (J+2)%3 (the set launch J-1 consumed).
-hipError_t launch_bounces(const TraceArgs& a, const PathQueue queues[2], unsigned* count_sets[3], unsigned* launch_counter, int blocks,
-                          unsigned split_mask, int from, hipStream_t s) {
-    size_t lds = size_t(a.stack_levels) * kBlock * sizeof(uint2);
-    unsigned J = *launch_counter;
-    int stage = 0;
-    for (int first = from; first < a.max_bounces;) {
-        int last = first;
-        while (last + 1 < a.max_bounces && !((split_mask >> (last + 1)) & 1u)) last++;
-        PathQueue in = queues[stage & 1];
-        in.counts = count_sets[J % 3];
-        PathQueue out = queues[(stage & 1) ^ 1];
-        out.counts = count_sets[(J + 1) % 3];
-        hipLaunchKernelGGL(bounce_kernel, dim3(blocks), dim3(kBlock), lds, s, a, in, out, count_sets[(J + 2) % 3], first, last);
-        J++;
-        stage++;
-        first = last + 1;
-    }
-    *launch_counter = J;
-    return hipGetLastError();
-}
 
 hipError_t launch_trace_wavefront(const TraceArgs& a, const PathQueue queues[2], unsigned* count_sets[3], unsigned* launch_counter,
                                   int blocks, unsigned split_mask, hipStream_t s) {

@@ -247,7 +247,7 @@ int alloc_images(vxrt_ctx* c) {
             }
         }
     }
-    const size_t tiles = waves / 4;
+    const size_t tiles = trace_tile_count(c->band.width, c->band.local_rows);
     c->schedules.resize(size_t(c->inflight));
     for (vxrt_ctx::TileSchedule& t : c->schedules) {
         for (uint32_t** p : {&t.cost, &t.order, &t.last_cost}) {
@@ -732,7 +732,7 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* first_old
             // Re-sort the tiles for this stream's coming frames from the costs just measured: after its first
             // frame, then every 8th (costs keep accumulating as a running maximum in between; ~7 us per sort).
             if (c->use_tile_order && (!sched.valid || sched.age >= 8)) {
-                const unsigned tiles = unsigned((c->band.width + 15) / 16) * unsigned((c->band.local_rows + 15) / 16);
+                const unsigned tiles = trace_tile_count(c->band.width, c->band.local_rows);
                 HIP_TRY(launch_tile_order(sched.cost, sched.order, sched.last_cost, tiles, ts));
                 sched.valid = true;
                 sched.age = 0;
@@ -1026,11 +1026,22 @@ int vxrt_reset_stats(vxrt_ctx* c) try {
 // Diagnostics: shader-clock duration of every 16x16 tile in the last traced frame (monolithic kernel).
 int vxrt_debug_tile_costs(vxrt_ctx* c, uint32_t* out, size_t n) try {
     if (!valid_ctx(c) || !out) { set_error("null argument"); return VXRT_E_INVALID; }
-    const size_t tiles = size_t((c->band.width + 15) / 16) * size_t((c->band.local_rows + 15) / 16);
-    if (n != tiles || c->schedules.empty()) { set_error("tile count mismatch"); return VXRT_E_INVALID; }
+    // reported per 16x16 pixels whatever the kernel's own tile is: the maximum over the kernel tiles inside
+    const size_t out_x = size_t((c->band.width + 15) / 16), out_y = size_t((c->band.local_rows + 15) / 16);
+    if (n != out_x * out_y || c->schedules.empty()) { set_error("tile count mismatch"); return VXRT_E_INVALID; }
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = sync_all(c)) return rc;
-    HIP_TRY(hipMemcpy(out, c->schedules[size_t(c->last_schedule)].last_cost, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    int tw = 16, th = 16;
+    trace_tile_dims(&tw, &th);
+    const size_t kx = size_t((c->band.width + tw - 1) / tw), ky = size_t((c->band.local_rows + th - 1) / th);
+    std::vector<uint32_t> raw(kx * ky);
+    HIP_TRY(hipMemcpy(raw.data(), c->schedules[size_t(c->last_schedule)].last_cost, raw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) out[i] = 0;
+    for (size_t y = 0; y < ky; y++)
+        for (size_t x = 0; x < kx; x++) {
+            uint32_t& o = out[(y * size_t(th) / 16) * out_x + x * size_t(tw) / 16];
+            o = raw[y * kx + x] > o ? raw[y * kx + x] : o;
+        }
     return VXRT_OK;
 } VXRT_CATCH
 
