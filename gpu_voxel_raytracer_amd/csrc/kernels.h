@@ -131,7 +131,8 @@ void trace_tile_dims(int* w, int* h);                  // pixels per block  // m
 hipError_t launch_trace_rayqueue(const TraceArgs& a, const PathQueue& hits, unsigned* count_sets[3], unsigned* launch_counter,
                                  const RayQueue& q, int shade_blocks, int trace_blocks, unsigned min_rays_per_wave, hipStream_t s);
 // longest-tile-first schedule for the next launch: order[] = tiles sorted by descending cost; cost[] is cleared
-hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t* last_cost, unsigned tiles, hipStream_t s);
+// scratch: 256 * 128 uint32
+hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t* last_cost, uint32_t* scratch, unsigned tiles, hipStream_t s);
 // wavefront: primary_kernel + max_bounces x bounce_kernel; queues[2] ping-pong, count_sets[3] rotate
 hipError_t launch_trace_wavefront(const TraceArgs& a, const PathQueue queues[2], unsigned* count_sets[3], unsigned* launch_counter,
                                   int blocks, unsigned split_mask, hipStream_t s);

@@ -192,46 +192,63 @@ __global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const Trac
     }
 }
 
-// Counting sort of the tiles by descending cost (key = log2 of the cost with two mantissa bits), one block.  Each thread owns a
-// contiguous range of tiles and handles runs of equal keys with one LDS atomic (neighbouring tiles mostly cost the same: sky).
-// rocprofv3 shows 0.1-1.1 ms for it on a busy GPU — a single block waiting for wave slots between trace waves; it runs in the
-// shadow of the other stream's launch and changes the frame rate by nothing measurable.
-__global__ __launch_bounds__(1024) void tile_order_kernel(uint32_t* cost, uint32_t* order, uint32_t* last_cost, unsigned tiles) {
-    __shared__ unsigned hist[128], offs[128];
-    const unsigned tid = threadIdx.x;
-    if (tid < 128) hist[tid] = 0;
+// Counting sort of the tiles by descending cost (key = log2 of the cost with two mantissa bits: 128 bins) in three small launches:
+// per-block histograms over contiguous tile ranges (coalesced reads) -> one block turns them into (key, block) offsets -> each block
+// scatters its tiles.  (One 1024-thread block doing all of it took 0.46 ms for the 129 600 tiles of a 4K frame — on the trace
+// stream's critical path whenever a single frame is rendered per call.)
+constexpr unsigned kSortBlocks = 64, kSortBins = 128;   // block_hist is [bin][block]
+
+__device__ __forceinline__ unsigned tile_key(uint32_t c) {
+    if (c < 4u) return c;
+    const unsigned e = 31u - unsigned(__clz(int(c)));
+    return (e << 2 | ((c >> (e - 2u)) & 3u)) - 4u;   // 4..127, monotone in c
+}
+
+__global__ __launch_bounds__(256) void tile_hist_kernel(const uint32_t* cost, uint32_t* block_hist, unsigned tiles, unsigned per_block) {
+    __shared__ unsigned hist[kSortBins];
+    if (threadIdx.x < kSortBins) hist[threadIdx.x] = 0;
     __syncthreads();
-    auto key_of = [](uint32_t c) -> unsigned {
-        if (c < 4u) return c;
-        const unsigned e = 31u - unsigned(__clz(int(c)));
-        return (e << 2 | ((c >> (e - 2u)) & 3u)) - 4u;   // 4..127, monotone in c
-    };
-    const unsigned per = (tiles + blockDim.x - 1u) / blockDim.x;
-    const unsigned t0 = tid * per < tiles ? tid * per : tiles, t1 = t0 + per < tiles ? t0 + per : tiles;
-    for (unsigned t = t0; t < t1;) {
-        const unsigned k = key_of(cost[t]);
-        unsigned run = 1;
-        while (t + run < t1 && key_of(cost[t + run]) == k) run++;
-        atomicAdd(&hist[127u - k], run);
-        t += run;
+    const unsigned t0 = blockIdx.x * per_block, t1 = t0 + per_block < tiles ? t0 + per_block : tiles;
+    for (unsigned t = t0 + threadIdx.x; t < t1; t += 256u) atomicAdd(&hist[kSortBins - 1u - tile_key(cost[t])], 1u);
+    __syncthreads();
+    if (threadIdx.x < kSortBins) block_hist[threadIdx.x * gridDim.x + blockIdx.x] = hist[threadIdx.x];
+}
+
+// block_hist[k][b] -> the position in `order` where block b's tiles of bin k start (bins in descending cost, blocks in order).
+// 4 waves x 32 bins; lane = block (blocks <= 64): an exclusive wave scan per bin, then the bins' bases.
+__global__ __launch_bounds__(256) void tile_scan_kernel(uint32_t* block_hist, unsigned blocks) {
+    __shared__ unsigned total[kSortBins], base[kSortBins];
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (unsigned k = wave * 32u; k < wave * 32u + 32u; k++) {
+        const unsigned v = lane < blocks ? block_hist[k * blocks + lane] : 0u;
+        unsigned x = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned y = __shfl_up(x, off, 64);
+            if (int(lane) >= off) x += y;
+        }
+        if (lane < blocks) block_hist[k * blocks + lane] = x - v;
+        if (lane == 63u) total[k] = x;
     }
     __syncthreads();
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
         unsigned sum = 0;
-        for (int k = 0; k < 128; k++) { offs[k] = sum; sum += hist[k]; }
+        for (unsigned i = 0; i < kSortBins; i++) { base[i] = sum; sum += total[i]; }
     }
     __syncthreads();
-    for (unsigned t = t0; t < t1;) {
-        const unsigned k = key_of(cost[t]);
-        unsigned run = 1;
-        while (t + run < t1 && key_of(cost[t + run]) == k) run++;
-        const unsigned pos = atomicAdd(&offs[127u - k], run);
-        for (unsigned i = 0; i < run; i++) order[pos + i] = t + i;
-        t += run;
-    }
+    for (unsigned k = wave * 32u; k < wave * 32u + 32u; k++)
+        if (lane < blocks) block_hist[k * blocks + lane] += base[k];
+}
+
+__global__ __launch_bounds__(256) void tile_scatter_kernel(uint32_t* cost, uint32_t* order, uint32_t* last_cost, const uint32_t* block_offs,
+                                                          unsigned tiles, unsigned per_block) {
+    __shared__ unsigned offs[kSortBins];
+    if (threadIdx.x < kSortBins) offs[threadIdx.x] = block_offs[threadIdx.x * gridDim.x + blockIdx.x];
     __syncthreads();
-    for (unsigned t = tid; t < tiles; t += blockDim.x) {
-        last_cost[t] = cost[t];
+    const unsigned t0 = blockIdx.x * per_block, t1 = t0 + per_block < tiles ? t0 + per_block : tiles;
+    for (unsigned t = t0 + threadIdx.x; t < t1; t += 256u) {
+        const uint32_t c = cost[t];
+        order[atomicAdd(&offs[kSortBins - 1u - tile_key(c)], 1u)] = t;
+        last_cost[t] = c;
         cost[t] = 0u;
     }
 }
@@ -252,8 +269,12 @@ hipError_t launch_trace(const TraceArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t* last_cost, unsigned tiles, hipStream_t s) {
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, cost, order, last_cost, tiles);
+hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t* last_cost, uint32_t* scratch, unsigned tiles, hipStream_t s) {
+    const unsigned blocks = (tiles + 255u) / 256u < kSortBlocks ? (tiles + 255u) / 256u : kSortBlocks;
+    const unsigned per_block = (tiles + blocks - 1u) / blocks;
+    hipLaunchKernelGGL(tile_hist_kernel, dim3(blocks), dim3(256), 0, s, cost, scratch, tiles, per_block);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(256), 0, s, scratch, blocks);
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3(blocks), dim3(256), 0, s, cost, order, last_cost, scratch, tiles, per_block);
     return hipGetLastError();
 }
 

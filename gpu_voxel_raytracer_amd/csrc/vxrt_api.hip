@@ -138,6 +138,7 @@ struct vxrt_ctx {
         uint32_t* cost = nullptr;
         uint32_t* order = nullptr;
         uint32_t* last_cost = nullptr;  // copy for diagnostics (vxrt_debug_tile_costs)
+        uint32_t* scratch = nullptr;    // per-block histograms of the sort (256 x 128)
         bool valid = false;
         int age = 0;  // frames traced since the last sort
     };
@@ -183,7 +184,7 @@ void free_images(vxrt_ctx* c) {
         *p = nullptr;
     }
     for (vxrt_ctx::TileSchedule& t : c->schedules)
-        for (uint32_t** p : {&t.cost, &t.order, &t.last_cost}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        for (uint32_t** p : {&t.cost, &t.order, &t.last_cost, &t.scratch}) { if (*p) (void)hipFree(*p); *p = nullptr; }
     c->schedules.clear();
     for (vxrt_ctx::StreamQueues& sq : c->queues) {
         for (float4** p : {&sq.hitq[0], &sq.hitq[1]}) { if (*p) (void)hipFree(*p); *p = nullptr; }
@@ -254,6 +255,7 @@ int alloc_images(vxrt_ctx* c) {
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), (tiles + 1) * sizeof(uint32_t)));
             HIP_TRY(hipMemsetAsync(*p, 0, (tiles + 1) * sizeof(uint32_t), c->stream));
         }
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t.scratch), 256 * 128 * sizeof(uint32_t)));
         t.valid = false;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -733,7 +735,7 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* first_old
             // frame, then every 8th (costs keep accumulating as a running maximum in between; ~7 us per sort).
             if (c->use_tile_order && (!sched.valid || sched.age >= 8)) {
                 const unsigned tiles = trace_tile_count(c->band.width, c->band.local_rows);
-                HIP_TRY(launch_tile_order(sched.cost, sched.order, sched.last_cost, tiles, ts));
+                HIP_TRY(launch_tile_order(sched.cost, sched.order, sched.last_cost, sched.scratch, tiles, ts));
                 sched.valid = true;
                 sched.age = 0;
             }
