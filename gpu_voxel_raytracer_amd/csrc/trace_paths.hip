@@ -14,7 +14,7 @@
 //     voxels.comp:314-371), finish paths (voxels.comp:384-391), start the next ray (voxels.comp:138-160).
 //
 // The shading code exists once and runs for >= kGate lanes at a time; the walk never waits for the longest ray of a round.
-// scripts/sim_schedule.py::tail_refill prices this on the oracle's per-ray step counts: 17-21 M wave-instructions for the
+// tests/sim_schedule.py::tail_refill prices this on the oracle's per-ray step counts: 17-21 M wave-instructions for the
 // bench frame's tail against 31.6 M in lock step.  Per path the operation order is voxels.comp's; results are bit-identical.
 #include "trace_common.h"
 

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""CPU-side what-if for the monolithic tracer's wave scheduling (no GPU): takes the oracle's per-ray octree step
+"""ORACLE-BASED DIAGNOSTIC (test infrastructure: lives under tests/ because it calls the oracle; not collected by pytest).
+CPU-side what-if for the monolithic tracer's wave scheduling (no GPU): takes the oracle's per-ray octree step
 counts of the bench frame (orc_trace_steps) and prices three ways of running an 8x8 tile on one wave64:
 
   sync   every lane casts its next ray, the wave leaves the walk loop when the LAST lane's ray ends, then all shade
@@ -15,7 +16,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # tests/ -> repo root
 sys.path.insert(0, ROOT)
 from gpu_voxel_raytracer_amd import scenes  # noqa: E402
 from oracle import oracle as O  # noqa: E402
