@@ -12,7 +12,7 @@ import sys
 tag = sys.argv[1]
 base = f"gpurun_out/prof_{tag}"
 out = {}
-KERNELS = r"(trace_kernel|bounce_kernel|tile_order_kernel|primary_kernel|shade_kernel|trace_rays_kernel)"
+KERNELS = r"(trace_kernel|bounce_kernel|path_kernel|tile_hist_kernel|tile_scan_kernel|tile_scatter_kernel|primary_kernel|shade_kernel|trace_rays_kernel)"
 
 
 def counters(sub):
