@@ -76,6 +76,21 @@ def cpu_baseline(pos, mrgb, cam, target_seconds=float(os.environ.get("VXRT_BENCH
                       f"{threads} threads"}
 
 
+def pick_schedule(world, steps, inflight=0, batch=0):
+    """Launches in flight and frames per launch for `world` ranks and a run of `steps` frames (0 = choose).
+    A frame's longest tile is a serial chain of ~0.15-0.3 ms however few rows a rank owns, so a rank needs that much work in
+    flight: 16-32 frames per launch, and the more launches overlapping the smaller its share of the frame (measured per rank with
+    scripts/exp_rank_emulation.py: 2x16 / 3x16 / 3x32 / 4x32 for 1 / 2 / 4 / 8 ranks).  Short runs get smaller launches so that
+    the pipeline still holds a few of them."""
+    if inflight <= 0:
+        inflight = 2 if world == 1 else (3 if world <= 4 else 4)
+    if batch <= 0:
+        batch = 16 if world <= 2 else 32
+        while batch > 1 and batch * inflight * 2 > max(steps, 1):
+            batch //= 2
+    return inflight, batch
+
+
 def main():
     global BOUNCES
     ap = argparse.ArgumentParser()
@@ -114,15 +129,7 @@ def main():
             dist.init_process_group(backend)
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
-    if args.inflight <= 0:
-        # A frame's longest tile is a serial chain of ~0.15-0.3 ms however few rows a rank owns, so a rank needs that much
-        # work in flight: 16-32 frames per launch, and the more launches overlapping the smaller its share of the frame
-        # (measured per rank with scripts/exp_rank_emulation.py: 2x16 / 3x16 / 3x32 / 4x32 for 1 / 2 / 4 / 8 ranks).
-        args.inflight = 2 if world == 1 else (3 if world <= 4 else 4)
-    if args.batch <= 0:
-        args.batch = 16 if world <= 2 else 32
-        while args.batch > 1 and args.batch * args.inflight * 2 > max(args.steps, 1):   # short runs: keep the pipeline fed
-            args.batch //= 2
+    args.inflight, args.batch = pick_schedule(world, args.steps, args.inflight, args.batch)
     from gpu_voxel_raytracer_amd import Camera, Context, TIMED, TRACE, scenes
 
     pos, mrgb, size = scenes.load_scene(SCENE)

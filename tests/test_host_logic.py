@@ -136,3 +136,20 @@ def test_product_fails_loudly_without_gpu(H):
     with pytest.raises(VxrtError) as e:
         Context(64, 64)
     assert e.value.status == H.E_DEVICE
+
+
+def test_bench_schedule_choice():
+    """bench.py's frames per launch / launches in flight for the driver's N and K (pure host logic)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.pick_schedule(1, 1000) == (2, 16) and bench.pick_schedule(2, 1000) == (3, 16)
+    assert bench.pick_schedule(4, 1000) == (3, 32) and bench.pick_schedule(8, 1000) == (4, 32)
+    for world in (1, 2, 4, 8):
+        for steps in (1, 2, 5, 20, 63, 64, 100):
+            inflight, batch = bench.pick_schedule(world, steps)
+            assert 1 <= batch <= 32 and 1 <= inflight <= 16
+            assert batch == 1 or batch * inflight * 2 <= steps      # a short run still holds two rounds of launches
+    assert bench.pick_schedule(8, 1000, inflight=2, batch=4) == (2, 4)   # explicit values are kept
+    assert bench.algorithmic_bytes(1920 * 1080, 4, 359016 + 640000) == 48 * 1920 * 1080 + 999016 + 32 * 65536
