@@ -25,7 +25,7 @@ cam_pos, cam_dir, fov = scenes.bench_camera(size)
 basis = O.camera_axis_scaled(cam_pos, cam_dir, fov, 256, 256)
 coords, rgb = pos.astype(np.uint16), mrgb[:, 1:]
 ms = median_ms(lambda: O.cpu_rs_render(coords, rgb, cam_pos * 2, basis, 256, 256, time=0.0))
-print(f"config 1 (cpu.rs restated, 3x3x3 256x256, 2 rays/px max): {ms:.2f} ms/frame, {threads} hardware threads (the caster itself runs as the restatement's loop does)")
+print(f"config 1 (cpu.rs restated, 3x3x3 256x256, 2 rays/px max): {ms:.2f} ms/frame, 1 thread (the restatement of cpu.rs is a serial loop; the reference would spread it with rayon)")
 
 noise = O.noise_table()
 for name, w, h, b in (("menger", 1920, 1080, 4), ("monu10", 3840, 2160, 8)):
