@@ -590,11 +590,13 @@ int vxrt_set_scene_params(vxrt_ctx* c, const vxrt_uniforms* u) try {
     c->uniforms.frame_number = frame;  // owned by the library, like update_bindings (src/context.rs:2152)
     return VXRT_OK;
 } VXRT_CATCH
+
 int vxrt_set_temporal(vxrt_ctx* c, const vxrt_temporal* t) try {
     if (!valid_ctx(c) || !t) { set_error("null argument"); return VXRT_E_INVALID; }
     c->temporal = *t;
     return VXRT_OK;
 } VXRT_CATCH
+
 int vxrt_set_denoise(vxrt_ctx* c, const vxrt_denoise* d) try {
     if (!valid_ctx(c) || !d) { set_error("null argument"); return VXRT_E_INVALID; }
     if (d->radius > 8) { set_error("denoise radius must be 0..8"); return VXRT_E_INVALID; }
