@@ -15,7 +15,9 @@
 //    exact and equal to the shader's incremental float updates;
 //  * primary, bounce and sun rays of a pixel run through ONE traversal loop (a small state machine),
 //    so lanes that are in different shading phases still execute the traversal together;
-//  * a wave covers an 8x8 pixel tile (coherent primary rays, 128-byte output segments).
+//  * a wave covers an 8x8 pixel tile (coherent primary rays, 128-byte output segments) and is a block of its own;
+//  * the kernel follows a path up to its second hit (TraceArgs::tail_from); the paths still alive there are queued for
+//    bounce_kernel (trace_tail.hip); a launch covers up to 32 consecutive frames (TraceArgs::batch).
 //
 // Arithmetic follows include/vxrt_detmath.h: every float operation that can change a result is the
 // shader's operation, in the shader's order, never contracted.
@@ -42,11 +44,11 @@ constexpr int kTB = VXRT_TRACE_BLOCK;
 constexpr int kTileW = kTB == 64 ? 8 : 16, kTileH = kTB == 256 ? 16 : 8;
 
 __global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const TraceArgs a) {
-    extern __shared__ uint2 lds_stack[];  // [stack_levels][kBlock]
+    extern __shared__ uint2 lds_stack[];  // [stack_levels][kTB]
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    // 16x16 pixel tile per block, one 8x8 sub-tile per wave.  Blocks take tiles in the order of tile_order
-    // (longest tile of the previous frame first): a frame's cost is concentrated in the tiles that see
+    // One kTileW x kTileH pixel tile per block, an 8x8 sub-tile per wave.  Blocks take tiles in the order of tile_order
+    // (longest tile of the previous frames first): a frame's cost is concentrated in the tiles that see
     // geometry, and started last they would leave the chip idling behind a few long waves.
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     const unsigned tiles_x = unsigned(a.band.width + kTileW - 1) / unsigned(kTileW);
