@@ -129,7 +129,7 @@ struct vxrt_ctx {
     int trace_variant = 0;
     // tracer 0 (auto): scenes that do not fit the 256 MB Infinity Cache use the all-in-one kernel — compacting paths trades
     // the locality of a tile's rays for lane utilisation, which loses once SVO gathers go to HBM (config 5, 5.6 GiB:
-    // 2.56 vs 3.39 ms per 4K frame)
+    // 2.29 vs 3.30 ms per 4K frame)
     bool auto_tracer = false;
     int shade_blocks = 1024;
     unsigned rays_per_wave = 256;  // ray-queue tracer: fewest rays a trace wave takes (more = better lane refill, fewer waves)
