@@ -3,7 +3,10 @@ the window — a camera path, N frames of trace -> temporal -> denoise, and imag
 
     python -m gpu_voxel_raytracer_amd.frame_loop --scene menger --frames 32 --radius 2 --out gpurun_out/menger
 
-Scenes: a fixture name (tests/golden/scenes/*.npz), a .vox file, or `menger:<level>[:clip[:emissive_period]]`.
+Scenes: a fixture name (tests/golden/scenes/*.npz), a .vox file (`--whole-scene`: every model of its scene graph),
+`menger:<level>[:clip[:emissive_period]]`, or `default[:seed]` = the reference's start-up scene and camera
+(src/context.rs:838-910, 618-622).  `--noise blue` generates the blue-noise table on the GPU, `--noise <file.zip>` loads
+one in the reference's resource format.
 The reference shows `denoised_color` through an sRGB swap chain without tone mapping (shaders/display.frag,
 src/context.rs:1352-1403); the PNGs are written the same way (clamp to [0,1], sRGB encode)."""
 import argparse
@@ -32,8 +35,13 @@ def srgb8(rgb):
     return (y * 255.0 + 0.5).astype(np.uint8)
 
 
-def load_into(ctx, scene):
-    """Returns the model size (x, y, z in file axes) used for camera placement."""
+def load_into(ctx, scene, whole_scene=False):
+    """Returns the model size (x, y, z in file axes) used for camera placement (None: keep the reference's start camera)."""
+    from . import host
+    if scene.startswith("default"):
+        seed = int(scene.split(":")[1]) if ":" in scene else 1
+        ctx.recreate_octree(*host.default_scene_voxels(seed))
+        return None
     if scene.startswith("menger:"):
         parts = [int(p) for p in scene.split(":")[1:]] + [0, 0]
         level, clip, period = parts[0], parts[1], parts[2]
@@ -41,9 +49,12 @@ def load_into(ctx, scene):
         side = min(3 ** level, clip or 3 ** level)
         return (side, side, side)
     if os.path.exists(scene):
-        from . import host
         data = open(scene, "rb").read()
-        pos, mrgb, size = host.vox_to_voxels(data)
+        if whole_scene:
+            pos, mrgb, (lo, hi) = host.vox_scene_to_voxels(data, host.VOX_ALL_MODELS | host.VOX_LENIENT_MATERIALS | host.VOX_REBASE)
+            size = (hi[0] + 1, hi[2] + 1, hi[1] + 1)   # renderer axes (x, z, y) -> file axes
+        else:
+            pos, mrgb, size = host.vox_to_voxels(data)
         ctx.recreate_octree(pos, mrgb)
         return size
     pos, mrgb, size = scenes.load_scene(scene)
@@ -52,15 +63,27 @@ def load_into(ctx, scene):
 
 
 def run(scene="menger", width=1280, height=720, frames=16, bounces=3, radius=0, moving=False, out=None, device=0,
-        frames_in_flight=1, dump_every=0):
+        frames_in_flight=1, dump_every=0, noise="white", spp=1, whole_scene=False):
     """Renders `frames` frames; returns the last denoised frame (float32 [h, w, 4]) and the context statistics."""
-    with Context(width, height, device=device, max_bounces=bounces, frames_in_flight=frames_in_flight) as ctx:
-        size = load_into(ctx, scene)
+    from . import host
+    with Context(width, height, device=device, max_bounces=bounces, frames_in_flight=frames_in_flight,
+                 frames_per_launch=min(max(spp, 1), 32)) as ctx:
+        if noise == "blue":
+            ctx.set_noise(host.blue_noise(device=device))
+        elif noise != "white":
+            size_px, table = host.load_blue_noise(noise)
+            if size_px != 128:
+                raise ValueError("blue noise images must be 128 x 128 (src/context.rs:1027-1032)")
+            ctx.set_noise(table)
+        size = load_into(ctx, scene, whole_scene)
         ctx.denoise_uniforms.radius = radius
         for f in range(frames):
             t = (f / max(frames, 1)) * 0.25 if moving else 0.0
-            ctx.camera = Camera(*orbit_camera(size, 0.62 + t))
-            ctx.render(ALL)
+            ctx.camera = Camera(*orbit_camera(size, 0.62 + t)) if size is not None else Camera()
+            if spp > 1:
+                ctx.render_spp(ALL, spp)
+            else:
+                ctx.render(ALL)
             if out and dump_every and (f + 1) % dump_every == 0:
                 save_png(ctx.read(DENOISED), f"{out}_{f + 1:04d}.png")
         img = ctx.read(DENOISED)
@@ -86,10 +109,13 @@ def main():
     ap.add_argument("--radius", type=int, default=0)
     ap.add_argument("--moving", action="store_true", help="orbit the camera (temporal reprojection at work)")
     ap.add_argument("--dump-every", type=int, default=0)
+    ap.add_argument("--noise", default="white", help="white (seeded stand-in), blue (void-and-cluster, made on the GPU) or an archive")
+    ap.add_argument("--spp", type=int, default=1, help="samples per pixel per displayed frame (vxrt_render_spp)")
+    ap.add_argument("--whole-scene", action="store_true", help="place every model of a .vox file's scene graph")
     ap.add_argument("--out", default="gpurun_out/frame")
     args = ap.parse_args()
     img, st = run(args.scene, args.width, args.height, args.frames, args.bounces, args.radius, args.moving, args.out,
-                  dump_every=args.dump_every)
+                  dump_every=args.dump_every, noise=args.noise, spp=args.spp, whole_scene=args.whole_scene)
     print(f"{args.scene}: {st.frames} frames, {st.rays} rays, image {img.shape[1]}x{img.shape[0]} -> {args.out}.png, "
           f"mean radiance {float(np.nanmean(img[..., :3])):.4f}")
 
