@@ -32,7 +32,8 @@ from oracle import oracle as O  # noqa: E402
 
 REF_VOX = "/root/reference/vox"
 OUT = os.path.dirname(os.path.abspath(__file__))
-SCENES = ["menger", "monu10", "castle", "3x3x3", "8x8x8", "room"]
+SCENES = ["menger", "monu10", "castle", "3x3x3", "8x8x8", "room",
+          "custom", "teapot", "nature", "chr_knight", "doom", "shelf", "monu9", "chr_sword", "monu1"]   # all 15 files of vox/
 
 
 def levels(octree):

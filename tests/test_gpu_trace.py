@@ -67,6 +67,18 @@ def test_trace_bit_exact(O, H, scenes, noise, name, w, h, bounces, camera):
         assert rays == ref_rays, "ray count"
 
 
+@pytest.mark.parametrize("name", ["custom", "teapot", "nature", "chr_knight", "doom", "shelf", "monu9", "chr_sword", "monu1"])
+def test_trace_bit_exact_remaining_reference_scenes(O, H, scenes, noise, name):
+    """The other nine files of the reference's vox/ (with the eight above: all fifteen), two views each."""
+    for camera in ("bench", "close"):
+        for (g, rays, ref) in render_both(O, H, scenes, noise, name, 192, 112, 4, frames=(1, 2), camera=camera, specularity=0.05):
+            assert_bits_equal(g[0], ref[0], f"colour {name} {camera}")
+            assert_bits_equal(g[1], ref[1], f"nd {name} {camera}")
+            assert_bits_equal(g[2], ref[2], f"albedo {name} {camera}")
+            assert rays == ref[3]
+        assert (g[1][..., 3] >= 0).any(), name     # the view sees the model
+
+
 def test_trace_specular_and_no_sun(O, H, scenes, noise):
     for kw in (dict(specularity=0.5), dict(specularity=1.0), dict(sun_strength=0.0), dict(emit=0.0, specularity=0.25)):
         for (g, rays, ref) in render_both(O, H, scenes, noise, "castle", 128, 80, 4, camera="close", **kw):
