@@ -301,9 +301,12 @@ __device__ __forceinline__ bool walkf_begin(WalkF& w, const SceneView& sc, f3 o,
 // One trip of the while(true) loop (voxels.comp:163-246) for a regular ray, max_distance = 2^30.
 __device__ __forceinline__ int walkf_step(WalkF& w, const SceneView& sc, uint2* stack) {
     if (++w.iterations >= 2048) return kWalkCap;             // voxels.comp:166-169
-    if (w.time > kAlmostInfinity) return kWalkMiss;          // voxels.comp:171-173
     const uint32_t bit = 1u << w.octant;
-    if (w.rec.masks & (bit << 8)) return kWalkLeaf;          // value < 0
+    {   // voxels.comp:171-177 as ONE branch (every divergent region costs exec-mask bookkeeping: measured + 1.7 %); the
+        // distance check comes first in the shader, so it wins when both hold
+        const bool too_far = w.time > kAlmostInfinity, leaf = (w.rec.masks & (bit << 8)) != 0u;
+        if (too_far | leaf) return too_far ? kWalkMiss : kWalkLeaf;
+    }
 
     const f3 tm = (w.center - w.o) * w.inv;                  // voxels.comp:191
     const uint32_t directional = w.octant ^ w.dir_mask;
@@ -433,19 +436,13 @@ __device__ __forceinline__ f3 node_rgb(int32_t node) {
 __device__ const float kOver255[256] = {VX_D64(0), VX_D64(64), VX_D64(128), VX_D64(192)};
 // node_color, voxels.comp:253-258
 __device__ __forceinline__ f3 node_color(int32_t node) {
-#ifdef VXRT_AB_NO_LUT
-    return node_rgb(node) / 255.0f;
-#else
     return mk3(kOver255[(node >> 16) & 0xff], kOver255[(node >> 8) & 0xff], kOver255[node & 0xff]);
-#endif
 }
 // node_emmitance, voxels.comp:260-266: ((e * emit_strength) * rgb) / 255 with e = 0 or 1.  For a voxel that does not emit
 // the numerator is 0 * emit_strength * rgb = 0 (for any finite emit_strength) and the three divisions are skipped.
 __device__ __forceinline__ f3 node_emittance(int32_t node, float emit_strength) {
     const bool emits = (node & kEmitBit) != 0;
-#ifndef VXRT_AB_NO_LUT
     if (!emits && 0.0f * emit_strength == 0.0f) return splat3(0.0f);
-#endif
     float e = emits ? 1.0f : 0.0f;
     return ((e * emit_strength) * node_rgb(node)) / 255.0f;
 }
