@@ -78,3 +78,43 @@ def test_noise_zip_reader_survives_damaged_archives(H, tmp_path):
                 assert e.status in (H.E_NOISE, H.E_INVALID)
                 bad += 1
     assert bad > 100 and ok + bad == 600
+
+
+def test_decoders_under_sanitizers(H, tmp_path):
+    """The same decoders (host-only C++, no HIP) built by g++ with AddressSanitizer + UBSan and run over damaged .vox files and
+    archives: no report, exit code 0.  (GPU AddressSanitizer is not available on the pool; this covers the code that parses
+    untrusted bytes.)"""
+    import subprocess
+    from conftest import ROOT
+    csrc = os.path.join(ROOT, "gpu_voxel_raytracer_amd", "csrc")
+    exe = str(tmp_path / "asan_host_driver")
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-ffp-contract=off",
+                            os.path.join(ROOT, "tests", "asan_host_driver.cpp"), os.path.join(csrc, "scene_host.cpp"),
+                            os.path.join(csrc, "vox_scene.cpp"), os.path.join(csrc, "noise_zip.cpp"), "-o", exe, "-lz"],
+                           capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-3000:]
+    rng = np.random.default_rng(99)
+    model = ((5, 6, 7), [(x, (x * 3) % 6, (x * 5) % 7, 1 + x % 3) for x in range(5)])
+    graph = ntrn(0, 1) + ngrp(1, [2, 4]) + ntrn(2, 3, t=(3, -2, 1), r=4 | (1 << 4)) + nshp(3, [0]) + ntrn(4, 5, t=(-9, 0, 2)) + nshp(5, [1])
+    files = []
+    for k, seed in enumerate([make_vox(), make_vox(pack=2), scene_file([model, model], graph)]):
+        for i, data in enumerate(mutations(seed, rng, 150)):
+            p = str(tmp_path / f"v{k}_{i}.vox")
+            open(p, "wb").write(data)
+            files.append(p)
+    table = rng.random((3, 16, 16), dtype=np.float32)
+    stored = str(tmp_path / "seed.zip")
+    H.save_blue_noise(stored, table, size=16)
+    deflated = str(tmp_path / "seed_deflated.zip")
+    with zipfile.ZipFile(deflated, "w", zipfile.ZIP_DEFLATED) as z:
+        for i in range(3):
+            z.writestr("%d.raw" % i, raw_image(table[i]))
+    for k, path in enumerate((stored, deflated)):
+        for i, data in enumerate(mutations(open(path, "rb").read(), rng, 150)):
+            p = str(tmp_path / f"z{k}_{i}.zip")
+            open(p, "wb").write(data)
+            files.append(p)
+    run = subprocess.run([exe] + files, capture_output=True, text=True, env={**os.environ, "ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0"})
+    assert run.returncode == 0, (run.stdout[-500:], run.stderr[-4000:])
+    assert "ERROR: AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr, run.stderr[-4000:]
+    assert run.stdout.startswith("ok ")
