@@ -62,7 +62,8 @@ struct TraceArgs {
     uint32_t frame_number;
     uint32_t launch_index;  // counts trace launches of the context (persistent kernel: which tile counter to use)
     int stack_levels;  // LDS stack entries per thread (= octree depth, >= 1)
-    Cam cam;
+    Cam cam;                 // = cams[0]: the single-frame kernels use this
+    Cam cams[kMaxBatch];     // trace_kernel: frame f of the launch is seen through cams[f] (all equal for a camera at rest)
     // per-frame constants hoisted from voxels.comp main() (identical for every pixel)
     float sun_dir[3];        // voxels.comp:296
     float sun_dir_n[3];      // normalize(sun_dir)      voxels.comp:347

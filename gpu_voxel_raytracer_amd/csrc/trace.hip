@@ -85,8 +85,9 @@ __global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const Trac
 
         const f3 sun_dir = ld3(a.sun_dir), sun_color = ld3(a.sun_color), sky = ld3(a.sky_color);
 
-        f3 o = ld3(a.cam.o);
-        f3 d = norm3((float(x) * ld3(a.cam.r) - float(y) * ld3(a.cam.u)) + ld3(a.cam.f));  // voxels.comp:299-303
+        const Cam& cam = a.cams[fb];
+        f3 o = ld3(cam.o);
+        f3 d = norm3((float(x) * ld3(cam.r) - float(y) * ld3(cam.u)) + ld3(cam.f));  // voxels.comp:299-303
 
         f3 sample = splat3(0.0f), blend = splat3(1.0f);
         uint32_t ambient_rays = 1;

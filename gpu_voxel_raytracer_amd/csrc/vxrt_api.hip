@@ -649,13 +649,20 @@ void update_bindings(vxrt_ctx* c) {
 }
 
 // The trace stage of the next g frames (parameters at rest) as ONE launch of the tracer: g ring slots, frame numbers
-// frame_number+1 .. +g.  g > 1 only with the trace_kernel-based tracers (1 and 4).  slots[k] = ring slot of frame k;
-// *first_old = the "old" camera of the first of these frames (the later ones see the current camera as their old one).
-int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* first_old) {
+// frame_number+1 .. +g.  g > 1 only with the trace_kernel-based tracers (1, 4, 5).  slots[k] = ring slot of frame k.
+// path: optional g camera poses (position, direction), one per frame; null = the camera stays where it is.  cams / olds
+// (g entries each): the camera and the "old" camera of every frame, as temporal.comp and denoise.comp of that frame see them.
+int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam* olds, const float (*path_pos)[3] = nullptr,
+                 const float (*path_dir)[3] = nullptr) {
     const uint32_t first_frame_number = c->uniforms.frame_number + 1;
     for (uint32_t k = 0; k < g; k++) {
+        if (path_pos) {
+            memcpy(c->cam_pos, path_pos[k], sizeof c->cam_pos);
+            memcpy(c->cam_dir, path_dir[k], sizeof c->cam_dir);
+        }
         update_bindings(c);
-        if (k == 0) *first_old = c->old_cam;
+        cams[k] = c->cam;
+        olds[k] = c->old_cam;
     }
     const vxrt_uniforms& u = c->uniforms;
     // next frame slots (never the temporal history) and the trace stream of this launch
@@ -691,7 +698,8 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* first_old
     a.frame_number = first_frame_number;
     a.launch_index = 0;
     a.stack_levels = c->depth < 1 ? 1 : int(c->depth);
-    a.cam = c->cam;
+    a.cam = cams[0];
+    for (uint32_t k = 0; k < g; k++) a.cams[k] = cams[k];
     // voxels.comp:296 and the other per-frame constants, evaluated once with the same operations
     f3 sun_dir = mk3(vx_cos(u.sun_yaw) * vx_cos(u.sun_pitch), -vx_sin(u.sun_pitch), vx_sin(u.sun_yaw) * vx_cos(u.sun_pitch));
     f3 sun_n = norm3(sun_dir), neg_sun_n = norm3(-sun_dir);
@@ -856,8 +864,8 @@ int vxrt_render(vxrt_ctx* c, uint32_t flags) try {
     const bool timed = (flags & VXRT_TIMED) != 0;
     if (flags & VXRT_TRACE) {
         int slot = 0;
-        Cam first_old;
-        if (int rc = trace_frames(c, 1, timed, &slot, &first_old)) return rc;
+        Cam cam, old;
+        if (int rc = trace_frames(c, 1, timed, &slot, &cam, &old)) return rc;
     }
     if (int rc = post_stages(c, flags, timed)) return rc;
     if (flags & VXRT_TRACE) c->old_cam_valid = true;  // the next frame's "old" camera is this frame's
@@ -866,32 +874,53 @@ int vxrt_render(vxrt_ctx* c, uint32_t flags) try {
 
 // `count` frames with the parameters at rest.  With vxrt_config.frames_per_launch = B > 1 the trace stage of up to B
 // consecutive frames is one launch (see trace_frames); temporal / denoise then run per frame, in frame order.
-int vxrt_render_frames(vxrt_ctx* c, uint32_t flags, uint32_t count) try {
-    if (int rc = check_render(c, flags)) return rc;
-    HIP_TRY(hipSetDevice(c->cfg.device));
+// `count` frames; frame k through camera pose k of `path_pos` / `path_dir` (null: the camera at rest), one launch per `batch` frames
+static int render_sequence(vxrt_ctx* c, uint32_t flags, uint32_t count, const float (*path_pos)[3], const float (*path_dir)[3]) {
     const bool timed = (flags & VXRT_TIMED) != 0;
     const uint32_t batch = (flags & VXRT_TRACE) && (c->trace_variant == 0 || c->trace_variant >= 4) ? uint32_t(c->batch) : 1u;
     if (batch <= 1) {
-        for (uint32_t i = 0; i < count; i++)
+        for (uint32_t i = 0; i < count; i++) {
+            if (path_pos) {
+                memcpy(c->cam_pos, path_pos[i], sizeof c->cam_pos);
+                memcpy(c->cam_dir, path_dir[i], sizeof c->cam_dir);
+            }
             if (int rc = vxrt_render(c, flags)) return rc;
+        }
         return VXRT_OK;
     }
     for (uint32_t done = 0; done < count;) {
         const uint32_t g = count - done < batch ? count - done : batch;
         int slots[kMaxBatch];
-        Cam first_old;
-        if (int rc = trace_frames(c, g, timed, slots, &first_old)) return rc;
-        const Cam at_rest = c->cam;
-        for (uint32_t k = 0; k < g; k++) {
+        Cam cams[kMaxBatch], olds[kMaxBatch];
+        if (int rc = trace_frames(c, g, timed, slots, cams, olds, path_pos ? path_pos + done : nullptr, path_dir ? path_dir + done : nullptr)) return rc;
+        for (uint32_t k = 0; k < g; k++) {   // temporal / denoise of frame k see frame k's cameras
             c->slot = slots[k];
-            c->old_cam = k == 0 ? first_old : at_rest;
+            c->cam = cams[k];
+            c->old_cam = olds[k];
             if (int rc = post_stages(c, flags, timed)) return rc;
             c->old_cam_valid = true;
         }
-        c->old_cam = g > 1 ? at_rest : first_old;
         done += g;
     }
     return VXRT_OK;
+}
+
+// `count` frames with the parameters at rest.  With vxrt_config.frames_per_launch = B > 1 the trace stage of up to B
+// consecutive frames is one launch (see trace_frames); temporal / denoise then run per frame, in frame order.
+int vxrt_render_frames(vxrt_ctx* c, uint32_t flags, uint32_t count) try {
+    if (int rc = check_render(c, flags)) return rc;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    return render_sequence(c, flags, count, nullptr, nullptr);
+} VXRT_CATCH
+
+// `count` frames along a camera path: frame k = vxrt_set_camera(positions[k], directions[k], fov) + vxrt_render(flags), with the
+// trace stage of up to frames_per_launch consecutive frames in one launch.
+int vxrt_render_path(vxrt_ctx* c, uint32_t flags, uint32_t count, const float (*positions)[3], const float (*directions)[3], float fov) try {
+    if (int rc = check_render(c, flags)) return rc;
+    if (!positions || !directions) { set_error("null argument"); return VXRT_E_INVALID; }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    c->cam_fov = fov;
+    return render_sequence(c, flags, count, positions, directions);
 } VXRT_CATCH
 
 // One displayed frame of `spp` samples per pixel: `spp` consecutive trace frames with the parameters at rest
@@ -909,9 +938,9 @@ int vxrt_render_spp(vxrt_ctx* c, uint32_t flags, uint32_t spp) try {
     for (uint32_t done = 0; done < spp;) {
         const uint32_t g = spp - done < batch ? spp - done : batch;
         int slots[kMaxBatch];
-        Cam old_of_group;
-        if (int rc = trace_frames(c, g, timed, slots, &old_of_group)) return rc;
-        if (done == 0) first_old = old_of_group;
+        Cam cams[kMaxBatch], olds[kMaxBatch];
+        if (int rc = trace_frames(c, g, timed, slots, cams, olds)) return rc;
+        if (done == 0) first_old = olds[0];
         if (spp > 1 && pixels > 0) {
             SppArgs a{};
             for (uint32_t k = 0; k < g; k++) {

@@ -67,7 +67,7 @@ def run(scene="menger", width=1280, height=720, frames=16, bounces=3, radius=0, 
     """Renders `frames` frames; returns the last denoised frame (float32 [h, w, 4]) and the context statistics."""
     from . import host
     with Context(width, height, device=device, max_bounces=bounces, frames_in_flight=frames_in_flight,
-                 frames_per_launch=min(max(spp, 1), 32)) as ctx:
+                 frames_per_launch=min(max(spp, 1), 32) if spp > 1 else min(max(frames, 1), 16)) as ctx:
         if noise == "blue":
             ctx.set_noise(host.blue_noise(device=device))
         elif noise != "white":
@@ -77,6 +77,11 @@ def run(scene="menger", width=1280, height=720, frames=16, bounces=3, radius=0, 
             ctx.set_noise(table)
         size = load_into(ctx, scene, whole_scene)
         ctx.denoise_uniforms.radius = radius
+        if spp == 1 and size is not None and not (out and dump_every):
+            # nothing to dump in between: the whole camera path in one call, several frames per trace launch
+            path = [orbit_camera(size, 0.62 + ((f / max(frames, 1)) * 0.25 if moving else 0.0)) for f in range(frames)]
+            ctx.render_path(ALL, [p[0] for p in path], [p[1] for p in path], path[0][2])
+            frames = 0
         for f in range(frames):
             t = (f / max(frames, 1)) * 0.25 if moving else 0.0
             ctx.camera = Camera(*orbit_camera(size, 0.62 + t)) if size is not None else Camera()

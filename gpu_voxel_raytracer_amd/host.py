@@ -356,6 +356,18 @@ class Context:
         self.update_bindings()
         _check(lib().vxrt_render_frames(self._h, C.c_uint32(flags), C.c_uint32(count)), "vxrt_render_frames")
 
+    def render_path(self, flags, positions, directions, fov=None):
+        """Frames along a camera path (vxrt_render_path): frame k is seen from positions[k] towards directions[k]."""
+        pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        dirs = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
+        if len(pos) != len(dirs):
+            raise ValueError("one direction per position")
+        self.update_bindings()
+        fov = self.camera.fov if fov is None else float(np.float32(fov))
+        _check(lib().vxrt_render_path(self._h, C.c_uint32(flags), C.c_uint32(len(pos)), _p(pos), _p(dirs), C.c_float(fov)), "vxrt_render_path")
+        if len(pos):
+            self.camera = Camera(pos[-1], dirs[-1], fov)
+
     def render_spp(self, flags, spp):
         """One displayed frame of `spp` samples per pixel (vxrt_render_spp): spp trace frames averaged, then temporal / denoise."""
         self.update_bindings()

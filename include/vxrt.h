@@ -175,6 +175,10 @@ void vxrt_default_denoise(vxrt_denoise* d);     /* DenoiseUniforms::default(),  
 int vxrt_render(vxrt_ctx* ctx, uint32_t flags);
 /* `count` consecutive frames with the parameters currently set (camera at rest): count x vxrt_render. */
 int vxrt_render_frames(vxrt_ctx* ctx, uint32_t flags, uint32_t count);
+/* `count` frames along a camera path: frame k = vxrt_set_camera(positions[k], directions[k], fov) + vxrt_render(flags) — the
+ * fly-through Context::update drives interactively (src/context.rs:1959-2001) — with up to frames_per_launch consecutive
+ * frames per trace launch (each frame through its own camera; temporal reprojects from the previous frame's). */
+int vxrt_render_path(vxrt_ctx* ctx, uint32_t flags, uint32_t count, const float (*positions)[3], const float (*directions)[3], float fov);
 /* One displayed frame of `spp` samples per pixel, as BASELINE's "N spp" is defined in SURVEY.md 8d: spp consecutive trace
  * frames (frame_number advances by spp, parameters at rest) averaged with equal weights — binary32 sum in frame order,
  * one division — then temporal / denoise (per flags) once on the average.  The reference itself takes one sample per

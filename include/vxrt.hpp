@@ -178,6 +178,16 @@ class Context {
         check(vxrt_set_denoise(ctx_, &denoise_uniforms), "vxrt_set_denoise");
         check(vxrt_render_frames(ctx_, flags, count), "vxrt_render_frames");
     }
+    // frames along a camera path (vxrt_render_path); `camera` ends at the last pose
+    void render_path(uint32_t flags, const std::vector<Vec3>& positions, const std::vector<Vec3>& directions) {
+        if (positions.size() != directions.size()) throw Error(VXRT_E_INVALID, "render_path: one direction per position");
+        check(vxrt_set_scene_params(ctx_, &uniforms), "vxrt_set_scene_params");
+        check(vxrt_set_temporal(ctx_, &temporal_uniforms), "vxrt_set_temporal");
+        check(vxrt_set_denoise(ctx_, &denoise_uniforms), "vxrt_set_denoise");
+        check(vxrt_render_path(ctx_, flags, uint32_t(positions.size()), reinterpret_cast<const float(*)[3]>(positions.data()),
+                               reinterpret_cast<const float(*)[3]>(directions.data()), camera.fov), "vxrt_render_path");
+        if (!positions.empty()) { camera.position = positions.back(); camera.direction = directions.back(); }
+    }
     // one displayed frame of `spp` samples per pixel (vxrt_render_spp)
     void render_spp(uint32_t flags, uint32_t spp) {
         check(vxrt_set_camera(ctx_, camera.position.data(), camera.direction.data(), camera.fov), "vxrt_set_camera");

@@ -340,3 +340,33 @@ def test_samples_per_pixel(O, H, scenes, noise, spp, batch, inflight):
         with Context(w, h) as ctx:
             ctx.recreate_octree(pos, mrgb)
             ctx.render_spp(ALL, 0)
+
+
+@pytest.mark.parametrize("batch,inflight", [(4, 2), (16, 1), (3, 3)])
+def test_camera_path_batched_equals_frame_by_frame(O, H, scenes, noise, batch, inflight):
+    """vxrt_render_path: frames along a moving camera, several per trace launch (each through its own camera, temporal reprojecting
+    from the previous frame's) == set_camera + render, frame by frame — which test_moving_camera_reprojection pins to the oracle."""
+    from gpu_voxel_raytracer_amd import ALL, TRACE, Camera, Context
+    w, h, bounces, radius = 144, 96, 4, 2
+    pos, mrgb, size = scenes.load_scene("castle")
+    p0, d0, fov = scenes.close_camera(size)
+    n = 11
+    path_p = np.stack([p0 + np.float32(0.05 * k) * np.array([1, 0.2, 0.3], np.float32) for k in range(n)]).astype(np.float32)
+    path_d = np.stack([d0 + np.float32(0.01 * k) * np.array([0, 1, 0], np.float32) for k in range(n)]).astype(np.float32)
+    with Context(w, h, max_bounces=bounces, noise=noise) as one, \
+            Context(w, h, max_bounces=bounces, noise=noise, frames_per_launch=batch, frames_in_flight=inflight) as many:
+        for ctx in (one, many):
+            ctx.recreate_octree(pos, mrgb)
+            ctx.denoise_uniforms.radius = radius
+        for flags, lo, hi in ((ALL, 0, 5), (TRACE, 5, 7), (ALL, 7, n)):
+            for k in range(lo, hi):
+                one.camera = Camera(path_p[k], path_d[k], fov)
+                one.render(flags)
+            many.render_path(flags, path_p[lo:hi], path_d[lo:hi], fov)
+            for img, label in zip(range(5), ("colour", "nd", "albedo", "accum", "denoised")):
+                assert_bits_equal(many.read(img), one.read(img), f"{label} after frames {lo}..{hi - 1}, batch {batch}")
+            assert many.stats().rays == one.stats().rays
+        # and a frame at rest afterwards still reprojects from the path's last camera
+        one.render(ALL)
+        many.render(ALL)
+        assert_bits_equal(many.read(3), one.read(3), "accum after the path")
