@@ -126,6 +126,9 @@ struct RayQueue {
 };
 
 hipError_t launch_trace(const TraceArgs& a, hipStream_t s);
+// test hook: the walk (cast_ray) for caller-given rays; out = 8 floats per ray (hit, time, bits(leaf word), normal, 0, 0)
+hipError_t launch_path_log(const TraceArgs& a, int x, int y, float* log, hipStream_t s);
+hipError_t launch_cast_probe(const TraceArgs& a, const float* origins, const float* dirs, float* out, unsigned n, hipStream_t s);
 unsigned trace_tile_count(int width, int local_rows);  // blocks per frame of trace_kernel = entries of a tile schedule
 void trace_tile_dims(int* w, int* h);                  // pixels per block  // monolithic: one pixel per lane, all bounces
 // ray queues: primary_kernel, then shade / trace-rays launches per path segment with per-lane ray refill

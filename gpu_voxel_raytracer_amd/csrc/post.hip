@@ -288,6 +288,22 @@ __global__ void detmath_probe_kernel(int fn, const float* x, const float* y, flo
             v = dot3(a, b) + len3(b);
             break;
         }
+        case 9: case 10: {  // the y / z of random_hemisphere (voxels.comp:277-287) before the flip: signs of zero matter there
+            float phi = (2.0f * 3.14159265358979f) * x[i];
+            float rx = 2.0f * y[i] - 1.0f;
+            float plane_radius = vx_sqrt(1.0f - rx * rx);
+            v = fn == 9 ? plane_radius * vx_cos(phi) : plane_radius * vx_sin(phi);
+            break;
+        }
+        case 11: v = x[i] * y[i]; break;
+        case 12: v = x[i] - y[i]; break;
+        case 13: v = x[i] - y[i] * vx_min0(2.0f * x[i]); break;
+        case 14: v = vx_min(x[i], y[i]); break;
+        case 15: v = vx_max(x[i], y[i]); break;
+        case 16: v = vx_max(0.0f, x[i]) * y[i]; break;
+        case 17: v = vx_sign(x[i]) * y[i]; break;
+        case 18: v = vx_clamp(x[i], y[i], 1.0f); break;
+        case 19: v = vx_min0(x[i]) * y[i]; break;
     }
     out[i] = v;
 }

@@ -258,6 +258,73 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(uint32_t* cost, uint3
 
 }  // namespace
 
+namespace {
+// Test hook (vxrt_debug_cast_rays): cast_ray — the walk every tracer uses — for caller-given rays, one lane per ray.
+// out: 8 floats per ray = hit flag, time, bits(leaf word), normal xyz, 0, 0.
+__global__ __launch_bounds__(kTB) void cast_probe_kernel(const TraceArgs a, const float* origins, const float* dirs, float* out, unsigned n) {
+    extern __shared__ uint2 lds_stack[];
+    const unsigned i = blockIdx.x * kTB + threadIdx.x;
+    if (i >= n) return;
+    const SceneView sc = make_scene(a);
+    RayHit hit;
+    hit.time = 0.0f; hit.node = 0; hit.normal = splat3(0.0f);
+    const bool ok = cast_ray(sc, ld3(origins + 3 * i), ld3(dirs + 3 * i), kAlmostInfinity, lds_stack + threadIdx.x, hit);
+    float* o = out + 8 * size_t(i);
+    o[0] = ok ? 1.0f : 0.0f; o[1] = hit.time; o[2] = __int_as_float(hit.node);
+    o[3] = hit.normal.x; o[4] = hit.normal.y; o[5] = hit.normal.z; o[6] = 0.0f; o[7] = 0.0f;
+}
+// Test hook (vxrt_debug_path_log): one pixel's path with every cast logged — cast_ray and shade_hit, the code of all tracers, in one lane.
+__global__ __launch_bounds__(kTB) void path_log_kernel(const TraceArgs a, int x, int y, float* log) {
+    extern __shared__ uint2 lds_stack[];
+    if (threadIdx.x != 0) return;
+    const SceneView sc = make_scene(a);
+    Rng rng;
+    rng.noise = a.noise;
+    rng.index = uint32_t(x) % 128u + (uint32_t(y) % 128u) * 128u + (a.frame_number % 512u) * kNoiseLayer;
+    const f3 sun_dir = ld3(a.sun_dir), sun_color = ld3(a.sun_color);
+    f3 o = ld3(a.cam.o);
+    f3 d = norm3((float(x) * ld3(a.cam.r) - float(y) * ld3(a.cam.u)) + ld3(a.cam.f));
+    f3 sample = splat3(0.0f), blend = splat3(1.0f);
+    uint32_t ambient_rays = 1;
+    int casts = 0;
+    auto cast = [&](f3 ro, f3 rd, RayHit& hit) {
+        hit.time = 0.0f; hit.node = 0; hit.normal = splat3(0.0f);
+        const bool ok = cast_ray(sc, ro, rd, kAlmostInfinity, lds_stack, hit);
+        if (casts < 32) {
+            float* r = log + 12 * casts++;
+            r[0] = ro.x; r[1] = ro.y; r[2] = ro.z; r[3] = rd.x; r[4] = rd.y; r[5] = rd.z; r[6] = ok ? 1.0f : 0.0f; r[7] = hit.time;
+            r[8] = __int_as_float(hit.node); r[9] = hit.normal.x; r[10] = hit.normal.y; r[11] = hit.normal.z;
+        }
+        return ok;
+    };
+    for (int bounce = 0; bounce < a.max_bounces; bounce++) {
+        RayHit hit;
+        if (!cast(o, d, hit)) break;
+        const Shaded s = shade_hit(a, bounce, o + d * hit.time, d, hit.normal, hit.node, sample, blend, ambient_rays, rng, sun_dir, sun_color);
+        sample = s.sample; blend = s.blend; ambient_rays = s.ambient_rays;
+        if (s.flags & kFlagSun) {
+            RayHit sh;
+            cast(s.origin, s.sun_dir, sh);
+        }
+        o = s.origin;
+        d = s.bounce_dir;
+    }
+    log[12 * 32] = float(casts);
+}
+}  // namespace
+
+hipError_t launch_cast_probe(const TraceArgs& a, const float* origins, const float* dirs, float* out, unsigned n, hipStream_t s) {
+    size_t lds = size_t(a.stack_levels) * kTB * sizeof(uint2);
+    hipLaunchKernelGGL(cast_probe_kernel, dim3((n + kTB - 1) / kTB), dim3(kTB), lds, s, a, origins, dirs, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_path_log(const TraceArgs& a, int x, int y, float* log, hipStream_t s) {
+    size_t lds = size_t(a.stack_levels) * kTB * sizeof(uint2);
+    hipLaunchKernelGGL(path_log_kernel, dim3(1), dim3(kTB), lds, s, a, x, y, log);
+    return hipGetLastError();
+}
+
 // tiles (= blocks per frame) of trace_kernel: the unit of the longest-tile-first schedule
 unsigned trace_tile_count(int width, int local_rows) {
     return unsigned((width + kTileW - 1) / kTileW) * unsigned((local_rows + kTileH - 1) / kTileH);

@@ -464,7 +464,7 @@ __device__ __forceinline__ f3 random_hemisphere(f3 n, Rng& rng) {
     float plane_radius = vx_sqrt(1.0f - r.x * r.x);
     r.y = plane_radius * vx_cos(phi);
     r.z = plane_radius * vx_sin(phi);
-    return r - n * vx_min(0.0f, 2.0f * dot3(n, r));
+    return r - n * vx_min0(2.0f * dot3(n, r));  // min(0.0, .): see vx_min0
 }
 
 __device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }

@@ -648,6 +648,29 @@ void update_bindings(vxrt_ctx* c) {
     c->uniforms.frame_number += 1;  // wrapping
 }
 
+// The fields of TraceArgs that depend on the scene and the uniforms only (not on the frame slots or the launch).
+void frame_constants(const vxrt_ctx* c, TraceArgs& a) {
+    const vxrt_uniforms& u = c->uniforms;
+    a.svo = c->d_svo; a.leaves = c->d_leaves; a.noise = c->d_noise;
+    memcpy(a.root_center, c->root_center, sizeof a.root_center);
+    a.root_size = c->root_size;
+    a.band = c->band;
+    a.max_bounces = int(c->cfg.max_bounces);
+    a.launch_index = 0;
+    a.stack_levels = c->depth < 1 ? 1 : int(c->depth);
+    // voxels.comp:296 and the other per-frame constants, evaluated once with the same operations
+    f3 sun_dir = mk3(vx_cos(u.sun_yaw) * vx_cos(u.sun_pitch), -vx_sin(u.sun_pitch), vx_sin(u.sun_yaw) * vx_cos(u.sun_pitch));
+    f3 sun_n = norm3(sun_dir), neg_sun_n = norm3(-sun_dir);
+    f3 sun_color = u.sun_strength * mk3(u.sun_color[0], u.sun_color[1], u.sun_color[2]);
+    a.sun_dir[0] = sun_dir.x; a.sun_dir[1] = sun_dir.y; a.sun_dir[2] = sun_dir.z;
+    a.sun_dir_n[0] = sun_n.x; a.sun_dir_n[1] = sun_n.y; a.sun_dir_n[2] = sun_n.z;
+    a.neg_sun_dir_n[0] = neg_sun_n.x; a.neg_sun_dir_n[1] = neg_sun_n.y; a.neg_sun_dir_n[2] = neg_sun_n.z;
+    a.sun_color[0] = sun_color.x; a.sun_color[1] = sun_color.y; a.sun_color[2] = sun_color.z;
+    a.sky_color[0] = u.sky_color[0]; a.sky_color[1] = u.sky_color[1]; a.sky_color[2] = u.sky_color[2];
+    a.sun_exponent = 1.0f / (u.sun_size * u.sun_size);
+    a.sun_size = u.sun_size; a.sun_strength = u.sun_strength; a.emit_strength = u.emit_strength; a.specularity = u.specularity;
+}
+
 // The trace stage of the next g frames (parameters at rest) as ONE launch of the tracer: g ring slots, frame numbers
 // frame_number+1 .. +g.  g > 1 only with the trace_kernel-based tracers (1, 4, 5).  slots[k] = ring slot of frame k.
 // path: optional g camera poses (position, direction), one per frame; null = the camera stays where it is.  cams / olds
@@ -664,7 +687,6 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
         cams[k] = c->cam;
         olds[k] = c->old_cam;
     }
-    const vxrt_uniforms& u = c->uniforms;
     // next frame slots (never the temporal history) and the trace stream of this launch
     int s = c->slot;
     for (uint32_t k = 0; k < g; k++) {
@@ -681,7 +703,7 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
     }
 
     TraceArgs a;
-    a.svo = c->d_svo; a.leaves = c->d_leaves; a.noise = c->d_noise;
+    frame_constants(c, a);
     for (uint32_t k = 0; k < g; k++) {
         const vxrt_ctx::Slot& sl = c->ring[size_t(slots[k])];
         a.out[k] = FrameOut{sl.sampled_color, sl.nd, sl.albedo};
@@ -691,26 +713,9 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
     a.ray_counter = c->d_rays;
     a.tile_order = (c->use_tile_order && sched.valid) ? sched.order : nullptr;
     a.tile_cost = c->use_tile_order ? sched.cost : nullptr;
-    memcpy(a.root_center, c->root_center, sizeof a.root_center);
-    a.root_size = c->root_size;
-    a.band = c->band;
-    a.max_bounces = int(c->cfg.max_bounces);
     a.frame_number = first_frame_number;
-    a.launch_index = 0;
-    a.stack_levels = c->depth < 1 ? 1 : int(c->depth);
     a.cam = cams[0];
     for (uint32_t k = 0; k < g; k++) a.cams[k] = cams[k];
-    // voxels.comp:296 and the other per-frame constants, evaluated once with the same operations
-    f3 sun_dir = mk3(vx_cos(u.sun_yaw) * vx_cos(u.sun_pitch), -vx_sin(u.sun_pitch), vx_sin(u.sun_yaw) * vx_cos(u.sun_pitch));
-    f3 sun_n = norm3(sun_dir), neg_sun_n = norm3(-sun_dir);
-    f3 sun_color = u.sun_strength * mk3(u.sun_color[0], u.sun_color[1], u.sun_color[2]);
-    a.sun_dir[0] = sun_dir.x; a.sun_dir[1] = sun_dir.y; a.sun_dir[2] = sun_dir.z;
-    a.sun_dir_n[0] = sun_n.x; a.sun_dir_n[1] = sun_n.y; a.sun_dir_n[2] = sun_n.z;
-    a.neg_sun_dir_n[0] = neg_sun_n.x; a.neg_sun_dir_n[1] = neg_sun_n.y; a.neg_sun_dir_n[2] = neg_sun_n.z;
-    a.sun_color[0] = sun_color.x; a.sun_color[1] = sun_color.y; a.sun_color[2] = sun_color.z;
-    a.sky_color[0] = u.sky_color[0]; a.sky_color[1] = u.sky_color[1]; a.sky_color[2] = u.sky_color[2];
-    a.sun_exponent = 1.0f / (u.sun_size * u.sun_size);
-    a.sun_size = u.sun_size; a.sun_strength = u.sun_strength; a.emit_strength = u.emit_strength; a.specularity = u.specularity;
     if (c->band.local_rows > 0) {
         EventPair p;
         if (timed) { p = take_pair(c, 0); HIP_TRY(hipEventRecord(p.a, ts)); }
@@ -1325,6 +1330,68 @@ int vxrt_default_scene_voxels(uint32_t seed, int16_t (*pos)[3], uint8_t (*mrgb)[
         if (pos) { pos[i][0] = v.x; pos[i][1] = v.y; pos[i][2] = v.z; }
         if (mrgb) { mrgb[i][0] = v.m; mrgb[i][1] = v.r; mrgb[i][2] = v.g; mrgb[i][3] = v.b; }
     }
+    return VXRT_OK;
+} VXRT_CATCH
+
+// Test hook: cast_bounded_ray (voxels.comp:134-247) as the kernels implement it, for caller-given rays of the current scene.
+int vxrt_debug_cast_rays(vxrt_ctx* c, const float* origins, const float* dirs, size_t n, uint8_t* hit, float* time, int32_t* node, float* normal) try {
+    if (!valid_ctx(c) || !origins || !dirs || !hit || !time || !node || !normal) { set_error("null argument"); return VXRT_E_INVALID; }
+    if (!c->has_scene) { set_error("no scene set"); return VXRT_E_NOSCENE; }
+    if (n == 0) return VXRT_OK;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = vxrt_sync(c)) return rc;
+    float *d_o = nullptr, *d_d = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_o), n * 12));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_d), n * 12));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), n * 32));
+    HIP_TRY(hipMemcpy(d_o, origins, n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_d, dirs, n * 12, hipMemcpyHostToDevice));
+    TraceArgs a{};
+    a.svo = c->d_svo; a.leaves = c->d_leaves;
+    memcpy(a.root_center, c->root_center, sizeof a.root_center);
+    a.root_size = c->root_size;
+    a.stack_levels = c->depth < 1 ? 1 : int(c->depth);
+    HIP_TRY(launch_cast_probe(a, d_o, d_d, d_out, unsigned(n), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<float> out(n * 8);
+    HIP_TRY(hipMemcpy(out.data(), d_out, n * 32, hipMemcpyDeviceToHost));
+    (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_out);
+    for (size_t i = 0; i < n; i++) {
+        hit[i] = out[8 * i] != 0.0f;
+        time[i] = out[8 * i + 1];
+        memcpy(&node[i], &out[8 * i + 2], 4);
+        normal[3 * i] = out[8 * i + 3]; normal[3 * i + 1] = out[8 * i + 4]; normal[3 * i + 2] = out[8 * i + 5];
+    }
+    return VXRT_OK;
+} VXRT_CATCH
+
+// Test hook: the path of ONE pixel of the next frame (frame_number + 1, the camera as set), cast by cast, as the kernels compute it
+// (cast_ray and shade_hit of trace_common.h, in voxels.comp's order).  log: 12 floats per cast = origin, direction, hit flag, time,
+// bits(leaf word), normal; at most 32 casts.  Nothing is rendered and no context state changes, apart from the camera basis.
+int vxrt_debug_path_log(vxrt_ctx* c, int32_t x, int32_t y, float* log, int32_t* casts) try {
+    if (!valid_ctx(c) || !log || !casts) { set_error("null argument"); return VXRT_E_INVALID; }
+    if (!c->has_scene) { set_error("no scene set"); return VXRT_E_NOSCENE; }
+    if (x < 0 || y < 0 || x >= int(c->cfg.width) || y >= int(c->cfg.height)) { set_error("pixel outside the frame"); return VXRT_E_INVALID; }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = vxrt_sync(c)) return rc;
+    const Cam keep_cam = c->cam, keep_old = c->old_cam;
+    const vxrt_uniforms keep_u = c->uniforms;
+    update_bindings(c);
+    TraceArgs a{};
+    frame_constants(c, a);
+    a.frame_number = c->uniforms.frame_number;
+    a.cam = c->cam;
+    a.batch = 1;
+    c->cam = keep_cam; c->old_cam = keep_old; c->uniforms = keep_u;
+    float* d_log = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_log), (12 * 32 + 1) * sizeof(float)));
+    HIP_TRY(launch_path_log(a, x, y, d_log, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<float> out(12 * 32 + 1);
+    HIP_TRY(hipMemcpy(out.data(), d_log, out.size() * sizeof(float), hipMemcpyDeviceToHost));
+    (void)hipFree(d_log);
+    *casts = int32_t(out[12 * 32]);
+    memcpy(log, out.data(), size_t(*casts) * 12 * sizeof(float));
     return VXRT_OK;
 } VXRT_CATCH
 

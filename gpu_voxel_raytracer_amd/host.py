@@ -246,7 +246,7 @@ def menger_voxels(level, mrgb=(0, 0xb0, 0xd0, 0x60), clip=0, emissive_period=0):
 
 
 def detmath_probe(fn, x, y=None, device=0):
-    names = {"sin": 0, "cos": 1, "exp": 2, "log": 3, "pow": 4, "sqrt": 5, "div": 6, "tan": 7, "chain": 8}
+    names = {"sin": 0, "cos": 1, "exp": 2, "log": 3, "pow": 4, "sqrt": 5, "div": 6, "tan": 7, "chain": 8, "hemi_y": 9, "hemi_z": 10, "mul": 11, "sub": 12, "flip": 13, "min": 14, "max": 15, "max0": 16, "sign": 17, "clamp": 18, "min0": 19}
     x = np.ascontiguousarray(x, np.float32)
     y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), np.float32)
     out = np.zeros_like(x)
@@ -355,6 +355,23 @@ class Context:
         """`count` frames with the current camera and parameters in one call (vxrt_render_frames)."""
         self.update_bindings()
         _check(lib().vxrt_render_frames(self._h, C.c_uint32(flags), C.c_uint32(count)), "vxrt_render_frames")
+
+    def cast_rays(self, origins, dirs):
+        """Test hook (vxrt_debug_cast_rays): the kernels' cast_bounded_ray for given rays -> (hit bool[n], time, node int32, normal[n,3])."""
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        n = len(o)
+        hit, time, node, normal = np.zeros(n, np.uint8), np.zeros(n, np.float32), np.zeros(n, np.int32), np.zeros((n, 3), np.float32)
+        _check(lib().vxrt_debug_cast_rays(self._h, _p(o), _p(d), C.c_size_t(n), _p(hit), _p(time), _p(node), _p(normal)), "vxrt_debug_cast_rays")
+        return hit.astype(bool), time, node, normal
+
+    def path_log(self, x, y):
+        """Test hook (vxrt_debug_path_log): the casts of pixel (x, y) of the next frame -> float32[casts, 12]
+        (origin, direction, hit, time, bits(leaf word), normal)."""
+        self.update_bindings()
+        log, n = np.zeros((32, 12), np.float32), C.c_int32(0)
+        _check(lib().vxrt_debug_path_log(self._h, C.c_int32(x), C.c_int32(y), _p(log), C.byref(n)), "vxrt_debug_path_log")
+        return log[:n.value]
 
     def render_path(self, flags, positions, directions, fov=None):
         """Frames along a camera path (vxrt_render_path): frame k is seen from positions[k] towards directions[k]."""

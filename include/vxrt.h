@@ -262,6 +262,16 @@ int vxrt_set_menger(vxrt_ctx* ctx, uint32_t level, uint32_t clip, const uint8_t 
  * host-vs-device bit equality the numeric contract promises can be checked. */
 int vxrt_detmath_probe(int32_t device, int32_t fn, const float* x, const float* y, float* out, size_t n);
 
+/* Test hook: cast_bounded_ray (shaders/voxels.comp:134-247, max_distance 2^30) as the kernels implement it, for n caller-given
+ * rays (origins, dirs: 3 floats each) through the current scene: hit flag, time, leaf word, normal (3 floats) per ray. */
+int vxrt_debug_cast_rays(vxrt_ctx* ctx, const float* origins, const float* dirs, size_t n, uint8_t* hit, float* time, int32_t* node,
+                         float* normal);
+
+/* Test hook: the path of pixel (x, y) of the NEXT frame (frame_number + 1, camera as set), cast by cast, as the kernels compute it.
+ * log: room for 32 casts of 12 floats = origin, direction, hit flag, time, bits(leaf word), normal; *casts = how many were made.
+ * Renders nothing and leaves the context as it was. */
+int vxrt_debug_path_log(vxrt_ctx* ctx, int32_t x, int32_t y, float* log, int32_t* casts);
+
 /* Diagnostics: duration (shader clocks) of each 16x16 tile of the last traced frame, row-major over
  * ceil(width/16) x ceil(local_rows/16) tiles — the data the longest-tile-first scheduler works from. */
 int vxrt_debug_tile_costs(vxrt_ctx* ctx, uint32_t* out, size_t n);

@@ -32,6 +32,14 @@ VX_HD float vx_u2f(uint32_t u) { union { float f; uint32_t u; } c; c.u = u; retu
 /* ---- GLSL min/max/sign/abs/clamp/mix, literally as the GLSL 4.50 spec words them ------------- */
 /* min(x,y): "Returns y if y < x, otherwise it returns x" — NaN behaviour follows from that. */
 VX_HD float vx_min(float x, float y) { return (y < x) ? y : x; }
+/* min(0.0, v) — the form voxels.comp:285 uses — on integer bits: v if v < 0 (sign set, not -0, not NaN), else +0.0.
+ * Written this way because the gfx950 backend turns `(v < 0.0f) ? v : 0.0f` into v_min_f32 0, v, which returns -0.0
+ * for v = -0.0 where the GLSL wording (and g++) return +0.0; a bounce direction with a different sign of zero then
+ * takes a different octant at the next cast.  Use this wherever the first argument of min() is the constant zero. */
+VX_HD float vx_min0(float v) {
+    uint32_t b = vx_f2u(v);
+    return (b > 0x80000000u && b <= 0xff800000u) ? v : 0.0f;
+}
 /* max(x,y): "Returns y if x < y, otherwise it returns x". */
 VX_HD float vx_max(float x, float y) { return (x < y) ? y : x; }
 /* sign(x): 1.0 if x > 0, 0.0 if x = 0, -1.0 if x < 0 (NaN -> 0.0). */

@@ -198,6 +198,13 @@ def trace(octree, noise, uniforms, width, height, max_bounces=3, crop=None, nthr
     return color, nd, alb, int(rays)
 
 
+def path_log(octree, noise, uniforms, max_bounces, x, y):
+    """The casts of one pixel's path (orc_trace_pixel_log) -> float32[casts, 12] = origin, direction, hit, time, bits(leaf word), normal."""
+    log = np.zeros((32, 12), np.float32)
+    n = lib().orc_trace_pixel_log(_p(octree), _p(noise), C.byref(uniforms), C.c_int(max_bounces), C.c_int(x), C.c_int(y), _p(log))
+    return log[:n]
+
+
 def cast_rays(octree, origins, dirs, max_distance=float(1 << 30)):
     origins = np.ascontiguousarray(origins, np.float32)
     dirs = np.ascontiguousarray(dirs, np.float32)
@@ -264,7 +271,7 @@ def cpu_rs_render(coords_u16, rgb_u8, cam_pos, basis9, width, height, time=0.0):
 
 
 def detmath(fn, x, y=None):
-    names = {"sin": 0, "cos": 1, "exp": 2, "log": 3, "pow": 4, "sqrt": 5, "div": 6, "tan": 7}
+    names = {"sin": 0, "cos": 1, "exp": 2, "log": 3, "pow": 4, "sqrt": 5, "div": 6, "tan": 7, "hemi_y": 9, "hemi_z": 10, "mul": 11, "sub": 12, "flip": 13, "min": 14, "max": 15, "max0": 16, "sign": 17, "clamp": 18, "min0": 19}
     x = np.ascontiguousarray(x, np.float32)
     y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), np.float32)
     out = np.zeros_like(x)

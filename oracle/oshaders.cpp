@@ -64,6 +64,14 @@ static uint32_t current_octant(V3 position, V3 center) {
 
 thread_local long long g_iterations = 0;  // diagnostic: octree steps taken by this thread
 thread_local int* g_phase_steps = nullptr;  // diagnostic: steps of each successive ray of the current pixel
+thread_local float* g_ray_log = nullptr;    // diagnostic: 12 floats per cast of the current pixel (origin, dir, hit, time, node bits, normal)
+thread_local int g_ray_log_n = 0;
+static void log_ray(V3 o, V3 d, bool hit, const orc::Hit& h) {
+    if (!g_ray_log || g_ray_log_n >= 32) return;
+    float* r = g_ray_log + 12 * g_ray_log_n++;
+    r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z; r[6] = hit ? 1.0f : 0.0f; r[7] = h.time;
+    memcpy(&r[8], &h.node, 4); r[9] = h.normal.x; r[10] = h.normal.y; r[11] = h.normal.z;
+}
 thread_local int g_phase = 0;
 
 // voxels.comp:134-247
@@ -238,6 +246,7 @@ static int trace_pixel(const int32_t* octree, const float* noise, const OrcUnifo
         rays++;
         bool primary_hit = cast_bounded_ray(octree, ray_origin, ray_dir, ALMOST_INFINITY, &h);
         if (g_phase_steps && g_phase < 32) g_phase_steps[g_phase++] = h.iterations;
+        log_ray(ray_origin, ray_dir, primary_hit, h);
         if (primary_hit) {
             V3 normal = h.normal;
             V3 hit_pos = ray_origin + ray_dir * h.time;
@@ -267,6 +276,7 @@ static int trace_pixel(const int32_t* octree, const float* noise, const OrcUnifo
                     rays++;
                     bool sun_obstructed = cast_bounded_ray(octree, hit_pos + 1e-5f * normal, normalize(-light_dir), ALMOST_INFINITY, &sh);
                     if (g_phase_steps && g_phase < 32) g_phase_steps[g_phase++] = sh.iterations;
+                    log_ray(hit_pos + 1e-5f * normal, normalize(-light_dir), sun_obstructed, sh);
                     ambient_rays++;
                     if (!sun_obstructed) {
                         sample_color = sample_color + ((sun_color * color) * blending_factor) * vx_max(0.0f, dot(normal, normalize(-light_dir)));
@@ -391,6 +401,16 @@ void orc_trace_steps(const int32_t* octree, const float* noise, const OrcUniform
             row[0] = (int32_t)(g_iterations - before);
         }
     });
+}
+
+// Diagnostic: every cast of one pixel's path: 12 floats per ray (origin, dir, hit, time, node bits, normal); returns the ray count.
+int orc_trace_pixel_log(const int32_t* octree, const float* noise, const OrcUniforms* u, int max_bounces, int x, int y, float* log) {
+    float c[4], n[4], a[4];
+    g_ray_log = log;
+    g_ray_log_n = 0;
+    trace_pixel(octree, noise, *u, max_bounces, x, y, c, n, a);
+    g_ray_log = nullptr;
+    return g_ray_log_n;
 }
 
 // Batch of single rays through cast_bounded_ray — for traversal unit tests and the DDA cross-check.
@@ -533,6 +553,22 @@ void orc_detmath(int fn, const float* x, const float* y, float* out, size_t n) {
             case 5: out[i] = vx_sqrt(x[i]); break;
             case 6: out[i] = x[i] / y[i]; break;
             case 7: out[i] = vx_tan(x[i]); break;
+            case 9: case 10: {  // y / z of random_hemisphere before the flip
+                float phi = (2.0f * 3.14159265358979f) * x[i];
+                float rx = 2.0f * y[i] - 1.0f;
+                float plane_radius = vx_sqrt(1.0f - rx * rx);
+                out[i] = fn == 9 ? plane_radius * vx_cos(phi) : plane_radius * vx_sin(phi);
+                break;
+            }
+            case 11: out[i] = x[i] * y[i]; break;
+            case 12: out[i] = x[i] - y[i]; break;
+            case 13: out[i] = x[i] - y[i] * vx_min(0.0f, 2.0f * x[i]); break;
+            case 14: out[i] = vx_min(x[i], y[i]); break;
+            case 15: out[i] = vx_max(x[i], y[i]); break;
+            case 16: out[i] = vx_max(0.0f, x[i]) * y[i]; break;
+            case 17: out[i] = vx_sign(x[i]) * y[i]; break;
+            case 18: out[i] = vx_clamp(x[i], y[i], 1.0f); break;
+            case 19: out[i] = vx_min(0.0f, x[i]) * y[i]; break;  // the GLSL wording; the device's vx_min0 must equal it
             default: out[i] = 0.0f;
         }
     }

@@ -39,3 +39,18 @@ def test_div_pow_bit_equal(O, H):
     dev, cpu = H.detmath_probe("pow", xp, yp), O.detmath("pow", xp, yp)
     m = ~(np.isnan(dev) & np.isnan(cpu))
     assert np.array_equal(dev[m].view(np.uint32), cpu[m].view(np.uint32))
+
+
+SPECIAL = np.array([0.0, -0.0, 0.25, 0.5, 0.75, 0.125, 1 - 2.0 ** -24, 1.0, -1.0, 2.0, -2.0, np.inf, -np.inf, np.nan, 1e-40, -1e-40,
+                    1e-45, -1e-45, 3.0, -0.5], np.float32)
+
+
+@pytest.mark.parametrize("fn", ["hemi_y", "hemi_z", "mul", "sub", "flip", "min", "max", "max0", "sign", "clamp", "min0"])
+def test_signs_of_zero_and_special_operands(O, H, fn):
+    """Bit equality INCLUDING the sign of zero on every pair of special operands.  (A bounce direction (-1, +0, -0) and one
+    (-1, -0, -0) walk different octants: a kernel compiler that folds min(0.0, v) into v_min_f32 changed 16 pixels of a frame
+    whose noise table holds exact zeros — found by tests/test_gpu_stress.py at scale 12, fixed with vx_min0.)"""
+    x, y = [a.ravel() for a in np.meshgrid(SPECIAL, SPECIAL)]
+    dev, cpu = H.detmath_probe(fn, x, y), O.detmath(fn, x, y)
+    bad = np.flatnonzero((dev.view(np.uint32) != cpu.view(np.uint32)) & ~(np.isnan(dev) & np.isnan(cpu)))
+    assert len(bad) == 0, [(float(x[i]), float(y[i]), float(dev[i]), float(cpu[i])) for i in bad[:5]]
