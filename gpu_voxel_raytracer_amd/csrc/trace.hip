@@ -70,12 +70,7 @@ __global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const Trac
     rec.node = 0; rec.normal_ambient = 0; rec.rng_index = 0; rec.pix = 0;
     rec.hit_pos = rec.dir = rec.sample = rec.blend = splat3(0.0f);
     if (active) {
-        SceneView sc;
-        sc.svo = a.svo;
-        sc.leaves = a.leaves;
-        sc.root_center = ld3(a.root_center);
-        sc.root_size = a.root_size;
-        sc.root_min = sc.root_center - splat3(0.5f * a.root_size);
+        const SceneView sc = make_scene(a);
         uint2* stack = lds_stack + tid;
         const size_t pix = size_t(lrow) * a.band.width + x;
 

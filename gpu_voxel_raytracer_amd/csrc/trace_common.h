@@ -47,6 +47,8 @@ struct SceneView {
     f3 root_center;
     f3 root_min;
     float root_size;
+    float cell, inv_cell;  // edge of the finest cell a node's octant can be (root_size * 2^-levels), and its reciprocal
+    int levels;            // node levels 0 .. levels-1
 };
 
 // cast_bounded_ray, voxels.comp:134-247.  `stack` points at this thread's column of the LDS stack
@@ -298,6 +300,82 @@ __device__ __forceinline__ bool walkf_begin(WalkF& w, const SceneView& sc, f3 o,
     return true;
 }
 
+#ifndef VXRT_LOCATE
+#define VXRT_LOCATE 0   // measured: 0.157 vs 0.126 ms per bench frame with it (see the note below and DESIGN.md section 8)
+#endif
+
+// The initial descent of a ray that STARTS INSIDE the root cube (walkf_begin left time = 0: every secondary ray), in a loop of
+// its own.  While time is 0 the loop of voxels.comp:163-246 only descends: current_octant(origin + dir * 0, centre) picks the
+// child that holds the origin, level after level, until that octant is empty or a leaf — the path is a function of the origin
+// alone, and a secondary ray spends 6-7 of its ~10 trips on it, ~115 instructions each in walkf_step.  Here:
+//   1. the origin's cell at the finest level as integers j: cell j spans (lo_j, lo_j + cell] per axis — the strict > of
+//      current_octant — decided with exact compares against the (dyadic, exactly representable) planes;
+//   2. per level: the octant is one bit of each j; has_next and the sibling to resume with (voxels.comp:191-204, time = 0)
+//      go into the frame exactly as a walked trip would leave them; the child's far-plane times by selection; no leaf test
+//      (the octant is a child), no position, no time update (every near plane is behind the origin: max(0, <= 0) = 0);
+//   3. the walk state at the level D where the octant is no child: D trips counted, near-plane times from plane_times (what
+//      the selections would have produced: a plane's crossing time depends on the plane only).
+// Results are bit-identical to walking those trips (tests/test_gpu_trace.py, test_gpu_degenerate.py, test_gpu_scenes.py with
+// -DVXRT_LOCATE=1).  NOT the default: the loop is ~62 instructions per level against ~95 for a walked descend, but a wave in lock
+// step pays max(D) of these and then max(R) walk trips instead of max(D + R) — the descent is 7 of a wave's ~36 trips, not 6 of a
+// ray's 10 — and the second copy of the code costs 16-20 spilled registers in trace_kernel and bounce_kernel: 25 % slower.
+__device__ __forceinline__ void walkf_locate(WalkF& w, const SceneView& sc, uint2* stack) {
+    const int top = (1 << sc.levels) - 1;
+    int j[3];
+    const float oc[3] = {w.o.x, w.o.y, w.o.z}, rm[3] = {sc.root_min.x, sc.root_min.y, sc.root_min.z};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        int c = int(__builtin_floorf((oc[k] - rm[k]) * sc.inv_cell));   // within 1 of the truth (one rounding of the difference)
+        c = c < 0 ? 0 : (c > top ? top : c);
+        const float lo = rm[k] + float(c) * sc.cell;                   // exact
+        c += !(lo < oc[k]) ? -1 : (oc[k] > lo + sc.cell ? 1 : 0);
+        j[k] = c < 0 ? 0 : (c > top ? top : c);                        // on the root's faces: low side / high side, as the compares go
+    }
+    uint32_t l = 0, oct, mask = 0;
+    SvoRecord rec = w.rec;
+    f3 center = w.center, ex = w.ex;
+    float exit = w.exit, quarter = 0.25f * sc.root_size;
+    for (;;) {
+        const int sh = sc.levels - 1 - int(l);
+        const uint32_t bx = uint32_t(j[0] >> sh) & 1u, by = uint32_t(j[1] >> sh) & 1u, bz = uint32_t(j[2] >> sh) & 1u;
+        oct = bx << 2 | by << 1 | bz;
+        const uint32_t bit = 1u << oct;
+        if ((rec.masks & bit) == 0u || sh == 0) break;                 // empty or a leaf: walkf_step takes over here
+        const f3 tm = (center - w.o) * w.inv;                          // voxels.comp:191
+        const uint32_t directional = oct ^ w.dir_mask;
+        const bool far_x = (directional & 4u) != 0u, far_y = (directional & 2u) != 0u, far_z = (directional & 1u) != 0u;
+        const float mx = far_x ? kAlmostInfinity : tm.x;
+        const float my = far_y ? kAlmostInfinity : tm.y;
+        const float mz = far_z ? kAlmostInfinity : tm.z;
+        const float next_time = vx_min3(mx, my, mz);
+        const uint32_t transition = (mx == next_time) ? 4u : ((my == next_time) ? 2u : 1u);
+        const bool has_next = next_time <= exit && (directional & transition) == 0u;
+        stack[l * kStackStride] = make_uint2(rec.masks | (oct ^ transition) << 16, rec.base);   // read back only if has_next
+        mask |= (has_next ? 1u : 0u) << l;
+        const uint2 raw = *reinterpret_cast<const uint2*>(sc.svo + (rec.base + __popc(rec.masks & (bit - 1u))));
+        ex = mk3(far_x ? ex.x : tm.x, far_y ? ex.y : tm.y, far_z ? ex.z : tm.z);
+        exit = vx_min3(ex.x, ex.y, ex.z);
+        center = center + mk3(bx ? quarter : -quarter, by ? quarter : -quarter, bz ? quarter : -quarter);   // exact
+        quarter *= 0.5f;
+        rec.masks = raw.x & 0xffffu;
+        rec.base = raw.y;
+        l++;
+    }
+    if (l == 0u) return;                                               // nothing to skip
+    const int up = sc.levels - int(l);
+    w.ix = uint32_t(j[0] >> up); w.iy = uint32_t(j[1] >> up); w.iz = uint32_t(j[2] >> up);
+    w.lvl = l;
+    w.has_next_mask = mask;
+    w.iterations = int(l);
+    w.rec = rec;
+    w.octant = oct;
+    w.center = center;
+    w.ex = ex;
+    w.exit = exit;
+    const f3 hs = mk3(vx_copysign(2.0f * quarter, w.inv.x), vx_copysign(2.0f * quarter, w.inv.y), vx_copysign(2.0f * quarter, w.inv.z));
+    w.en = ((center - hs) - w.o) * w.inv;
+}
+
 // One trip of the while(true) loop (voxels.comp:163-246) for a regular ray, max_distance = 2^30.
 __device__ __forceinline__ int walkf_step(WalkF& w, const SceneView& sc, uint2* stack) {
     if (++w.iterations >= 2048) return kWalkCap;             // voxels.comp:166-169
@@ -407,6 +485,9 @@ __device__ __forceinline__ bool cast_ray(const SceneView& sc, f3 o, f3 d, float 
         WalkF w;
         entered = walkf_begin(w, sc, o, d, inv);
         if (entered) {
+#if VXRT_LOCATE
+            if (w.time == 0.0f) walkf_locate(w, sc, stack);
+#endif
             do { status = walkf_step(w, sc, stack); } while (status == kWalkOn);
             const uint32_t bit = 1u << w.octant;
             center = w.center; time = w.time; lvl = w.lvl; octant = w.octant;
@@ -584,6 +665,9 @@ __device__ __forceinline__ SceneView make_scene(const TraceArgs& a) {
     sc.root_center = ld3(a.root_center);
     sc.root_size = a.root_size;
     sc.root_min = sc.root_center - splat3(0.5f * a.root_size);
+    sc.levels = a.stack_levels;
+    sc.cell = __builtin_ldexpf(a.root_size, -a.stack_levels);
+    sc.inv_cell = 1.0f / sc.cell;
     return sc;
 }
 
