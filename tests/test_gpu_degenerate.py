@@ -49,6 +49,46 @@ def test_degenerate_noise_tables(O, H, scenes, noise, monkeypatch, label, name, 
             assert rays == ref[3]
 
 
+@pytest.mark.parametrize("label", ["zeros30", "specials"])
+@pytest.mark.parametrize("specularity,sun,emit", [(0.3, None, None), (1.0, None, 2.0), (0.0, 0.0, 3.0), (0.26, 0.0, None)])
+@pytest.mark.parametrize("name", ["menger", "room"])
+def test_degenerate_noise_other_shading_branches(O, H, scenes, noise, label, specularity, sun, emit, name):
+    """The same tables through the specular branch (reflect + normalize of degenerate vectors; 0.25 < 0.26 but not < 0.25: the
+    branch compare sits on a table value), with the sun off, and with emitters."""
+    from gpu_voxel_raytracer_amd import TRACE, Camera, Context
+    table = tables(noise)[label]
+    w, h, bounces = 192, 112, 5
+    pos, mrgb, size = scenes.load_scene(name)
+    octree = O.create_octree(pos, mrgb)
+    cam = scenes.close_camera(size)
+    u = O.Uniforms.default()
+    u.specularity = specularity
+    if sun is not None:
+        u.sun_strength = sun
+    if emit is not None:
+        u.emit_strength = emit
+    u.set_camera(cam[0], O.camera_axis_scaled(cam[0], cam[1], cam[2], w, h))
+    with Context(w, h, max_bounces=bounces, noise=table) as ctx:
+        ctx.recreate_octree(pos, mrgb)
+        ctx.camera = Camera(*cam)
+        ctx.uniforms.specularity = specularity
+        if sun is not None:
+            ctx.uniforms.sun_strength = sun
+        if emit is not None:
+            ctx.uniforms.emit_strength = emit
+        for frame in (1, 2):
+            ctx.set_frame_number(frame - 1)
+            ctx.reset_stats()
+            ctx.render(TRACE)
+            got = [ctx.read(i) for i in range(3)]
+            rays = ctx.stats().rays
+            u.frame_number = frame
+            ref = O.trace(octree, table, u, w, h, bounces, crop=(0, 0, w, h))
+            for i, what in enumerate(("colour", "normal/depth", "albedo/node")):
+                assert_bits_equal(got[i], ref[i], f"{what} {name} {label} spec {specularity} sun {sun} emit {emit} frame {frame}")
+            assert rays == ref[3]
+
+
 def test_path_log_matches_the_oracle(O, H, scenes, noise):
     """vxrt_debug_path_log: the casts of single pixels, bit for bit (signs of zero included) those of the oracle's path."""
     from gpu_voxel_raytracer_amd import Camera, Context
