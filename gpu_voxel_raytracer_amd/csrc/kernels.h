@@ -73,7 +73,7 @@ struct TraceArgs {
     float sun_exponent;      // 1.0 / pow(sun_size, 2)  voxels.comp:380
     float sun_size, sun_strength, emit_strength, specularity;
     // monolithic kernel with a compacted tail (tracer 4): a path that is still alive when it reaches hit number
-    // `tail_from` (>= 1; 0: off) is appended to `tail` instead of being followed; bounce_kernel finishes those paths
+    // `tail_from` (0 = the first hit; tail.recs == nullptr: off) is appended to `tail` instead of being followed; bounce_kernel finishes those paths
     PathQueue tail;
     unsigned* tail_zero;   // counter set to clear for a later launch (see launch_trace_wavefront)
     int tail_from;

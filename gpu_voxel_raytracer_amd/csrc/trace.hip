@@ -119,7 +119,14 @@ __global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const Trac
 
             const f3 n = hit.normal;
             const f3 hit_pos = o + d * hit.time;
-            if (bounce == a.tail_from && bounce > 0) {  // hand the path over, in the state bounce_kernel resumes from
+            const f3 color = bounce == 0 ? splat3(1.0f) : node_color(hit.node);
+            const f3 emit = node_emittance(hit.node, a.emit_strength);
+            if (bounce == 0) {  // first-hit G-buffer                           voxels.comp:320-324,392-396
+                store_out(fo.nd + pix, make_float4(n.x, n.y, n.z, hit.time));
+                f3 alb = (hit.node & kEmitBit) == 0 ? node_color(hit.node) : splat3(1.0f);
+                store_out(fo.albedo + pix, make_float4(alb.x, alb.y, alb.z, __int_as_float(hit.node)));
+            }
+            if (a.tail.recs != nullptr && bounce == a.tail_from) {  // hand the path over, in the state bounce_kernel resumes from
                 rec.hit_pos = hit_pos;
                 rec.node = hit.node;
                 rec.dir = d;
@@ -130,13 +137,6 @@ __global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const Trac
                 rec.pix = uint32_t(pix) | fb << kPixBits;
                 to_tail = true;
                 break;
-            }
-            const f3 color = bounce == 0 ? splat3(1.0f) : node_color(hit.node);
-            const f3 emit = node_emittance(hit.node, a.emit_strength);
-            if (bounce == 0) {  // first-hit G-buffer                           voxels.comp:320-324,392-396
-                store_out(fo.nd + pix, make_float4(n.x, n.y, n.z, hit.time));
-                f3 alb = (hit.node & kEmitBit) == 0 ? node_color(hit.node) : splat3(1.0f);
-                store_out(fo.albedo + pix, make_float4(alb.x, alb.y, alb.z, __int_as_float(hit.node)));
             }
 
             if (rng.next() < a.specularity) {  // specular                     voxels.comp:326-334
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const Trac
             store_out(fo.color + pix, make_float4(out.x, out.y, out.z, 1.0f));
         }
     }
-    if (a.tail_from > 0) {
+    if (a.tail.recs != nullptr) {
         zero_counts(a.tail_zero, tid);
         queue_append(a.tail, (blockIdx.x * unsigned(kTB / 64) + unsigned(wave)) % kShards, to_tail, rec, lane);
     }

@@ -483,7 +483,7 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) try {
     if (c->trace_variant >= 4 && cfg->max_bounces < 2) c->trace_variant = 0;  // no tail to compact
     if (const char* v = getenv("VXRT_PATH_BLOCKS")) c->path_blocks = atoi(v);
     if (const char* v = getenv("VXRT_TAIL_FROM")) c->tail_from = atoi(v);
-    if (c->tail_from < 1 || c->tail_from >= int(cfg->max_bounces)) c->tail_from = 1;
+    if (c->tail_from < 0 || c->tail_from >= int(cfg->max_bounces)) c->tail_from = 1;
     if (const char* v = getenv("VXRT_TAIL_SPLIT")) c->tail_split = unsigned(strtoul(v, nullptr, 0));
     if (const char* v = getenv("VXRT_SHADE_BLOCKS")) c->shade_blocks = atoi(v);
     if (const char* v = getenv("VXRT_RAYS_PER_WAVE")) c->rays_per_wave = unsigned(atoi(v));

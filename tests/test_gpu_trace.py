@@ -159,6 +159,8 @@ def test_full_size_bench_config_crops(O, H, scenes, noise):
     {"VXRT_TRACE_VARIANT": "4", "VXRT_TAIL_FROM": "2", "VXRT_INFLIGHT": "4"},           # ... tail from hit 2, frames in flight
     {"VXRT_TRACE_VARIANT": "4", "VXRT_TRACE_BLOCKS": "16", "VXRT_TILE_ORDER": "0"},     # ... few tail waves, raster tile order
     {"VXRT_TRACE_VARIANT": "4", "VXRT_TAIL_SPLIT": "0xc", "VXRT_INFLIGHT": "3"},        # ... tail compacted again at segments 2 and 3
+    {"VXRT_TRACE_VARIANT": "4", "VXRT_TAIL_FROM": "0"},                                 # ... tail from the first hit: the head casts primary rays only
+    {"VXRT_TRACE_VARIANT": "4", "VXRT_TAIL_FROM": "0", "VXRT_INFLIGHT": "3", "VXRT_TAIL_SPLIT": "0x6"},
     {"VXRT_TRACE_VARIANT": "5"},                                                        # monolithic head + path_kernel (lanes refilled path by path)
     {"VXRT_TRACE_VARIANT": "5", "VXRT_PATH_BLOCKS": "1", "VXRT_INFLIGHT": "2"},         # ... four waves take the whole queue: many refills per lane
     {"VXRT_TRACE_VARIANT": "5", "VXRT_TAIL_FROM": "2", "VXRT_BATCH": "4"},              # ... tail from hit 2 (the API calls here are single frames)
