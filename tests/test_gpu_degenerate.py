@@ -108,3 +108,27 @@ def test_path_log_matches_the_oracle(O, H, scenes, noise):
             assert g.shape == o.shape, (x, y, g.shape, o.shape)
             same = (g.view(np.uint32) == o.view(np.uint32)) | (np.isnan(g) & np.isnan(o))
             assert same.all(), (x, y, g[~same.all(1)][:1], o[~same.all(1)][:1])
+
+
+@pytest.mark.parametrize("label,radius,moving", [("specials", 2, False), ("zeros30", 1, True), ("all_zero", 0, False), ("specials", 8, True)])
+def test_degenerate_noise_through_temporal_and_denoise(O, H, scenes, noise, label, radius, moving):
+    """The traced frames of such tables hold NaN and inf colours (0/0 in normalize, 0 * inf weights); temporal.comp's mix / clamp and
+    denoise.comp's exp / log / division must carry them exactly as the oracle does, frame after frame (NaN == NaN here)."""
+    from gpu_voxel_raytracer_amd import ALL, Camera, Context
+    from test_gpu_pipeline import OraclePipeline
+    table = tables(noise)[label]
+    w, h, bounces = 160, 96, 4
+    ref = OraclePipeline(O, scenes, table, "menger", w, h, bounces, radius)
+    cam = list(scenes.close_camera(ref.size))
+    pos, mrgb, _ = scenes.load_scene("menger")
+    with Context(w, h, max_bounces=bounces, noise=table) as ctx:
+        ctx.recreate_octree(pos, mrgb)
+        ctx.denoise_uniforms.radius = radius
+        for f in range(4):
+            if moving:
+                cam[0] = (np.asarray(cam[0], np.float32) + np.float32(0.37) * np.array([1, 0.25, -0.5], np.float32)).astype(np.float32)
+            ctx.camera = Camera(*cam)
+            ctx.render(ALL)
+            want = ref.render(cam)
+            for img, wimg, what in zip(range(5), want, ("colour", "nd", "albedo", "accum", "denoised")):
+                assert_bits_equal(ctx.read(img), wimg, f"{what} frame {f + 1} {label} r={radius} moving={moving}")
