@@ -32,6 +32,10 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 WIDTH, HEIGHT, BOUNCES, SCENE = 1920, 1080, 4, "menger"
+# Rows are dealt to the ranks in interleaved bands of this height.  8 = the tracer's tile height: at 8 ranks the band sets' costs are
+# within 0.0161-0.0179 ms per frame of each other, with 16-row bands 0.0153-0.0206 (1080 rows are 67.5 such bands, and the sponge's
+# structure beats against the 128-row period).  (A denoise radius > 0 needs 16-row bands; this benchmark is the trace stage.)
+BAND_ROWS = 8
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -80,10 +84,12 @@ def pick_schedule(world, steps, inflight=0, batch=0):
     """Launches in flight and frames per launch for `world` ranks and a run of `steps` frames (0 = choose).
     A frame's longest tile is a serial chain of ~0.15-0.3 ms however few rows a rank owns, so a rank needs that much work in
     flight: 16-32 frames per launch, and the more launches overlapping the smaller its share of the frame (measured per rank with
-    scripts/exp_rank_emulation.py: 2x16 / 3x16 / 3x32 / 4x32 for 1 / 2 / 4 / 8 ranks).  Short runs get smaller launches so that
-    the pipeline still holds a few of them."""
+    scripts/exp_rank_emulation.py: 2x16 / 3x16 / 3x32 / 3x32 for 1 / 2 / 4 / 8 ranks).  Never more than 3: with the context's own
+    stream that makes 4, the number of hardware queues a process gets by default (GPU_MAX_HW_QUEUES) — a 5th stream shares a queue
+    with another one and its launches serialise behind that one's (scripts/exp_first_context.py: 0.0236 vs 0.0181 ms per frame for
+    one of 8 ranks).  Short runs get smaller launches so that the pipeline still holds a few of them."""
     if inflight <= 0:
-        inflight = 2 if world == 1 else (3 if world <= 4 else 4)
+        inflight = 2 if world == 1 else 3
     if batch <= 0:
         batch = 16 if world <= 2 else 32
         while batch > 1 and batch * inflight * 2 > max(steps, 1):
@@ -101,7 +107,7 @@ def main():
     ap.add_argument("--view", default="bench", choices=["bench", "close", "away"])
     ap.add_argument("--bounces", type=int, default=BOUNCES, help="diagnostic only; the benchmark is 4")
     ap.add_argument("--inflight", type=int, default=0,
-                    help="trace launches that may be on the GPU together, one HIP stream each (default: 2 on one GPU, 3-4 per rank otherwise)")
+                    help="trace launches that may be on the GPU together, one HIP stream each (default: 2 on one GPU, 3 per rank otherwise)")
     ap.add_argument("--batch", type=int, default=0,
                     help="consecutive frames per trace launch (vxrt_config.frames_per_launch; default: 16, 32 from 4 ranks on, fewer for short runs)")
     args = ap.parse_args()
@@ -137,7 +143,7 @@ def main():
     if args.view == "away":   # diagnostic: every primary ray misses (pure G-buffer write traffic)
         cam = (cam[0], -cam[1], cam[2])
 
-    ctx = Context(WIDTH, HEIGHT, device=device, max_bounces=BOUNCES, rank=rank, nranks=world, band_rows=16,
+    ctx = Context(WIDTH, HEIGHT, device=device, max_bounces=BOUNCES, rank=rank, nranks=world, band_rows=BAND_ROWS,
                   frames_in_flight=args.inflight, frames_per_launch=args.batch)
     ctx.recreate_octree(pos, mrgb)
     ctx.camera = Camera(*cam)
@@ -187,7 +193,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"vox/{SCENE}.vox {WIDTH}x{HEIGHT}, 1 spp, {BOUNCES} bounces, trace stage only "
                                    f"(BASELINE configs[1]); camera '{args.view}' of SURVEY §8d; Uniforms::default()",
-                       "parallelism": f"screen bands x{world} (16-row interleave, scene replicated)",
+                       "parallelism": f"screen bands x{world} ({BAND_ROWS}-row interleave, scene replicated)",
                        "launches_in_flight": args.inflight, "frames_per_launch": args.batch,
                        "rays_per_frame": rays // args.steps, "rays_per_pixel": round(rays / args.steps / (WIDTH * HEIGHT), 4),
                        "mpixels_per_s": round(WIDTH * HEIGHT * args.steps / elapsed / 1e6, 1)},

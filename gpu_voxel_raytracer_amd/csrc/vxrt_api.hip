@@ -451,7 +451,7 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) try {
     uint32_t nranks = cfg->nranks == 0 ? 1 : cfg->nranks;
     if (nranks > 1 && cfg->rank >= nranks) { set_error("rank >= nranks"); return VXRT_E_INVALID; }
     uint32_t band_rows = cfg->band_rows == 0 ? 16 : cfg->band_rows;
-    if (band_rows % 16 != 0) { set_error("band_rows must be a multiple of 16"); return VXRT_E_INVALID; }
+    if (band_rows % 8 != 0) { set_error("band_rows must be a multiple of 8 (of 16 for a denoise radius > 0)"); return VXRT_E_INVALID; }
 
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -624,6 +624,10 @@ int check_render(vxrt_ctx* c, uint32_t flags) {
     if ((flags & VXRT_ALL) == 0) { set_error("no stage selected"); return VXRT_E_INVALID; }
     if (!c->has_scene) { set_error("vxrt_render before any scene was set"); return VXRT_E_NOSCENE; }
     const bool multi = c->band.nranks > 1;
+    if ((flags & VXRT_DENOISE) && multi && c->denoise.radius > 0 && c->band.band_rows % 16 != 0) {
+        set_error("denoise with radius > 0 on row bands needs band_rows to be a multiple of 16 (its 16x16 tiles must not straddle bands)");
+        return VXRT_E_INVALID;
+    }
     if ((flags & VXRT_DENOISE) && multi && c->denoise.radius > 0 && (flags & (VXRT_TRACE | VXRT_TEMPORAL))) {
         set_error("multi-rank denoise with radius > 0 needs the halo: render TRACE|TEMPORAL, exchange, then DENOISE");
         return VXRT_E_INVALID;

@@ -93,12 +93,15 @@ typedef struct vxrt_config {
     uint32_t noise_seed;      /* seed of the generated noise table when `noise` is NULL                 */
     const float* noise;       /* optional 512*128*128 floats in [0,1) (layout of shaders/voxels.comp:65-71) */
     uint32_t rank, nranks;    /* this context renders the row bands b with b % nranks == rank ...       */
-    uint32_t band_rows;       /* ... where band b = rows [b*band_rows, (b+1)*band_rows); 0 -> 16.       */
+    uint32_t band_rows;       /* ... where band b = rows [b*band_rows, (b+1)*band_rows); 0 -> 16.  A multiple of 8;
+                               * of 16 if the denoise stage runs with radius > 0 (its tiles are 16 rows).   */
                               /* nranks = 0 or 1 -> the whole frame                                     */
     uint32_t frames_in_flight;/* 0/1: every stage of a frame runs in submission order on one stream (the
                                  reference's single queue).  F = 2..16: the TRACE stage of up to F consecutive
                                  frames may run concurrently (one HIP stream each, ring of F+2 G-buffer slots);
-                                 temporal/denoise still run in frame order.  Results are identical.       */
+                                 temporal/denoise still run in frame order.  Results are identical.  Beyond 3 the
+                                 streams outnumber the 4 hardware queues a process gets by default (GPU_MAX_HW_QUEUES):
+                                 launches of streams that share a queue serialise.                          */
     uint32_t tracer;          /* scheduling of the trace stage; every choice gives bit-identical images:
                                  0 auto (4 when max_bounces >= 2, else 1), 1 monolithic kernel (one pixel per lane,
                                  all bounces, longest-tile-first), 2 wavefront (one launch per path segment, live

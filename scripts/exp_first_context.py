@@ -1,0 +1,17 @@
+"""Is the first context of a process slower than later ones (seen in exp_rank_emulation.py at 8 ranks)?  One rank's band set, timed in
+several passes inside one context, then again in a second context."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gpu_voxel_raytracer_amd import Context, Camera, TRACE, scenes
+W, H = 1920, 1080
+pos, mrgb, size = scenes.load_scene("menger")
+cam = scenes.bench_camera(size)
+infl, batch, band = int(os.environ.get("INFL", "4")), int(os.environ.get("BATCH", "32")), int(os.environ.get("BAND", "8"))
+nranks, rank = int(os.environ.get("NRANKS", "8")), int(os.environ.get("RANK", "3"))
+for rep in range(3):
+    with Context(W, H, max_bounces=4, rank=rank, nranks=nranks, frames_in_flight=infl, frames_per_launch=batch, band_rows=band) as ctx:
+        ctx.recreate_octree(pos, mrgb); ctx.camera = Camera(*cam)
+        for p in range(4):
+            n = max(20 * batch * infl // (8 // nranks), batch * infl)
+            t0 = time.perf_counter(); ctx.render_frames(TRACE, n); ctx.sync(); dt = (time.perf_counter() - t0) / n
+            print(f"context {rep} pass {p}: {dt * 1e3:.4f} ms/frame", flush=True)

@@ -90,4 +90,43 @@ def test_multirank_denoise_without_halo_is_refused(H, scenes, noise):
     with pytest.raises(VxrtError):
         Context(64, 64, rank=2, nranks=2)
     with pytest.raises(VxrtError):
-        Context(64, 64, rank=0, nranks=2, band_rows=8)
+        Context(64, 64, rank=0, nranks=2, band_rows=12)          # a multiple of 8 (the tracer's tiles); 16 for a denoise window
+
+
+@pytest.mark.parametrize("nranks,w,h", [(8, 96, 136), (3, 64, 100)])
+def test_eight_row_bands_without_denoise_window(H, scenes, noise, nranks, w, h):
+    """band_rows = 8 (bench.py's deal at N > 1: the tracer's tile height) through trace, temporal and the radius-0 denoise equals the
+    single-context frame; a denoise radius > 0 is refused for such bands (its 16-row tiles would straddle two of them)."""
+    from gpu_voxel_raytracer_amd import ALL, DENOISE, TEMPORAL, TRACE, Camera, Context
+    from gpu_voxel_raytracer_amd.host import VxrtError
+    pos, mrgb, size = scenes.load_scene("castle")
+    cam = Camera(*scenes.close_camera(size))
+    with Context(w, h, max_bounces=3, noise=noise) as single:
+        single.recreate_octree(pos, mrgb)
+        single.camera = cam
+        ctxs = [Context(w, h, max_bounces=3, noise=noise, rank=r, nranks=nranks, band_rows=8, frames_per_launch=2) for r in range(nranks)]
+        try:
+            rows = []
+            for c in ctxs:
+                c.recreate_octree(pos, mrgb)
+                c.camera = cam
+                rows.append(c.local_rows())
+            assert sorted(np.concatenate(rows).tolist()) == list(range(h))
+            assert rows[1][:8].tolist() == list(range(8, 16))
+            for frame in range(3):
+                single.render(ALL)
+                for c in ctxs:
+                    c.render(ALL)
+                for img in range(5):
+                    want = single.read(img)
+                    got = np.zeros_like(want)
+                    for c, rr in zip(ctxs, rows):
+                        got[rr] = c.read(img)
+                    assert_bits_equal(got, want, f"image {img} frame {frame + 1}")
+            ctxs[0].denoise_uniforms.radius = 2
+            with pytest.raises(VxrtError, match="multiple of 16"):
+                ctxs[0].render(DENOISE)
+            del TEMPORAL, TRACE
+        finally:
+            for c in ctxs:
+                c.close()
