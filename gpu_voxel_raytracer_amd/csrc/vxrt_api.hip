@@ -47,6 +47,14 @@ int hip_fail(hipError_t e, const char* what) {
         if (e_ != hipSuccess) return hip_fail(e_, #expr); \
     } while (0)
 
+// a device allocation that lives as long as the entry point that made it (released on every return path)
+struct ScratchBuffer {
+    void* p = nullptr;
+    ~ScratchBuffer() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
 struct EventPair {
     hipEvent_t a = nullptr, b = nullptr;
     int stage = 0;  // 0 trace, 1 temporal, 2 denoise
@@ -1269,13 +1277,11 @@ int vxrt_blue_noise(int32_t device, uint32_t seed, uint32_t size, uint32_t first
     if (device < 0 || device >= ndev) { set_error("device ordinal out of range"); return VXRT_E_INVALID; }
     HIP_TRY(hipSetDevice(device));
     const size_t bytes = size_t(layers) * size * size * sizeof(float);
-    float* d = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), bytes));
-    hipError_t le = launch_blue_noise(d, seed, first_layer, layers, int(size), nullptr);
-    if (le == hipSuccess) le = hipDeviceSynchronize();
-    if (le == hipSuccess) le = hipMemcpy(out, d, bytes, hipMemcpyDeviceToHost);
-    (void)hipFree(d);
-    if (le != hipSuccess) return hip_fail(le, "blue noise");
+    ScratchBuffer b;
+    HIP_TRY(b.alloc(bytes));
+    HIP_TRY(launch_blue_noise(b.as<float>(), seed, first_layer, layers, int(size), nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, b.as<float>(), bytes, hipMemcpyDeviceToHost));
     return VXRT_OK;
 } VXRT_CATCH
 
@@ -1344,10 +1350,11 @@ int vxrt_debug_cast_rays(vxrt_ctx* c, const float* origins, const float* dirs, s
     if (n == 0) return VXRT_OK;
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = vxrt_sync(c)) return rc;
-    float *d_o = nullptr, *d_d = nullptr, *d_out = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_o), n * 12));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_d), n * 12));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), n * 32));
+    ScratchBuffer b_o, b_d, b_out;
+    HIP_TRY(b_o.alloc(n * 12));
+    HIP_TRY(b_d.alloc(n * 12));
+    HIP_TRY(b_out.alloc(n * 32));
+    float *d_o = b_o.as<float>(), *d_d = b_d.as<float>(), *d_out = b_out.as<float>();
     HIP_TRY(hipMemcpy(d_o, origins, n * 12, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_d, dirs, n * 12, hipMemcpyHostToDevice));
     TraceArgs a{};
@@ -1359,7 +1366,6 @@ int vxrt_debug_cast_rays(vxrt_ctx* c, const float* origins, const float* dirs, s
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::vector<float> out(n * 8);
     HIP_TRY(hipMemcpy(out.data(), d_out, n * 32, hipMemcpyDeviceToHost));
-    (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_out);
     for (size_t i = 0; i < n; i++) {
         hit[i] = out[8 * i] != 0.0f;
         time[i] = out[8 * i + 1];
@@ -1387,13 +1393,13 @@ int vxrt_debug_path_log(vxrt_ctx* c, int32_t x, int32_t y, float* log, int32_t* 
     a.cam = c->cam;
     a.batch = 1;
     c->cam = keep_cam; c->old_cam = keep_old; c->uniforms = keep_u;
-    float* d_log = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_log), (12 * 32 + 1) * sizeof(float)));
+    ScratchBuffer b_log;
+    HIP_TRY(b_log.alloc((12 * 32 + 1) * sizeof(float)));
+    float* d_log = b_log.as<float>();
     HIP_TRY(launch_path_log(a, x, y, d_log, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::vector<float> out(12 * 32 + 1);
     HIP_TRY(hipMemcpy(out.data(), d_log, out.size() * sizeof(float), hipMemcpyDeviceToHost));
-    (void)hipFree(d_log);
     *casts = int32_t(out[12 * 32]);
     memcpy(log, out.data(), size_t(*casts) * 12 * sizeof(float));
     return VXRT_OK;
@@ -1403,16 +1409,16 @@ int vxrt_debug_path_log(vxrt_ctx* c, int32_t x, int32_t y, float* log, int32_t* 
 int vxrt_detmath_probe(int32_t device, int32_t fn, const float* x, const float* y, float* out, size_t n) try {
     if (!x || !y || !out) { set_error("null argument"); return VXRT_E_INVALID; }
     HIP_TRY(hipSetDevice(device));
-    float *dx = nullptr, *dy = nullptr, *dout = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dx), n * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dy), n * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dout), n * 4));
+    ScratchBuffer bx, by, bout;
+    HIP_TRY(bx.alloc(n * 4));
+    HIP_TRY(by.alloc(n * 4));
+    HIP_TRY(bout.alloc(n * 4));
+    float *dx = bx.as<float>(), *dy = by.as<float>(), *dout = bout.as<float>();
     HIP_TRY(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice));
     HIP_TRY(launch_detmath_probe(fn, dx, dy, dout, n, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
     return VXRT_OK;
 } VXRT_CATCH
 
