@@ -38,3 +38,31 @@ def test_glsl_min_max_sign_semantics(O):
     # checked through pow/exp/log being NaN-propagating and through the traversal tests; here: f2i definedness via tan/div
     z = O.detmath("div", np.array([1, -1, 0, 1], np.float32), np.array([0, 0, 0, np.inf], np.float32))
     assert z[0] == np.inf and z[1] == -np.inf and np.isnan(z[2]) and z[3] == 0
+
+
+def test_min0_equals_glsl_min_for_every_binary32(tmp_path):
+    """vx_min0(v) — the integer-compare form the kernels use for min(0.0, v) because the gfx950 backend folds the literal select into
+    v_min_f32 (-0 for v = -0) — against the literal GLSL wording, for all 2^32 bit patterns, bit for bit (gcc, -O2)."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    src = tmp_path / "min0.c"
+    src.write_text('''
+#include <stdio.h>
+#include "vxrt_detmath.h"
+int main(void) {
+    unsigned long long bad = 0;
+    uint32_t b = 0;
+    do {
+        float v = vx_u2f(b);
+        uint32_t want = vx_f2u(vx_min(0.0f, v)), got = vx_f2u(vx_min0(v));
+        if (want != got) { if (bad < 4) printf("%08x: want %08x got %08x\\n", b, want, got); bad++; }
+    } while (++b != 0);
+    printf("bad %llu\\n", bad);
+    return bad != 0;
+}
+''')
+    exe = tmp_path / "min0"
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip().endswith("bad 0"), out.stdout

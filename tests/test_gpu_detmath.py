@@ -54,3 +54,19 @@ def test_signs_of_zero_and_special_operands(O, H, fn):
     dev, cpu = H.detmath_probe(fn, x, y), O.detmath(fn, x, y)
     bad = np.flatnonzero((dev.view(np.uint32) != cpu.view(np.uint32)) & ~(np.isnan(dev) & np.isnan(cpu)))
     assert len(bad) == 0, [(float(x[i]), float(y[i]), float(dev[i]), float(cpu[i])) for i in bad[:5]]
+
+
+def test_min0_on_device_over_every_exponent(H):
+    """vx_min0 on the device against the GLSL wording evaluated in numpy: every sign x exponent with the extreme and some random
+    mantissas (zeros, denormals, infinities, quiet and signalling NaN patterns included), bit for bit."""
+    rng = np.random.default_rng(5)
+    mant = np.concatenate([[0, 1, 2, 0x3fffff, 0x400000, 0x400001, 0x7ffffe, 0x7fffff], rng.integers(0, 1 << 23, 56)]).astype(np.uint32)
+    se = (np.arange(512, dtype=np.uint32) << 23)
+    bits = (se[:, None] | mant[None, :]).ravel()
+    v = bits.view(np.float32)
+    dev = H.detmath_probe("min0", v, np.ones_like(v))                      # vx_min0(v) * 1.0f
+    with np.errstate(invalid="ignore"):
+        want = np.where(v < 0, v, np.float32(0.0)).astype(np.float32)      # min(0.0, v): "y if y < x, otherwise x" with x = 0.0
+    nan = np.isnan(v)
+    assert not np.isnan(dev[nan]).any() and (dev[nan].view(np.uint32) == 0).all()      # NaN < 0 is false: +0.0
+    assert np.array_equal(dev[~nan].view(np.uint32), want[~nan].view(np.uint32))
