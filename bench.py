@@ -13,7 +13,7 @@ timed steps; everything the timed region touches is resident in HBM before it st
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU; the frame's rows are dealt to the ranks in interleaved 16-row bands
+N > 1: one process per GPU; the frame's rows are dealt to the ranks in interleaved 8-row bands (BAND_ROWS)
 (scene and noise table replicated, no data-path collective for this stage), so total work is fixed:
 "scaling": "strong".  torch.distributed (RCCL) carries only the barrier and the time/ray reductions.
 """
