@@ -77,6 +77,8 @@ struct TraceArgs {
     PathQueue tail;
     unsigned* tail_zero;   // counter set to clear for a later launch (see launch_trace_wavefront)
     int tail_from;
+    uint32_t gbuf_frames;  // bit k: frame k of the launch writes its normal/depth and albedo/node images (all set, except for the samples of one
+                           // displayed frame, vxrt_render_spp, whose first hits are identical: only the frame that is kept writes them)
 };
 
 struct TemporalArgs {

@@ -57,6 +57,7 @@ __global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const Trac
     const unsigned batch = unsigned(a.batch);
     const unsigned fb = blockIdx.x % batch, ord = blockIdx.x / batch;
     const FrameOut fo = a.out[fb];
+    const bool gbuf = ((a.gbuf_frames >> fb) & 1u) != 0u;   // this frame's normal/depth and albedo/node images are wanted
     const unsigned tile = a.tile_order ? a.tile_order[ord] : ord;
     const int x = int(tile % tiles_x) * kTileW + (wave & 1) * 8 + (lane & 7);
     const int lrow = int(tile / tiles_x) * kTileH + (wave >> 1) * 8 + (lane >> 3);
@@ -109,8 +110,10 @@ __global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const Trac
                     blend = splat3(1.0f);
                     float sun_power = vx_pow(vx_max(0.0f, dot3(d, ld3(a.neg_sun_dir_n))), a.sun_exponent);
                     sample = sample + (sky + sun_color * sun_power) * blend;
-                    store_out(fo.nd + pix, make_float4(kAlmostInfinity, kAlmostInfinity, kAlmostInfinity, -1.0f));
-                    store_out(fo.albedo + pix, make_float4(1.0f, 1.0f, 1.0f, __int_as_float(0xffffff)));
+                    if (gbuf) {
+                        store_out(fo.nd + pix, make_float4(kAlmostInfinity, kAlmostInfinity, kAlmostInfinity, -1.0f));
+                        store_out(fo.albedo + pix, make_float4(1.0f, 1.0f, 1.0f, __int_as_float(0xffffff)));
+                    }
                 } else {
                     sample = sample + sky * blend;
                 }
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const Trac
             const f3 hit_pos = o + d * hit.time;
             const f3 color = bounce == 0 ? splat3(1.0f) : node_color(hit.node);
             const f3 emit = node_emittance(hit.node, a.emit_strength);
-            if (bounce == 0) {  // first-hit G-buffer                           voxels.comp:320-324,392-396
+            if (bounce == 0 && gbuf) {  // first-hit G-buffer                   voxels.comp:320-324,392-396
                 store_out(fo.nd + pix, make_float4(n.x, n.y, n.z, hit.time));
                 f3 alb = (hit.node & kEmitBit) == 0 ? node_color(hit.node) : splat3(1.0f);
                 store_out(fo.albedo + pix, make_float4(alb.x, alb.y, alb.z, __int_as_float(hit.node)));

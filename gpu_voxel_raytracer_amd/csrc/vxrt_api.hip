@@ -688,7 +688,7 @@ void frame_constants(const vxrt_ctx* c, TraceArgs& a) {
 // path: optional g camera poses (position, direction), one per frame; null = the camera stays where it is.  cams / olds
 // (g entries each): the camera and the "old" camera of every frame, as temporal.comp and denoise.comp of that frame see them.
 int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam* olds, const float (*path_pos)[3] = nullptr,
-                 const float (*path_dir)[3] = nullptr) {
+                 const float (*path_dir)[3] = nullptr, uint32_t gbuf_frames = 0xffffffffu) {
     const uint32_t first_frame_number = c->uniforms.frame_number + 1;
     for (uint32_t k = 0; k < g; k++) {
         if (path_pos) {
@@ -722,6 +722,7 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
     }
     a.out_color = a.out[0].color; a.out_nd = a.out[0].nd; a.out_albedo = a.out[0].albedo;
     a.batch = int(g);
+    a.gbuf_frames = gbuf_frames;
     a.ray_counter = c->d_rays;
     a.tile_order = (c->use_tile_order && sched.valid) ? sched.order : nullptr;
     a.tile_cost = c->use_tile_order ? sched.cost : nullptr;
@@ -956,7 +957,9 @@ int vxrt_render_spp(vxrt_ctx* c, uint32_t flags, uint32_t spp) try {
         const uint32_t g = spp - done < batch ? spp - done : batch;
         int slots[kMaxBatch];
         Cam cams[kMaxBatch], olds[kMaxBatch];
-        if (int rc = trace_frames(c, g, timed, slots, cams, olds)) return rc;
+        // the samples' first hits are identical: only the sample whose slot stays current writes normal/depth and albedo/node
+        const uint32_t gbuf = done + g == spp ? 1u << (g - 1u) : 0u;
+        if (int rc = trace_frames(c, g, timed, slots, cams, olds, nullptr, nullptr, gbuf)) return rc;
         if (done == 0) first_old = olds[0];
         if (spp > 1 && pixels > 0) {
             SppArgs a{};
