@@ -45,6 +45,7 @@ struct FrameOut {                  // the three voxels.comp outputs of one frame
 
 struct TraceArgs {
     const SvoRecord* svo;
+    SvoRecord root_rec;    // svo[0]: every cast begins with it, so it travels with the kernel arguments instead of being loaded
     const int32_t* leaves;
     const float* noise;
     float4* out_color;   // = out[0].*: the single-frame kernels (tracer 2 / 3) use these

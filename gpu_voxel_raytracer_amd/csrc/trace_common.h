@@ -44,6 +44,7 @@ __device__ __forceinline__ uint32_t octant_of(f3 p, f3 c) {
 struct SceneView {
     const SvoRecord* svo;
     const int32_t* leaves;
+    SvoRecord root_rec;
     f3 root_center;
     f3 root_min;
     float root_size;
@@ -91,7 +92,7 @@ __device__ __forceinline__ bool walk_begin(Walk& w, const SceneView& sc, f3 o, f
     w.size = sc.root_size;
     w.center = sc.root_center;
     w.ix = w.iy = w.iz = w.lvl = w.has_next_mask = 0;
-    w.rec = sc.svo[0];
+    w.rec = sc.root_rec;
     w.octant = octant_of(o + d * w.time, w.center);
     w.iterations = 0;
     return true;
@@ -294,7 +295,7 @@ __device__ __forceinline__ bool walkf_begin(WalkF& w, const SceneView& sc, f3 o,
     w.time = vx_max(0.0f, entry);
     w.center = sc.root_center;
     w.ix = w.iy = w.iz = w.lvl = w.has_next_mask = 0;
-    w.rec = sc.svo[0];
+    w.rec = sc.root_rec;
     w.octant = octant_of(o + d * w.time, w.center);
     w.iterations = 0;
     return true;
@@ -662,6 +663,7 @@ __device__ __forceinline__ SceneView make_scene(const TraceArgs& a) {
     SceneView sc;
     sc.svo = a.svo;
     sc.leaves = a.leaves;
+    sc.root_rec = a.root_rec;
     sc.root_center = ld3(a.root_center);
     sc.root_size = a.root_size;
     sc.root_min = sc.root_center - splat3(0.5f * a.root_size);

@@ -70,6 +70,7 @@ struct vxrt_ctx {
     // scene
     bool has_scene = false;
     SvoRecord* d_svo = nullptr;
+    SvoRecord root_rec{0, 0};  // d_svo[0], passed to the kernels by value (every cast starts with it)
     int32_t* d_leaves = nullptr;
     size_t svo_count = 0, leaf_count = 0;
     float root_center[3] = {0, 0, 0};
@@ -386,6 +387,7 @@ int upload_svo(vxrt_ctx* c, std::vector<SvoRecord>& recs, std::vector<int32_t>& 
     HIP_TRY(hipMemcpy(c->d_svo, recs.data(), recs.size() * sizeof(SvoRecord), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_leaves, leaves.data(), leaves.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     c->svo_count = recs.size();
+    c->root_rec = recs.empty() ? SvoRecord{0, 0} : recs[0];
     c->leaf_count = leaves.size();
     c->root_center[0] = c->root_center[1] = c->root_center[2] = 0.0f;  // src/context.rs:782-786
     c->root_size = float(1u << depth);                                   // src/context.rs:779
@@ -664,6 +666,7 @@ void update_bindings(vxrt_ctx* c) {
 void frame_constants(const vxrt_ctx* c, TraceArgs& a) {
     const vxrt_uniforms& u = c->uniforms;
     a.svo = c->d_svo; a.leaves = c->d_leaves; a.noise = c->d_noise;
+    a.root_rec = c->root_rec;
     memcpy(a.root_center, c->root_center, sizeof a.root_center);
     a.root_size = c->root_size;
     a.band = c->band;
@@ -1362,6 +1365,7 @@ int vxrt_debug_cast_rays(vxrt_ctx* c, const float* origins, const float* dirs, s
     HIP_TRY(hipMemcpy(d_d, dirs, n * 12, hipMemcpyHostToDevice));
     TraceArgs a{};
     a.svo = c->d_svo; a.leaves = c->d_leaves;
+    a.root_rec = c->root_rec;
     memcpy(a.root_center, c->root_center, sizeof a.root_center);
     a.root_size = c->root_size;
     a.stack_levels = c->depth < 1 ? 1 : int(c->depth);
