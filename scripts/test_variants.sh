@@ -1,0 +1,17 @@
+#!/bin/bash
+# usage: scripts/test_variants.sh      (here: builds; on the GPU box: gpurun -- 'scripts/test_variants.sh run')
+# The compile-time variants of the walk that are NOT in the default library stay bit-exact: this builds each
+# of them as gpu_voxel_raytracer_amd/libvxrt_<tag>.so (hipcc cross-compiles without a GPU) and, with `run`, puts the trace, scene
+# and degenerate-noise parity tests through it (VXRT_LIB selects the library).
+set -e
+cd "$(dirname "$0")/.."
+if [ "$1" != "run" ]; then
+  scripts/ab_build.sh locate -DVXRT_LOCATE=1
+  exit 0
+fi
+for tag in locate; do
+  lib=$PWD/gpu_voxel_raytracer_amd/libvxrt_$tag.so
+  [ -f "$lib" ] || { echo "build first: scripts/test_variants.sh"; exit 2; }
+  echo "== $tag"
+  VXRT_LIB=$lib python -m pytest tests/test_gpu_trace.py tests/test_gpu_scenes.py tests/test_gpu_degenerate.py -x -q -m gpu
+done
