@@ -20,6 +20,12 @@ N > 1: one process per GPU; the frame's rows are dealt to the ranks in interleav
 import argparse
 import json
 import os
+
+# Every trace launch in flight is a HIP stream, and a process's streams share GPU_MAX_HW_QUEUES hardware queues (4 by default).  With
+# RCCL's and torch's streams in the process as well, two busy trace streams can land on one queue and serialise (measured on one of 8
+# ranks' band sets, scripts/exp_first_context.py: 0.0266-0.0271 ms per frame with one or two foreign streams created first, 0.0178
+# with 8 queues in every arrangement).  Read by the HIP runtime when it initialises, i.e. before the first HIP call below.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import sys
 import time
 

@@ -16,6 +16,10 @@ Nothing here imports the test oracle.
 import ctypes as C
 import os
 
+# One HIP stream per trace launch in flight; a process's streams share GPU_MAX_HW_QUEUES hardware queues (default 4) with everything
+# else in it (RCCL, torch).  8 keeps busy streams apart.  Only effective before the first HIP call of the process.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 from . import _build

@@ -8,7 +8,21 @@ pos, mrgb, size = scenes.load_scene("menger")
 cam = scenes.bench_camera(size)
 infl, batch, band = int(os.environ.get("INFL", "4")), int(os.environ.get("BATCH", "32")), int(os.environ.get("BAND", "8"))
 nranks, rank = int(os.environ.get("NRANKS", "8")), int(os.environ.get("RANK", "3"))
-for rep in range(3):
+# other streams of the process that exist before the context does (RCCL's, torch's): they take hardware-queue slots too
+pre = int(os.environ.get("PRE_STREAMS", "0"))
+if pre:
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    keep = []
+    for _ in range(pre):
+        st = ctypes.c_void_p()
+        assert hip.hipStreamCreateWithFlags(ctypes.byref(st), 1) == 0
+        buf = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(buf), 1 << 20) == 0
+        assert hip.hipMemsetAsync(buf, 0, 1 << 20, st) == 0      # something runs on it, so the queue exists
+        assert hip.hipStreamSynchronize(st) == 0
+        keep.append((st, buf))
+for rep in range(int(os.environ.get("CONTEXTS", "3"))):
     with Context(W, H, max_bounces=4, rank=rank, nranks=nranks, frames_in_flight=infl, frames_per_launch=batch, band_rows=band) as ctx:
         ctx.recreate_octree(pos, mrgb); ctx.camera = Camera(*cam)
         for p in range(4):
