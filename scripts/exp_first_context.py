@@ -1,5 +1,8 @@
 """Is the first context of a process slower than later ones (seen in exp_rank_emulation.py at 8 ranks)?  One rank's band set, timed in
-several passes inside one context, then again in a second context."""
+several passes inside one context, then again in further contexts.  It is, when its trace streams share a hardware queue:
+INFL=4 (5 streams) in the first context, or INFL=3 with PRE_STREAMS=1..2 foreign streams created before it, at the default
+GPU_MAX_HW_QUEUES=4 (0.0236-0.0271 vs 0.0173-0.0181 ms per frame); INFL=3 with GPU_MAX_HW_QUEUES=8 is fast in every arrangement.
+env: INFL, BATCH, BAND, NRANKS, RANK, PRE_STREAMS, CONTEXTS, GPU_MAX_HW_QUEUES (host.py defaults it to 8)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gpu_voxel_raytracer_amd import Context, Camera, TRACE, scenes
