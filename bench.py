@@ -107,8 +107,8 @@ def main():
     global BOUNCES
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=960, help="frames timed (default 960: whole launches for every schedule, 2x16 .. 3x32)")
+    ap.add_argument("--warmup", type=int, default=96)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--view", default="bench", choices=["bench", "close", "away"])
     ap.add_argument("--bounces", type=int, default=BOUNCES, help="diagnostic only; the benchmark is 4")
