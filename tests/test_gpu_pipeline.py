@@ -300,6 +300,25 @@ def test_bench_contract_line():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mrays/s" and "frames" in c["sample"]
 
 
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N > 1 path as the driver launches it (torch.distributed.run, one process per rank), rehearsed with two ranks that share
+    this GPU over gloo (VXRT_BENCH_BACKEND): the ranks' band sets (8-row interleave) add up to the frame's ray count, one JSON line."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "96", "--warmup", "16", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env={**os.environ, "VXRT_BENCH_BACKEND": "gloo"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 96 and d["scaling"] == "strong" and "x2" in d["config"]["parallelism"]
+    assert abs(d["config"]["rays_per_frame"] - 3320514) < 64          # the single-context frame's count (sum over the ranks' bands)
+    assert d["value"] > 1000.0
+
+
 @pytest.mark.parametrize("spp,batch,inflight", [(4, 1, 1), (4, 4, 2), (5, 2, 1), (16, 16, 2), (3, 16, 1)])
 def test_samples_per_pixel(O, H, scenes, noise, spp, batch, inflight):
     """BASELINE's "N spp" (SURVEY 8d): N consecutive trace frames averaged with equal weights — binary32 sum in frame order, one
