@@ -51,4 +51,17 @@ namespace orc {
 struct Hit { float time; int32_t node; V3 normal; int iterations; };
 // cast_bounded_ray (shaders/voxels.comp:134-247) on a reference-layout octree buffer.
 bool cast_bounded_ray(const int32_t* octree, V3 origin, V3 dir, float max_distance, Hit* hit);
+
+// The octree buffer as the walk reads it: the header fields and nodes[] — stored (nodes) or, for a procedural scene too large
+// to store (BASELINE config 5: 261 M nodes = 8.4 GB in the reference's layout), materialised on first touch (lazy, oprocedural.cpp).
+struct LazyTree;
+struct LazyPool;
+struct Scene { V3 root_center; float root_size; const int32_t* nodes; LazyTree* lazy; };
+Scene scene_of(const int32_t* octree);
+bool cast_bounded_ray(const Scene& scene, V3 origin, V3 dir, float max_distance, Hit* hit);
+int32_t lazy_fetch(LazyTree* tree, int32_t node, uint32_t octant);   // nodes[8 * node + octant]
+LazyPool* lazy_pool(uint32_t level, uint32_t clip, const uint8_t mrgb[4], uint32_t emissive_period);   // one per scene, kept for the process
+LazyTree* lazy_acquire(LazyPool* pool);      // a tree for the calling thread's exclusive use ...
+void lazy_release(LazyPool* pool, LazyTree* tree);   // ... handed back with what it has materialised
+Scene lazy_scene(LazyTree* tree);
 }  // namespace orc

@@ -88,6 +88,8 @@ def lib():
         _lib.orc_voxels_from_vox.restype = C.c_long
         _lib.orc_create_octree.restype = C.c_long
         _lib.orc_trace.restype = C.c_longlong
+        _lib.orc_trace_menger.restype = C.c_longlong
+        _lib.orc_menger_lazy_nodes.restype = C.c_longlong
         _lib.orc_default_scene.restype = C.c_long
         _lib.orc_parse_raw_f32img.restype = C.c_long
     return _lib
@@ -196,6 +198,70 @@ def trace(octree, noise, uniforms, width, height, max_bounces=3, crop=None, nthr
     rays = lib().orc_trace(_p(octree), _p(noise), C.byref(uniforms), C.c_int(max_bounces), C.c_int(x0), C.c_int(y0),
                            C.c_int(x1), C.c_int(y1), _p(color), _p(nd), _p(alb), C.c_int(nthreads))
     return color, nd, alb, int(rays)
+
+
+def _menger_args(level, clip, mrgb, emissive_period):
+    return C.c_uint32(level), C.c_uint32(clip), _p(np.ascontiguousarray(mrgb, np.uint8)), C.c_uint32(emissive_period)
+
+
+def trace_menger(level, clip, mrgb, emissive_period, noise, uniforms, max_bounces, crop, nthreads=None):
+    """trace() over the implicit octree of the procedural Menger scene (oprocedural.cpp; BASELINE config 5 at any size)."""
+    x0, y0, x1, y1 = crop
+    h, w = y1 - y0, x1 - x0
+    color = np.zeros((h, w, 4), np.float32)
+    nd = np.zeros((h, w, 4), np.float32)
+    alb = np.zeros((h, w, 4), np.float32)
+    nthreads = nthreads or min(os.cpu_count() or 1, 32)
+    rays = lib().orc_trace_menger(*_menger_args(level, clip, mrgb, emissive_period), _p(noise), C.byref(uniforms), C.c_int(max_bounces),
+                                  C.c_int(x0), C.c_int(y0), C.c_int(x1), C.c_int(y1), _p(color), _p(nd), _p(alb), C.c_int(nthreads))
+    return color, nd, alb, int(rays)
+
+
+def cast_rays_menger(level, clip, mrgb, emissive_period, origins, dirs, max_distance=float(1 << 30), nthreads=None):
+    origins = np.ascontiguousarray(origins, np.float32)
+    dirs = np.ascontiguousarray(dirs, np.float32)
+    n = len(origins)
+    hit = np.zeros(n, np.uint8)
+    time = np.zeros(n, np.float32)
+    node = np.zeros(n, np.int32)
+    normal = np.zeros((n, 3), np.float32)
+    iters = np.zeros(n, np.int32)
+    nthreads = nthreads or min(os.cpu_count() or 1, 32)
+    lib().orc_cast_rays_menger(*_menger_args(level, clip, mrgb, emissive_period), _p(origins), _p(dirs), C.c_size_t(n),
+                               C.c_float(max_distance), _p(hit), _p(time), _p(node), _p(normal), _p(iters), C.c_int(nthreads))
+    return hit.astype(bool), time, node, normal, iters
+
+
+def dda_menger(level, clip, origins, dirs, nthreads=None):
+    """Independent binary64 DDA over the Menger voxel PREDICATE (no octree, no grid) -> hit, t, entry axis, cell."""
+    origins = np.ascontiguousarray(origins, np.float32)
+    dirs = np.ascontiguousarray(dirs, np.float32)
+    n = len(origins)
+    hit = np.zeros(n, np.uint8)
+    time = np.zeros(n, np.float64)
+    axis = np.zeros(n, np.int32)
+    cell = np.zeros((n, 3), np.int32)
+    nthreads = nthreads or os.cpu_count() or 1
+    lib().orc_dda_menger(C.c_uint32(level), C.c_uint32(clip), _p(origins), _p(dirs), C.c_size_t(n), _p(hit), _p(time), _p(axis),
+                         _p(cell), C.c_int(nthreads))
+    return hit.astype(bool), time, axis, cell
+
+
+def menger_cells(level, clip, mrgb, emissive_period, cells):
+    """The procedural scene's voxel predicate: (solid bool[n], leaf word int32[n]) for integer cells int32[n,3]."""
+    cells = np.ascontiguousarray(cells, np.int32)
+    solid = np.zeros(len(cells), np.uint8)
+    word = np.zeros(len(cells), np.int32)
+    lib().orc_menger_cells(*_menger_args(level, clip, mrgb, emissive_period), _p(cells), C.c_size_t(len(cells)), _p(solid), _p(word))
+    return solid.astype(bool), word
+
+
+def menger_depth(level, clip):
+    return int(lib().orc_menger_depth(C.c_uint32(level), C.c_uint32(clip)))
+
+
+def menger_lazy_nodes(level, clip, mrgb, emissive_period):
+    return int(lib().orc_menger_lazy_nodes(*_menger_args(level, clip, mrgb, emissive_period)))
 
 
 def path_log(octree, noise, uniforms, max_bounces, x, y):

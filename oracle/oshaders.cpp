@@ -75,12 +75,26 @@ static void log_ray(V3 o, V3 d, bool hit, const orc::Hit& h) {
 thread_local int g_phase = 0;
 
 // voxels.comp:134-247
-bool cast_bounded_ray(const int32_t* octree, V3 ray_origin, V3 ray_dir, float max_distance, Hit* out) {
+// The octree buffer of voxels.comp:58-63 (header + nodes[]) as the walk sees it.  `lazy` != null: nodes[] is not stored but
+// materialised slot by slot from a procedural voxel predicate on first touch (oprocedural.cpp) — the same words
+// create_octree (src/context.rs:710-796) would have produced for that voxel set, up to node numbering.
+Scene scene_of(const int32_t* octree) {
     float hdr[5];
     memcpy(hdr, octree, sizeof hdr);
-    const V3 root_center = v3(hdr[0], hdr[1], hdr[2]);
-    const float root_size = hdr[3];
-    const int32_t* nodes = octree + 5;
+    return Scene{v3(hdr[0], hdr[1], hdr[2]), hdr[3], octree + 5, nullptr};
+}
+static inline int32_t node_word(const Scene& sc, int32_t node, uint32_t octant) {
+    return sc.lazy ? lazy_fetch(sc.lazy, node, octant) : sc.nodes[8 * node + octant];
+}
+
+bool cast_bounded_ray(const int32_t* octree, V3 ray_origin, V3 ray_dir, float max_distance, Hit* out) {
+    return cast_bounded_ray(scene_of(octree), ray_origin, ray_dir, max_distance, out);
+}
+
+// voxels.comp:134-247
+bool cast_bounded_ray(const Scene& sc, V3 ray_origin, V3 ray_dir, float max_distance, Hit* out) {
+    const V3 root_center = sc.root_center;
+    const float root_size = sc.root_size;
     struct Frame { int32_t node; uint32_t octant; } stack[MAX_DEPTH];
 
     out->normal = v3s(0.0f);  // U1
@@ -115,7 +129,7 @@ bool cast_bounded_ray(const int32_t* octree, V3 ray_origin, V3 ray_dir, float ma
         }
         if (time > max_distance) return false;
 
-        int32_t value = nodes[8 * node + octant];
+        int32_t value = node_word(sc, node, octant);
 
         if (value < 0) {
             out->node = value;
@@ -218,7 +232,7 @@ static V3 pixel_ray_dir(const float* right, const float* up, const float* fwd, i
 
 // voxels.comp:289-397 for one pixel; out_* are rgba32f texels.  Returns the number of
 // cast_bounded_ray invocations (the "ray" of the Mrays/s metric).
-static int trace_pixel(const int32_t* octree, const float* noise, const OrcUniforms& u, int max_bounces, int px,
+static int trace_pixel(const Scene& octree, const float* noise, const OrcUniforms& u, int max_bounces, int px,
                        int py, float* out_color, float* out_nd, float* out_albedo) {
     Rng rng;
     rng.noise = noise;
@@ -375,7 +389,7 @@ long long orc_trace(const int32_t* octree, const float* noise, const OrcUniforms
         long long r = 0;
         for (int x = x0; x < x1; x++) {
             size_t o = 4 * ((size_t)(y - y0) * cw + (x - x0));
-            r += trace_pixel(octree, noise, *u, max_bounces, x, y, color + o, normal_depth + o, albedo + o);
+            r += trace_pixel(scene_of(octree), noise, *u, max_bounces, x, y, color + o, normal_depth + o, albedo + o);
         }
         rays += r;
     });
@@ -396,7 +410,7 @@ void orc_trace_steps(const int32_t* octree, const float* noise, const OrcUniform
             for (int k = 0; k < 17; k++) row[k] = 0;
             g_phase_steps = row + 1;
             g_phase = 0;
-            trace_pixel(octree, noise, *u, max_bounces, x, y, c, n, a);
+            trace_pixel(scene_of(octree), noise, *u, max_bounces, x, y, c, n, a);
             g_phase_steps = nullptr;
             row[0] = (int32_t)(g_iterations - before);
         }
@@ -408,7 +422,7 @@ int orc_trace_pixel_log(const int32_t* octree, const float* noise, const OrcUnif
     float c[4], n[4], a[4];
     g_ray_log = log;
     g_ray_log_n = 0;
-    trace_pixel(octree, noise, *u, max_bounces, x, y, c, n, a);
+    trace_pixel(scene_of(octree), noise, *u, max_bounces, x, y, c, n, a);
     g_ray_log = nullptr;
     return g_ray_log_n;
 }
@@ -424,6 +438,49 @@ void orc_cast_rays(const int32_t* octree, const float* origins, const float* dir
         normal[3 * i] = h.normal.x; normal[3 * i + 1] = h.normal.y; normal[3 * i + 2] = h.normal.z;
         if (iterations) iterations[i] = h.iterations;
     }
+}
+
+// ---- the same two entry points over the implicit octree of a procedural scene (oprocedural.cpp; BASELINE config 5) ----
+// orc_trace for the level-`level` Menger sponge clipped to [0, clip)^3 with leaf words orc_procedural_leaf_word(...).
+long long orc_trace_menger(uint32_t level, uint32_t clip, const uint8_t* mrgb, uint32_t emissive_period, const float* noise,
+                           const OrcUniforms* u, int max_bounces, int x0, int y0, int x1, int y1, float* color, float* normal_depth,
+                           float* albedo, int nthreads) {
+    int cw = x1 - x0;
+    std::atomic<long long> rays(0);
+    LazyPool* pool = lazy_pool(level, clip, mrgb, emissive_period);
+    parallel_rows(y0, y1, nthreads, [&](int y) {
+        LazyTree* tree = lazy_acquire(pool);
+        const Scene sc = lazy_scene(tree);
+        long long r = 0;
+        for (int x = x0; x < x1; x++) {
+            size_t o = 4 * ((size_t)(y - y0) * cw + (x - x0));
+            r += trace_pixel(sc, noise, *u, max_bounces, x, y, color + o, normal_depth + o, albedo + o);
+        }
+        rays += r;
+        lazy_release(pool, tree);
+    });
+    return rays.load();
+}
+
+void orc_cast_rays_menger(uint32_t level, uint32_t clip, const uint8_t* mrgb, uint32_t emissive_period, const float* origins,
+                          const float* dirs, size_t n, float max_distance, uint8_t* hit, float* time, int32_t* node, float* normal,
+                          int32_t* iterations, int nthreads) {
+    LazyPool* pool = lazy_pool(level, clip, mrgb, emissive_period);
+    const int chunks = (int)((n + 4095) / 4096);
+    parallel_rows(0, chunks, nthreads, [&](int c) {
+        LazyTree* tree = lazy_acquire(pool);
+        const Scene sc = lazy_scene(tree);
+        const size_t a = (size_t)c * 4096, b = a + 4096 < n ? a + 4096 : n;
+        for (size_t i = a; i < b; i++) {
+            Hit h;
+            bool ok = cast_bounded_ray(sc, v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]),
+                                       v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), max_distance, &h);
+            hit[i] = ok; time[i] = h.time; node[i] = h.node;
+            normal[3 * i] = h.normal.x; normal[3 * i + 1] = h.normal.y; normal[3 * i + 2] = h.normal.z;
+            if (iterations) iterations[i] = h.iterations;
+        }
+        lazy_release(pool, tree);
+    });
 }
 
 // temporal.comp main() over a full width x height frame.

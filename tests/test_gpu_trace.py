@@ -280,24 +280,52 @@ def test_zero_times_infinity_rays_through_the_gpu(O, H, scenes, noise):
         assert rays == ref[3]
 
 
-def test_iteration_cap(O, H, noise):
-    """voxels.comp:166-169: after 2047 loop trips a ray "hits" with node = LEAF_BIT.  A depth-15 scene with a long
-    sparse row of voxels makes grazing rays exceed the cap on both sides identically."""
-    f32 = np.float32
-    n = 1500
-    pos = np.stack([np.arange(n) * 20, np.zeros(n), np.arange(n) % 2], 1).astype(np.int16)   # up to x = 29980: depth 15
-    mrgb = np.tile(np.array([[0, 90, 90, 90]], np.uint8), (n, 1))
+def cap_scene():
+    """A row of 4 096 voxels along x (depth 12).  A ray that runs along the row through the EMPTY cells beside it enters
+    every leaf-parent node of the row (descend, step to the second empty octant, pop: >= 3 trips per two cells), never hits,
+    and is still inside the root cube when its 2 048th trip begins (tests/test_oracle_traversal.py asserts this in the oracle)."""
+    n = 4096
+    pos = np.zeros((n, 3), np.int16)
+    pos[:, 0] = np.arange(n)
+    return pos, np.tile(np.array([[0, 200, 100, 50]], np.uint8), (n, 1))
+
+
+CAP_RAYS_O = np.array([[-1, 0.75, 0.25]] * 4, np.float32)
+CAP_RAYS_D = np.array([[1, 0, 0], [1, 1e-5, 1e-5], [1, 1e-4, -2e-5], [1, 0, 1e-6]], np.float32)   # rows 0 and 3: a zero component -> walk_step
+
+
+@pytest.mark.parametrize("env", [{}, {"VXRT_TRACE_VARIANT": "0"}, {"VXRT_TRACE_VARIANT": "2", "VXRT_TRACE_SPLIT": "0x3"},
+                                 {"VXRT_TRACE_VARIANT": "3"}, {"VXRT_TRACE_VARIANT": "4", "VXRT_TAIL_FROM": "0"},
+                                 {"VXRT_TRACE_VARIANT": "5"}])
+def test_iteration_cap(O, H, noise, monkeypatch, env):
+    """voxels.comp:163-169: the 2 048th trip of the loop returns TRUE with out_node = LEAF_BIT, the time the walk is at, and
+    the normal unwritten (defined as 0 here and in the oracle, U1 — the shader leaves it undefined: parity unpinned).
+    Probe rays (both walks: regular rays -> walkf_step, a zero direction component -> walk_step) and a rendered frame in
+    which hundreds of primary rays are capped and their paths go on from the capped "hit" — for every tracer variant."""
+    from gpu_voxel_raytracer_amd import Camera, Context
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    pos, mrgb = cap_scene()
     octree = O.create_octree(pos, mrgb)
-    o = np.array([[-1.0, 0.26, 0.24]], f32)
-    d = np.array([[1.0, 1e-6, 2e-6]], f32); d /= np.linalg.norm(d)
-    hit, t, node, normal, iters = O.cast_rays(octree, o, d)
-    cam = (o[0], d[0], 0.02)
-    for (g, rays, ref) in _render_voxels(O, noise, pos, mrgb, cam, 48, 32, 2):
+    d = (CAP_RAYS_D / np.linalg.norm(CAP_RAYS_D, axis=1, keepdims=True)).astype(np.float32)
+    hit, t, node, normal, iters = O.cast_rays(octree, CAP_RAYS_O, d)
+    assert hit.all() and (iters == 2048).all() and (node == -2 ** 31).all() and (normal == 0).all()     # the oracle is capped
+    with Context(64, 64, max_bounces=2, noise=noise) as ctx:
+        ctx.recreate_octree(pos, mrgb)
+        ghit, gt, gnode, gnormal = ctx.cast_rays(CAP_RAYS_O, d)
+    assert ghit.all() and (gnode == -2 ** 31).all() and (gnormal == 0).all()
+    assert_bits_equal(gt, t, "time at the cap")
+    # a frame: camera looking along the row, 0.01 rad field of view
+    cam = (np.array([-1, 0.6, 0.25], np.float32), np.array([1, 0, 0], np.float32), 0.01)
+    for (g, rays, ref) in _render_voxels(O, noise, pos, mrgb, cam, 96, 64, 3, frames=(1, 2)):
+        capped = ref[2][..., 3].view(np.uint32) == 0x80000000
+        assert capped.sum() > 500 and (ref[1][..., 3] >= 0).sum() > capped.sum() + 500          # capped and ordinary hits
+        assert (ref[1][capped][:, :3] == 0).all() and (ref[2][capped][:, :3] == 0).all()       # normal 0 (U1), albedo of rgb 0
+        gcap = g[2][..., 3].view(np.uint32) == 0x80000000
+        assert np.array_equal(gcap, capped)
         for a, b, label in zip(g, ref[:3], ("colour", "nd", "albedo")):
-            assert_bits_equal(a, b, label)
+            assert_bits_equal(a, b, f"{label} with capped rays {env}")
         assert rays == ref[3]
-        capped = (ref[2][..., 3].view(np.uint32) == 0x80000000)
-    assert iters[0] < 2048 or node[0] == -2147483648
 
 
 def test_tracer_field_of_the_config(O, H, scenes, noise):

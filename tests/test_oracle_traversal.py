@@ -61,7 +61,7 @@ def test_octree_walk_matches_dense_dda(O, scenes, name, n):
     assert hard.mean() < 2e-4, int(hard.sum())
     rel = np.abs(t[both].astype(np.float64) - dt[both]) / np.maximum(dt[both], 1e-3)
     assert np.quantile(rel, 0.999) < 1e-4
-    assert iters.max() < 2048
+    assert iters.max() < 2048           # none of these rays is cut short; the cap itself: test_iteration_cap_is_reached
 
 
 def test_axis_parallel_rays(O, scenes):
@@ -116,3 +116,21 @@ def test_zero_times_infinity_quirk(O, scenes):
     octree = O.create_octree(pos, mrgb)
     hit, t, node, normal, iters = O.cast_rays(octree, np.array([[1, 1, -5]], np.float32), np.array([[0, 0, 1]], np.float32))
     assert hit[0] and np.isnan(t[0]) and node[0] < 0 and iters[0] < 2048
+
+
+def test_iteration_cap_is_reached(O):
+    """voxels.comp:163-169: `if (iterations >= 2048) { out_node = LEAF_BIT; return true; }` — a ray along a 4 096-voxel row,
+    through the empty cells beside it, is still walking when trip 2 048 begins: hit with node 0x80000000, the time reached,
+    normal unwritten (0 here, U1).  A shorter row of the same kind stays below the cap and misses."""
+    n = 4096
+    pos = np.zeros((n, 3), np.int16)
+    pos[:, 0] = np.arange(n)
+    mrgb = np.tile(np.array([[0, 200, 100, 50]], np.uint8), (n, 1))
+    o = np.array([[-1, 0.75, 0.25]] * 4, np.float32)
+    d = np.array([[1, 0, 0], [1, 1e-5, 1e-5], [1, 1e-4, -2e-5], [1, 0, 1e-6]], np.float32)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    hit, t, node, normal, iters = O.cast_rays(O.create_octree(pos, mrgb), o, d)
+    assert hit.all() and (iters == 2048).all() and (node == -2 ** 31).all() and (normal == 0).all()
+    assert (t > 100).all() and (t < 2048).all()            # far along the row, still inside the root cube
+    hit, t, node, normal, iters = O.cast_rays(O.create_octree(pos[:512], mrgb[:512]), o, d)
+    assert (~hit).all() and (iters < 2048).all() and (iters > 700).all()
