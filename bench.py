@@ -7,14 +7,20 @@ MAX_BOUNCES = 4, path-trace stage only (no temporal / denoise), fixed camera, Un
 A "step" is one frame (frame_number advances every step, so every step draws different noise).
 
 Metric: Mrays/s, where a ray is one cast_bounded_ray invocation (primary, bounce or sun shadow ray),
-counted exactly on the device.  value = rays cast by all ranks / max-over-ranks wall time of the K
-timed steps; everything the timed region touches is resident in HBM before it starts.
+counted exactly on the device.  value = rays cast by all ranks / max-over-ranks wall time of K timed steps;
+everything the timed region touches is resident in HBM before it starts.
+
+Timing: a timed BLOCK is exactly K steps, bracketed by a barrier + device synchronisation on both sides.  The block is
+repeated back to back (>= 50 times and for >= 1 s of GPU time) and the MEDIAN block is reported, so that a short block
+(the driver's --steps 20 is 2.5 ms) is not at the mercy of one launch's jitter; `blocks` and the spread are in the line.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  ... bench.py --pipeline   the whole frame loop instead (BASELINE configs[3]: castle 3840x2160, 4 spp, temporal + denoise
+                            r = 8 with the RCCL halo exchange between ranks), halo bytes and exchange time reported apart.
 
 N > 1: one process per GPU; the frame's rows are dealt to the ranks in interleaved 8-row bands (BAND_ROWS)
-(scene and noise table replicated, no data-path collective for this stage), so total work is fixed:
+(scene and noise table replicated, no data-path collective for the trace stage), so total work is fixed:
 "scaling": "strong".  torch.distributed (RCCL) carries only the barrier and the time/ray reductions.
 """
 import argparse
@@ -26,6 +32,7 @@ import os
 # ranks' band sets, scripts/exp_first_context.py: 0.0266-0.0271 ms per frame with one or two foreign streams created first, 0.0178
 # with 8 queues in every arrangement).  Read by the HIP runtime when it initialises, i.e. before the first HIP call below.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import statistics
 import sys
 import time
 
@@ -33,16 +40,14 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# Frames in flight run on separate HIP streams; the ROCm runtime maps streams onto 4 hardware queues unless told
-# otherwise, which would cap the overlap at 4 kernels.  Must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 WIDTH, HEIGHT, BOUNCES, SCENE = 1920, 1080, 4, "menger"
 # Rows are dealt to the ranks in interleaved bands of this height.  8 = the tracer's tile height: at 8 ranks the band sets' costs are
 # within 0.0161-0.0179 ms per frame of each other, with 16-row bands 0.0153-0.0206 (1080 rows are 67.5 such bands, and the sponge's
-# structure beats against the 128-row period).  (A denoise radius > 0 needs 16-row bands; this benchmark is the trace stage.)
+# structure beats against the 128-row period).  (A denoise radius > 0 needs 16-row bands; the default benchmark is the trace stage.)
 BAND_ROWS = 8
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PROFILE_DIRS = ("r02", "r01")   # newest first: where the rocprofv3 summaries of the default command are kept
 
 
 def algorithmic_bytes(pixels, bounces, scene_bytes):
@@ -51,16 +56,17 @@ def algorithmic_bytes(pixels, bounces, scene_bytes):
     return 48 * pixels + scene_bytes + min(8 * bounces, 512) * 128 * 128 * 4
 
 
-def measured_traffic(frames_per_launch):
-    """HBM bytes per trace-stage launch (trace_kernel + bounce_kernel over frames_per_launch frames) from the rocprofv3 PMC
-    passes recorded in profiles/ (FETCH_SIZE and WRITE_SIZE need separate passes and cannot be collected from inside this
-    process), scaled to this run's frames per launch; None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01", "trace_stage_summary.json")
-    try:
-        t = json.load(open(path))["traffic"]
-        return float(t["hbm_bytes_per_launch_corrected"]) / float(t["frames_per_launch"]) * frames_per_launch
-    except (OSError, KeyError, ValueError, TypeError, ZeroDivisionError):
-        return None
+def recorded_profile():
+    """What rocprofv3 recorded for the default command (scripts/profile_round.sh -> profiles/rNN/trace_stage_summary.json):
+    HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes and the SQ instruction counters.  These need separate profiler
+    passes and cannot be collected from inside this process, so they are RECORDED values, not measurements of this run."""
+    for d in PROFILE_DIRS:
+        path = os.path.join(ROOT, "profiles", d, "trace_stage_summary.json")
+        try:
+            return json.load(open(path)), f"profiles/{d}/trace_stage_summary.json"
+        except (OSError, ValueError):
+            continue
+    return None, None
 
 
 def cpu_baseline(pos, mrgb, cam, target_seconds=float(os.environ.get("VXRT_BENCH_CPU_SECONDS", "12"))):
@@ -86,49 +92,54 @@ def cpu_baseline(pos, mrgb, cam, target_seconds=float(os.environ.get("VXRT_BENCH
                       f"{threads} threads"}
 
 
+def cpu_baseline_cpu_rs(target_seconds=float(os.environ.get("VXRT_BENCH_CPU_RS_SECONDS", "6"))):
+    """BASELINE configs[0] as north_star asks for it: the reference's src/cpu.rs ray caster (restated, oracle/ocpu.cpp — the
+    original is orphaned Rust that does not compile) on vox/3x3x3.vox at 256x256, threaded over the host's cores the way
+    src/cpu.rs:43-46 uses rayon.  A ray here is one Octree::cast_ray (primary + one shadow ray per hit)."""
+    from gpu_voxel_raytracer_amd import scenes
+    from oracle import oracle as O
+    pos, mrgb, size = scenes.load_scene("3x3x3")
+    cam_pos, cam_dir, fov = scenes.bench_camera(size)
+    basis = O.camera_axis_scaled(cam_pos, cam_dir, fov, 256, 256)
+    backend = O.CpuRsBackend(pos.astype(np.uint16), mrgb[:, 1:])
+    threads = os.cpu_count() or 1
+    img = backend.render(cam_pos * 2, basis, 256, 256, 0.0, threads)       # warm-up
+    rays_per_frame = 256 * 256 + int((img.reshape(-1, 3).max(1) > 0).sum())  # lower bound: lit pixels cast a shadow ray
+    times, t_end = [], time.perf_counter() + target_seconds
+    while time.perf_counter() < t_end or len(times) < 20:
+        t0 = time.perf_counter()
+        backend.render(cam_pos * 2, basis, 256, 256, 0.0, threads)
+        times.append(time.perf_counter() - t0)
+    backend.close()
+    ms = statistics.median(times) * 1e3
+    return {"value": round(ms, 4), "unit": "ms/frame", "cores": threads, "kind": "port",
+            "mrays_per_s": round(rays_per_frame / (ms * 1e-3) / 1e6, 2),
+            "sample": f"vox/3x3x3.vox 256x256, src/cpu.rs shading at time 0, median of {len(times)} frames, {threads} threads"}
+
+
 def pick_schedule(world, steps, inflight=0, batch=0):
-    """Launches in flight and frames per launch for `world` ranks and a run of `steps` frames (0 = choose).
+    """Launches in flight and frames per launch for `world` ranks and a timed block of `steps` frames (0 = choose).
     A frame's longest tile is a serial chain of ~0.15-0.3 ms however few rows a rank owns, so a rank needs that much work in
     flight: 16-32 frames per launch, and the more launches overlapping the smaller its share of the frame (measured per rank with
-    scripts/exp_rank_emulation.py: 2x16 / 3x16 / 3x32 / 3x32 for 1 / 2 / 4 / 8 ranks).  Never more than 3: with the context's own
-    stream that makes 4, the number of hardware queues a process gets by default (GPU_MAX_HW_QUEUES) — a 5th stream shares a queue
-    with another one and its launches serialise behind that one's (scripts/exp_first_context.py: 0.0236 vs 0.0181 ms per frame for
-    one of 8 ranks).  Short runs get smaller launches so that the pipeline still holds a few of them."""
+    scripts/exp_rank_emulation.py: 2x16 / 3x16 / 3x32 / 3x32 for 1 / 2 / 4 / 8 ranks).  Never more than 3 trace streams: with the
+    context's own stream that makes 4, and RCCL / torch bring streams of their own; a process gets GPU_MAX_HW_QUEUES = 8 hardware
+    queues here (set above), and streams beyond the queues share one and serialise (scripts/exp_first_context.py).
+    A short block is dealt to the launches in equal parts (20 steps = 2 launches of 10 frames), so that the block still runs with
+    `inflight` launches side by side."""
     if inflight <= 0:
         inflight = 2 if world == 1 else 3
     if batch <= 0:
         batch = 16 if world <= 2 else 32
-        while batch > 1 and batch * inflight * 2 > max(steps, 1):
-            batch //= 2
+        if steps < batch * inflight:
+            batch = max(1, min(32, -(-steps // inflight)))
     return inflight, batch
 
 
-def main():
-    global BOUNCES
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=960, help="frames timed (default 960: whole launches for every schedule, 2x16 .. 3x32)")
-    ap.add_argument("--warmup", type=int, default=96)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--view", default="bench", choices=["bench", "close", "away"])
-    ap.add_argument("--bounces", type=int, default=BOUNCES, help="diagnostic only; the benchmark is 4")
-    ap.add_argument("--inflight", type=int, default=0,
-                    help="trace launches that may be on the GPU together, one HIP stream each (default: 2 on one GPU, 3 per rank otherwise)")
-    ap.add_argument("--batch", type=int, default=0,
-                    help="consecutive frames per trace launch (vxrt_config.frames_per_launch; default: 16, 32 from 4 ranks on, fewer for short runs)")
-    args = ap.parse_args()
-    BOUNCES = args.bounces
-
+def init_dist():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
-
-    dist = None
-    device = local_rank
+    dist, torch, device = None, None, local_rank
     backend = os.environ.get("VXRT_BENCH_BACKEND", "nccl")  # "gloo": rehearsal with several ranks on one GPU
     if world > 1:
         import torch
@@ -139,8 +150,39 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend)
-    red_dev = "cuda" if backend == "nccl" else "cpu"
+    return world, rank, device, dist, torch, backend
 
+
+def reduce_max(dist, torch, dev, values):
+    if dist is None:
+        return values
+    t = torch.tensor(values, dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(v) for v in t.tolist()]
+
+
+def reduce_sum(dist, torch, dev, values):
+    if dist is None:
+        return values
+    t = torch.tensor(values, dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [int(v) for v in t.tolist()]
+
+
+def block_count(est_block_s, asked):
+    """>= 50 blocks and >= 1 s of GPU time (>= 0.25 s when asked for fewer blocks than that needs would take minutes)."""
+    if asked > 0:
+        return asked
+    return int(min(4000, max(50, np.ceil(1.0 / max(est_block_s, 1e-5)))))
+
+
+def trace_bench(args):
+    world, rank, device, dist, torch, backend = init_dist()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     args.inflight, args.batch = pick_schedule(world, args.steps, args.inflight, args.batch)
     from gpu_voxel_raytracer_amd import Camera, Context, TIMED, TRACE, scenes
 
@@ -149,7 +191,7 @@ def main():
     if args.view == "away":   # diagnostic: every primary ray misses (pure G-buffer write traffic)
         cam = (cam[0], -cam[1], cam[2])
 
-    ctx = Context(WIDTH, HEIGHT, device=device, max_bounces=BOUNCES, rank=rank, nranks=world, band_rows=BAND_ROWS,
+    ctx = Context(WIDTH, HEIGHT, device=device, max_bounces=args.bounces, rank=rank, nranks=world, band_rows=BAND_ROWS,
                   frames_in_flight=args.inflight, frames_per_launch=args.batch)
     ctx.recreate_octree(pos, mrgb)
     ctx.camera = Camera(*cam)
@@ -162,63 +204,212 @@ def main():
 
     ctx.render_frames(TRACE, args.warmup)
     barrier()
-    ctx.reset_stats()
-    barrier()
     t0 = time.perf_counter()
-    ctx.render_frames(TRACE | TIMED, args.steps)   # K steps = K frames, submitted back to back
+    ctx.render_frames(TRACE, args.steps)        # one untimed block: sizes the number of repetitions
     ctx.sync()
-    if dist is not None:
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    st = ctx.stats()
-    rays, kernel_ms, local_px = st.rays, st.trace_ms, st.pixels // max(args.steps, 1)
+    est = reduce_max(dist, torch, red_dev, [time.perf_counter() - t0])[0]
+    blocks = block_count(est, args.blocks)
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        r = torch.tensor([rays], dtype=torch.int64, device=red_dev)
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        rays = int(r.item())
+    times, rays_blk, kernel_ms, launches, frames_timed, local_px = [], [], 0.0, 0, 0, 0
+    for _ in range(blocks):
+        ctx.reset_stats()
+        barrier()
+        t0 = time.perf_counter()
+        ctx.render_frames(TRACE | TIMED, args.steps)   # K steps = K frames, submitted back to back
+        ctx.sync()
+        if dist is not None:
+            torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        st = ctx.stats()
+        elapsed = reduce_max(dist, torch, red_dev, [elapsed])[0]
+        rays = reduce_sum(dist, torch, red_dev, [st.rays])[0]
+        times.append(elapsed)
+        rays_blk.append(rays)
+        kernel_ms += st.trace_ms
+        launches += st.timed_launches
+        frames_timed += st.timed_frames
+        local_px = st.pixels // max(args.steps, 1)
+    scene_bytes = st.scene_bytes
 
     if rank == 0:
-        # Roofline of the trace stage = trace_kernel (every pixel up to its second hit) + bounce_kernel (the paths still
-        # alive there, compacted), back to back on one stream, covering `frames_per_launch` consecutive frames;
-        # launch_ms is the HIP-event time around the pair (rocprofv3's two average durations add up to it).  With S
-        # launches in flight S such pairs overlap on the GPU, so a pair's own duration is ~S x the time the chip
-        # spends on it: achieved = S x algorithmic bytes per launch / average pair duration.
-        launches = max(st.timed_launches, 1)
-        launch_ms = kernel_ms / launches
-        frames_per_launch = st.timed_frames / launches
-        alg = algorithmic_bytes(local_px, BOUNCES, st.scene_bytes)       # per frame
-        conc = max(1, min(args.inflight, launches))
-        achieved = conc * frames_per_launch * alg / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        order = np.argsort(times)
+        mid = int(order[len(order) // 2])
+        elapsed, rays = times[mid], rays_blk[mid]            # the median block
+        launch_ms = kernel_ms / max(launches, 1)
+        frames_per_launch = frames_timed / max(launches, 1)
+        alg = algorithmic_bytes(local_px, args.bounces, scene_bytes)       # per frame, this rank
+        wall = alg * args.steps / elapsed / 1e9                          # GB/s the block's wall time amounts to
+        conc = max(1, min(args.inflight, launches // max(blocks, 1)))
+        prof, prof_path = recorded_profile()
+        default_cfg = world == 1 and args.view == "bench" and args.bounces == 4
+        roof = {
+            # what the profile shows: VALU issue, not bandwidth, limits this stage (the `valu` object below).  The HBM
+            # figures stay because the path is nominally HBM-bound work (no contraction, no MFMA): achieved = algorithmic bytes of
+            # the K steps / the block's wall time; frac follows from wall time and nothing else.
+            "bound": "valu", "nominal_bound": "hbm", "kernel": "trace_kernel + bounce_kernel (one trace stage)",
+            "achieved": round(wall, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(wall / HBM_PEAK_GBS, 5),
+            "algorithmic_bytes_per_step": int(alg),
+            "traffic": None, "traffic_source": None,
+            # diagnostic, launch basis: HIP-event time around one launch (trace_kernel + bounce_kernel over frames_per_launch
+            # frames); `concurrent_launches` of them overlap, so bytes / launch_ms understates and x concurrency overstates
+            "launch": {"launch_ms": round(launch_ms, 4), "frames_per_launch": round(frames_per_launch, 2),
+                       "concurrent_launches": conc, "algorithmic_bytes_per_launch": int(alg * frames_per_launch),
+                       "gbs_one_launch_alone": round(alg * frames_per_launch / (launch_ms * 1e-3) / 1e9, 2) if launch_ms > 0 else None},
+        }
+        if prof is not None and default_cfg:
+            try:
+                t = prof["traffic"]
+                roof["traffic"] = float(t["hbm_bytes_per_launch_corrected"]) / float(t["frames_per_launch"])
+                roof["traffic_source"] = (f"RECORDED in {prof_path} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, read "
+                                          "side doubled per MI355X_MICROARCH.md), per step; not measured by this run")
+            except (KeyError, ValueError, TypeError, ZeroDivisionError):
+                pass
+            try:
+                sq = prof["sq"]
+                per_frame = sum(k["valu_wave_instr_per_launch"] for k in sq.values()) / float(prof["traffic"]["frames_per_launch"])
+                # 1024 SIMDs; a wave64 VALU instruction occupies its SIMD's issue port for 2 cycles at ~2.4 GHz
+                roof["valu"] = {"source": f"RECORDED in {prof_path} (rocprofv3 --pmc SQ_* pass), not measured by this run",
+                                "valu_wave_instr_per_step": round(per_frame),
+                                "issue_slot_frac": round(per_frame * 2 / (1024 * 2.4e9 * (elapsed / args.steps)), 3),
+                                "lane_utilisation": {k: round(v["lane_utilisation"], 3) for k, v in sq.items() if v.get("lane_utilisation")},
+                                "waitcnt_share": {k: round(v["waitcnt_share_of_wave_cycles"], 3) for k, v in sq.items()
+                                                  if v.get("waitcnt_share_of_wave_cycles")}}
+            except (KeyError, ValueError, TypeError, ZeroDivisionError):
+                pass
         out = {
             "metric": "Mrays/s", "value": round(rays / elapsed / 1e6, 2), "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"vox/{SCENE}.vox {WIDTH}x{HEIGHT}, 1 spp, {BOUNCES} bounces, trace stage only "
+            "config": {"workload": f"vox/{SCENE}.vox {WIDTH}x{HEIGHT}, 1 spp, {args.bounces} bounces, trace stage only "
                                    f"(BASELINE configs[1]); camera '{args.view}' of SURVEY §8d; Uniforms::default()",
                        "parallelism": f"screen bands x{world} ({BAND_ROWS}-row interleave, scene replicated)",
                        "launches_in_flight": args.inflight, "frames_per_launch": args.batch,
                        "rays_per_frame": rays // args.steps, "rays_per_pixel": round(rays / args.steps / (WIDTH * HEIGHT), 4),
                        "mpixels_per_s": round(WIDTH * HEIGHT * args.steps / elapsed / 1e6, 1)},
-            "roofline": {"bound": "hbm", "kernel": "trace_kernel + bounce_kernel (one trace stage)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": measured_traffic(frames_per_launch) if (world == 1 and args.view == "bench" and BOUNCES == 4) else None,
-                         "launch_ms": round(launch_ms, 4), "concurrent_launches": conc,
-                         "frames_per_launch": round(frames_per_launch, 2),
-                         "algorithmic_bytes_per_launch": int(alg * frames_per_launch),
-                         "achieved_wall_basis": round(alg * args.steps / elapsed / 1e9, 2)},
+            "timing": {"blocks": blocks, "steps_per_block": args.steps, "reported": "median block",
+                       "block_ms": {"min": round(min(times) * 1e3, 4), "median": round(elapsed * 1e3, 4), "max": round(max(times) * 1e3, 4)},
+                       "timed_region_s_total": round(sum(times), 3),
+                       "note": "ms_per_step is reciprocal THROUGHPUT (frames of a camera at rest, several per launch, launches "
+                               "overlapping); the latency of one vxrt_render call is ~0.3 ms (DESIGN.md §7)"},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pos, mrgb, cam)
+            out["cpu_baseline_cpu_rs"] = cpu_baseline_cpu_rs()
         print(json.dumps(out), flush=True)
 
     ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pipeline_bench(args):
+    """BASELINE configs[3]: vox/castle.vox at 3840x2160, 4 spp, screen bands over the ranks, temporal + denoise (r = 8) with the
+    halo exchange: per displayed frame  render_spp(TRACE | TEMPORAL, 4) -> vxrt_halo_export -> batch_isend_irecv (RCCL) ->
+    vxrt_halo_import -> DENOISE.  One step = one displayed frame; the exchange is timed apart (host clock around a synchronised
+    exchange) and the halo bytes per rank are reported."""
+    world, rank, device, dist, torch, backend = init_dist()
+    args.gpus = world
+    red_dev = "cuda" if backend == "nccl" else "cpu"
+    from gpu_voxel_raytracer_amd import DENOISE, TEMPORAL, TRACE, Camera, Context, distributed, scenes
+    w, h, bounces, spp, radius, band = 3840, 2160, 8, 4, args.radius, 16
+    pos, mrgb, size = scenes.load_scene("castle")
+    cam = scenes.close_camera(size)
+    ctx = Context(w, h, device=device, max_bounces=bounces, rank=rank, nranks=world, band_rows=band, frames_in_flight=1,
+                  frames_per_launch=spp)
+    ctx.recreate_octree(pos, mrgb)
+    ctx.camera = Camera(*cam)
+    ctx.denoise_uniforms.radius = radius
+    if world > 1 and torch is None:
+        import torch
+    halo = None
+    if world > 1:   # halo buffers on this rank's GPU; messages over RCCL, or staged through the host for a gloo rehearsal
+        halo = distributed.HaloExchange(ctx, dist, rank, world, torch.device("cuda", device), torch,
+                                        comm_device=None if backend == "nccl" else "cpu")
+    xchg = [0.0]
+
+    def frame():
+        ctx.render_spp(TRACE | TEMPORAL, spp)
+        if halo is not None and radius > 0:
+            ctx.sync()
+            t0 = time.perf_counter()
+            halo.exchange()
+            xchg[0] += time.perf_counter() - t0
+        ctx.render_stage(DENOISE)
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+            if backend == "nccl":
+                torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        frame()
+    barrier()
+    ctx.reset_stats()
+    xchg[0] = 0.0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame()
+    ctx.sync()
+    if dist is not None and backend == "nccl":
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    st = ctx.stats()
+    elapsed, x = reduce_max(dist, torch, red_dev, [elapsed, xchg[0]])
+    rays = reduce_sum(dist, torch, red_dev, [st.rays])[0]
+    if rank == 0:
+        px = w * h
+        alg = (48 * spp + 16 * spp + 16 + 80 + 64) * px     # spp trace frames + their average + temporal + denoise (SURVEY §8d)
+        out = {"metric": "Mrays/s", "value": round(rays / elapsed / 1e6, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"vox/castle.vox {w}x{h}, {spp} spp, {bounces} bounces, temporal + denoise r={radius} "
+                                      f"(BASELINE configs[3]); one step = one displayed frame",
+                          "parallelism": f"screen bands x{world} ({band}-row interleave, scene replicated), denoise halo over "
+                                         f"{'RCCL send/recv' if backend == 'nccl' else backend}"},
+               "halo": {"bytes_per_rank_per_frame": 2 * ctx.halo_bytes() if world > 1 else 0,
+                        "exchange_ms_per_frame": round(x / args.steps * 1e3, 4), "share_of_frame": round(x / elapsed, 4)},
+               "stage_ms_per_frame": {"trace": round(st.trace_ms / args.steps, 4), "temporal": round(st.temporal_ms / args.steps, 4),
+                                      "denoise": round(st.denoise_ms / args.steps, 4)},
+               "roofline": {"bound": "valu", "nominal_bound": "hbm", "kernel": "whole frame loop", "achieved": round(alg * args.steps / elapsed / 1e9, 2),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5), "traffic": None}}
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=0, help="frames per timed block (default 960: whole launches for every schedule, 2x16 .. 3x32; "
+                                                          "--pipeline: 24 displayed frames)")
+    ap.add_argument("--warmup", type=int, default=-1)
+    ap.add_argument("--blocks", type=int, default=0, help="timed blocks of --steps frames (default: >= 50 and >= 1 s of GPU time)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", action="store_true", help="time the whole frame loop with the denoise halo exchange (BASELINE configs[3])")
+    ap.add_argument("--radius", type=int, default=8, help="--pipeline: denoise radius")
+    ap.add_argument("--view", default="bench", choices=["bench", "close", "away"])
+    ap.add_argument("--bounces", type=int, default=BOUNCES, help="diagnostic only; the benchmark is 4")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="trace launches that may be on the GPU together, one HIP stream each (default: 2 on one GPU, 3 per rank otherwise)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="consecutive frames per trace launch (vxrt_config.frames_per_launch; default: 16, 32 from 4 ranks on; a short block "
+                         "is dealt to the launches in equal parts)")
+    args = ap.parse_args()
+    if args.pipeline:
+        args.steps = args.steps or 24
+        args.warmup = 4 if args.warmup < 0 else args.warmup
+        pipeline_bench(args)
+    else:
+        args.steps = args.steps or 960
+        args.warmup = 96 if args.warmup < 0 else args.warmup
+        trace_bench(args)
 
 
 if __name__ == "__main__":

@@ -19,23 +19,42 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
          "-Wno-unused-parameter"]
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+STAMP = LIB + ".srchash"   # what the library was built from (travels with it to the GPU box; modification times do not survive the trip)
+
+
+def source_hash(extra_flags=()):
+    """sha256 over the sources, headers and flags that make libvxrt.so."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read() + b"\0")
+    h.update(" ".join(FLAGS + list(extra_flags)).encode())
+    return h.hexdigest()
+
+
+def needs_build(extra_flags=()):
+    """True when libvxrt.so is missing or was built from other sources / flags than the tree holds now (by content)."""
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    try:
+        return open(STAMP).read().strip() != source_hash(extra_flags)
+    except OSError:
+        return True
 
 
 def build(force=False, verbose=False, extra_flags=()):
-    if not force and not needs_build():
+    extra_flags = list(extra_flags) + os.environ.get("VXRT_HIPCC_FLAGS", "").split()
+    if not force and not needs_build(extra_flags):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra_flags = list(extra_flags) + os.environ.get("VXRT_HIPCC_FLAGS", "").split()
-    cmd = [hipcc] + FLAGS + extra_flags + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB, "-lz"]
+    cmd = [hipcc] + FLAGS + extra_flags + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp", "-lz"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)      # other processes keep the library they mapped; new ones see a whole file
+    with open(STAMP, "w") as f:
+        f.write(source_hash(extra_flags) + "\n")
     return LIB
 
 

@@ -115,6 +115,7 @@ struct DenoiseArgs {
     Cam cam;
     uint32_t radius;
     float sigma_distance_2, sigma_range_2, albedo_factor;
+    int mode;   // 0 exact (bit-identical to the oracle), 1 tolerant (vxrt_set_option VXRT_OPT_DENOISE_MODE)
 };
 
 // Queue of live paths between two launches of the wavefront tracer (trace.hip): 64-byte records in 64 shards.

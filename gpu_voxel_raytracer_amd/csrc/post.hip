@@ -155,6 +155,13 @@ __global__ __launch_bounds__(256) void denoise_passthrough_kernel(const DenoiseA
 }
 
 // One 16x16 output tile per block, radius 1..8.
+// kTolerant = false: denoise.comp:64-80 operation for operation (IEEE division by sigma_range_2, the polynomial vx_exp of
+// include/vxrt_detmath.h): bit-identical to the oracle; ~85 instructions per tap, of which the division and the exponential are 40.
+// kTolerant = true (VXRT_OPT_DENOISE_MODE 1): the same weight as 2^(-(range terms) * log2(e) / sigma_range_2 - distance term * log2(e))
+// with the reciprocal folded into one multiplier, fused multiply-adds and the hardware's v_exp_f32 — ~30 instructions per tap.
+// The weight's relative error is ~|arg| * 2^-22 <= 2e-5; the filtered colour is a normalised average of such weights
+// (tests/test_gpu_pipeline.py: RMSE and maximum error against the oracle at 3840x2160, radius 8).
+template <bool kTolerant>
 __global__ __launch_bounds__(256) void denoise_kernel(const DenoiseArgs a) {
     extern __shared__ float4 lds_raw[];
     const int r = int(a.radius);
@@ -171,6 +178,7 @@ __global__ __launch_bounds__(256) void denoise_kernel(const DenoiseArgs a) {
     for (int i = threadIdx.x; i < taps * taps; i += 256) {
         const int dx = i % taps - r, dy = i / taps - r;
         wdist[i] = float(dx * dx + dy * dy) / a.sigma_distance_2;   // denoise.comp:79
+        if (kTolerant) wdist[i] *= 1.44269504088896341f;            // in units of log 2: the weight is an exp2 there
     }
     for (int i = threadIdx.x; i < tw * tw; i += 256) {
         int tx = i % tw, ty = i / tw;
@@ -221,6 +229,7 @@ __global__ __launch_bounds__(256) void denoise_kernel(const DenoiseArgs a) {
 
     float normalization = 0.0f;
     f3 sum = splat3(0.0f);
+    const float range_scale = -1.44269504088896341f / a.sigma_range_2;   // tolerant mode: -log2(e) / sigma_range_2
     for (int dy = -r; dy <= r; dy++) {
         const float4* rowA = tileA + (ly + r + dy) * tw + lx;
         const float4* rowB = tileB + (ly + r + dy) * tw + lx;
@@ -235,6 +244,16 @@ __global__ __launch_bounds__(256) void denoise_kernel(const DenoiseArgs a) {
             float depth_delta = clogd - wa.w;
             float material_delta = cmat != (wflags & 0xff) ? 1.0f : 0.0f;
             float bd = depth_bias * depth_delta;
+            if (kTolerant) {
+                float q = __builtin_fmaf(color_delta.z, color_delta.z, __builtin_fmaf(color_delta.y, color_delta.y, color_delta.x * color_delta.x));
+                float n2 = __builtin_fmaf(normal_delta.z, normal_delta.z, __builtin_fmaf(normal_delta.y, normal_delta.y, normal_delta.x * normal_delta.x));
+                n2 = __builtin_fmaf(bd, bd, n2) + material_delta;
+                q = __builtin_fmaf(1e4f, n2, q);
+                const float factor = __builtin_amdgcn_exp2f(__builtin_fmaf(q, range_scale, -rowW[dx]));
+                normalization += factor;
+                sum = mk3(__builtin_fmaf(wc.x, factor, sum.x), __builtin_fmaf(wc.y, factor, sum.y), __builtin_fmaf(wc.z, factor, sum.z));
+                continue;
+            }
             float factor_range = (((dot3(color_delta, color_delta) + 1e4f * dot3(normal_delta, normal_delta)) + 1e4f * (bd * bd)) +
                                   1e4f * material_delta) / a.sigma_range_2;
             float arg = -factor_range - rowW[dx];
@@ -325,7 +344,10 @@ hipError_t launch_denoise(const DenoiseArgs& a, hipStream_t s) {
     dim3 grid((a.band.width + 15) / 16, (a.band.local_rows + 15) / 16);
     int tw = 16 + 2 * int(a.radius), taps = 2 * int(a.radius) + 1;
     size_t lds = size_t(tw) * tw * 32 + size_t(taps * taps + 3) / 4 * 16;
-    hipLaunchKernelGGL(denoise_kernel, grid, dim3(256), lds, s, a);
+    if (a.mode == 1)
+        hipLaunchKernelGGL(denoise_kernel<true>, grid, dim3(256), lds, s, a);
+    else
+        hipLaunchKernelGGL(denoise_kernel<false>, grid, dim3(256), lds, s, a);
     return hipGetLastError();
 }
 

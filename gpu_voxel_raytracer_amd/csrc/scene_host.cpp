@@ -98,6 +98,37 @@ void builtin_palette(uint32_t* pal) {
 
 }  // namespace
 
+// What Rust's `str::parse::<f32>()` accepts (src/vox.rs:93-96 parses `_flux` with it): [+-] then "inf" | "infinity" | "nan"
+// (any case) or a decimal number — digits with an optional point (at least one digit on either side) and an optional
+// e/E[+-]digits exponent.  No blanks, no hex floats, no "nan(...)", which C's strtof would all accept.
+bool is_rust_f32_literal(const std::string& t) {
+    size_t i = 0;
+    const size_t n = t.size();
+    if (i < n && (t[i] == '+' || t[i] == '-')) i++;
+    auto lower_eq = [&](const char* w) {
+        size_t k = 0;
+        for (; w[k]; k++)
+            if (i + k >= n || (t[i + k] | 0x20) != w[k]) return false;
+        return i + k == n;
+    };
+    if (lower_eq("inf") || lower_eq("infinity") || lower_eq("nan")) return true;
+    size_t digits = 0;
+    while (i < n && t[i] >= '0' && t[i] <= '9') { i++; digits++; }
+    if (i < n && t[i] == '.') {
+        i++;
+        while (i < n && t[i] >= '0' && t[i] <= '9') { i++; digits++; }
+    }
+    if (digits == 0) return false;
+    if (i < n && (t[i] == 'e' || t[i] == 'E')) {
+        i++;
+        if (i < n && (t[i] == '+' || t[i] == '-')) i++;
+        size_t ed = 0;
+        while (i < n && t[i] >= '0' && t[i] <= '9') { i++; ed++; }
+        if (ed == 0) return false;
+    }
+    return i == n;
+}
+
 int decode_vox(const uint8_t* bytes, size_t len, VoxScene* out) {
     Span file(bytes, len);
     if (!file.has_prefix("VOX ")) { set_error("invalid magic number"); return VXRT_E_VOX_MAGIC; }
@@ -174,10 +205,7 @@ int decode_vox(const uint8_t* bytes, size_t len, VoxScene* out) {
                         return VXRT_E_VOX_MATERIAL;
                     }
                 } else if (key == "_flux") {
-                    std::string tmp(value);
-                    char* end = nullptr;
-                    (void)strtof(tmp.c_str(), &end);
-                    if (tmp.empty() || end != tmp.c_str() + tmp.size()) {
+                    if (!is_rust_f32_literal(std::string(value))) {
                         set_error("failed to parse value of material key `_flux`");
                         return VXRT_E_VOX_MATERIAL;
                     }

@@ -54,6 +54,9 @@ struct CameraBasis {
 // Camera::axis_scaled (src/camera.rs:19-28).
 CameraBasis camera_axis_scaled(const float dir[3], float fov, uint32_t width, uint32_t height);
 
+// the grammar of Rust's str::parse::<f32>() (`_flux` in MATL chunks, src/vox.rs:93-96)
+bool is_rust_f32_literal(const std::string& text);
+
 float noise_value(uint32_t seed, uint32_t index);  // documented in vxrt.h (vxrt_noise_table)
 
 // Level-L Menger sponge: cell (x,y,z) in [0,3^L)^3 is solid unless, at some base-3 digit position,

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const Trac
     const bool active = x < a.band.width && lrow < a.band.local_rows && y < a.band.height;
 
     uint32_t rays = 0;
-    bool to_tail = false;  // this lane's path continues in bounce_kernel (TraceArgs::tail)
+    const unsigned tail_shard = (blockIdx.x * unsigned(kTB / 64) + unsigned(wave)) % kShards;
+    uint32_t tail_slot = kNoSlot;  // != kNoSlot: this lane's path continues in bounce_kernel (TraceArgs::tail), from that record
     PathRec rec;
     rec.node = 0; rec.normal_ambient = 0; rec.rng_index = 0; rec.pix = 0;
     rec.hit_pos = rec.dir = rec.sample = rec.blend = splat3(0.0f);
@@ -129,7 +130,9 @@ __global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const Trac
                 f3 alb = (hit.node & kEmitBit) == 0 ? node_color(hit.node) : splat3(1.0f);
                 store_out(fo.albedo + pix, make_float4(alb.x, alb.y, alb.z, __int_as_float(hit.node)));
             }
-            if (a.tail.recs != nullptr && bounce == a.tail_from) {  // hand the path over, in the state bounce_kernel resumes from
+            // hand the path over, in the state bounce_kernel resumes from — unless the queue is full (it is sized from what
+            // earlier launches queued): then this lane goes on as in the all-in-one kernel
+            if (a.tail.recs != nullptr && bounce == a.tail_from && (tail_slot = queue_reserve(a.tail, tail_shard)) != kNoSlot) {
                 rec.hit_pos = hit_pos;
                 rec.node = hit.node;
                 rec.dir = d;
@@ -138,7 +141,6 @@ __global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const Trac
                 rec.blend = blend;
                 rec.rng_index = rng.index;
                 rec.pix = uint32_t(pix) | fb << kPixBits;
-                to_tail = true;
                 break;
             }
 
@@ -176,14 +178,14 @@ __global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const Trac
             if (++bounce >= a.max_bounces) break;
         }
 
-        if (!to_tail) {
+        if (tail_slot == kNoSlot) {
             f3 out = sample / float(ambient_rays);  // voxels.comp:391
             store_out(fo.color + pix, make_float4(out.x, out.y, out.z, 1.0f));
         }
     }
     if (a.tail.recs != nullptr) {
         zero_counts(a.tail_zero, tid);
-        queue_append(a.tail, (blockIdx.x * unsigned(kTB / 64) + unsigned(wave)) % kShards, to_tail, rec, lane);
+        if (tail_slot != kNoSlot) queue_store(a.tail, tail_shard, tail_slot, rec);
     }
 
     count_rays(a.ray_counter, rays, lane);

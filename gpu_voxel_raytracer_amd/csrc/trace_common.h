@@ -606,6 +606,30 @@ __device__ __forceinline__ void queue_append(const PathQueue& q, unsigned shard,
     }
 }
 
+// The same, for a queue that is sized by need instead of for the worst case (the compacted tail: vxrt_api.hip sizes it from what
+// earlier launches queued): called from INSIDE the path loop by exactly the lanes that want to hand their path over.  Returns the
+// lane's record slot in the shard, or kNoSlot when the shard is full — the lane then keeps following its path itself, which gives
+// the same result (the hand-over only moves work).  The shard's counter keeps counting past the capacity, so the host sees how
+// much room was wanted; consumers clamp it (queue_count).
+constexpr uint32_t kNoSlot = 0xffffffffu;
+__device__ __forceinline__ uint32_t queue_reserve(const PathQueue& q, unsigned shard) {
+    const unsigned long long m = __ballot(1);   // the lanes that are here
+    const unsigned rank = __builtin_amdgcn_mbcnt_hi(unsigned(m >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(m), 0u));
+    unsigned base = 0;
+    if (rank == 0u) base = atomicAdd(q.counts + shard * kCountStride, unsigned(__popcll(m)));
+    base = __builtin_amdgcn_readfirstlane(base);
+    const unsigned slot = base + rank;
+    return slot < q.shard_capacity ? slot : kNoSlot;
+}
+__device__ __forceinline__ void queue_store(const PathQueue& q, unsigned shard, uint32_t slot, const PathRec& rec) {
+    store_rec(q.recs + (size_t(shard) * q.shard_capacity + slot) * 4u, rec);
+}
+// records a consumer finds in shard `shard`
+__device__ __forceinline__ unsigned queue_count(const PathQueue& q, unsigned shard) {
+    const unsigned n = q.counts[shard * kCountStride];
+    return n < q.shard_capacity ? n : q.shard_capacity;
+}
+
 constexpr unsigned kFlagSun = 1u, kFlagBounce = 2u;
 struct Shaded {  // what shading a hit produces
     f3 sample, blend, pend_sun, pend_emit, origin, sun_dir, bounce_dir;

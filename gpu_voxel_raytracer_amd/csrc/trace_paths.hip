@@ -45,7 +45,7 @@ __global__ __launch_bounds__(kBlock, VXRT_PATH_WAVES) void path_kernel(const Tra
     uint2* stack = lds_stack + tid;
 
     // chunk table (as in bounce_kernel): lane q owns shard q; chunk c lives in the shard whose inclusive chunk count exceeds c
-    const unsigned my_count = in.counts[lane * kCountStride];
+    const unsigned my_count = queue_count(in, unsigned(lane));
     const unsigned my_chunks = (my_count + 63u) / 64u;
     unsigned incl = my_chunks;
     for (int off = 1; off < 64; off <<= 1) {

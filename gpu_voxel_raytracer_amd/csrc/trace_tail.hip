@@ -26,7 +26,7 @@ __global__ __launch_bounds__(kTailBlock, VXRT_BOUNCE_WAVES) void bounce_kernel(c
     uint2* stack = lds_stack + tid;
 
     // chunk table: lane q owns shard q
-    const unsigned my_count = in.counts[lane * kCountStride];
+    const unsigned my_count = queue_count(in, unsigned(lane));
     const unsigned my_chunks = (my_count + 63u) / 64u;
     unsigned incl = my_chunks;
     for (int off = 1; off < 64; off <<= 1) {
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(kTailBlock, VXRT_BOUNCE_WAVES) void bounce_kernel(c
         const unsigned entry = (c - first) * 64u + unsigned(lane);
         const bool valid = entry < count_q;
 
-        bool keep = false;
+        uint32_t out_slot = kNoSlot;   // != kNoSlot: the path goes on in the next launch, from that record of `out`
         PathRec rec;
         rec.node = 0; rec.normal_ambient = 0; rec.rng_index = 0; rec.pix = 0;
         rec.hit_pos = rec.dir = rec.sample = rec.blend = splat3(0.0f);
@@ -112,14 +112,14 @@ __global__ __launch_bounds__(kTailBlock, VXRT_BOUNCE_WAVES) void bounce_kernel(c
                     store_out(a.out[rec.pix >> kPixBits].color + (rec.pix & ((1u << kPixBits) - 1u)), make_float4(outc.x, outc.y, outc.z, 1.0f));
                     break;
                 }
-                if (bounce == last_bounce) {
+                // compact again: to the next queue — unless that is full, then this lane simply goes on
+                if (bounce == last_bounce && (out_slot = queue_reserve(out, c % kShards)) != kNoSlot) {
                     rec.rng_index = rng.index;
-                    keep = true;
                     break;
                 }
             }
         }
-        queue_append(out, c % kShards, keep, rec, lane);
+        if (out_slot != kNoSlot) queue_store(out, c % kShards, out_slot, rec);
     }
     count_rays(a.ray_counter, rays, lane);
 }

@@ -96,6 +96,9 @@ struct Node {
     std::vector<int32_t> models;    // S
 };
 
+constexpr size_t kMaxPlacedVoxels = size_t(1) << 27;   // 1 GiB of Voxel records
+constexpr long kMaxTranslation = 1L << 20;               // |_t| beyond this cannot place anything inside 16-bit coordinates
+
 struct Placer {
     const std::vector<Model>& models;
     const std::map<int32_t, Node>& nodes;
@@ -108,6 +111,8 @@ struct Placer {
 
     int place(const Model& m, const Xform& xf) {
         const int64_t pivot[3] = {m.size[0] / 2, m.size[1] / 2, m.size[2] / 2};
+        // a shape graph may instance one model any number of times: bound what a file can make this process allocate
+        if (out->size() + size_t(m.count) > kMaxPlacedVoxels) { set_error("scene places more than 2^27 voxels"); return VXRT_E_SCENE; }
         const uint8_t* c = m.cells;
         for (uint32_t i = 0; i < m.count; i++, c += 4) {
             // doubled coordinates of the cell centre relative to the pivot: odd integers, so R p + 2t is odd as well
@@ -240,9 +245,7 @@ int decode_vox_scene(const uint8_t* bytes, size_t len, uint32_t flags, VoxScene*
             }
             auto flux = d.find("_flux");
             if (flux != d.end() && !lenient) {
-                char* end = nullptr;
-                (void)strtof(flux->second.c_str(), &end);
-                if (flux->second.empty() || end != flux->second.c_str() + flux->second.size()) {
+                if (!is_rust_f32_literal(flux->second)) {
                     set_error("failed to parse value of material key `_flux`");
                     return VXRT_E_VOX_MATERIAL;
                 }
@@ -267,6 +270,7 @@ int decode_vox_scene(const uint8_t* bytes, size_t len, uint32_t flags, VoxScene*
                     for (int a = 0; a < 3; a++) {
                         v[a] = strtol(s, &end, 10);
                         if (end == s) { set_error("bad _t in nTRN"); return VXRT_E_SCENE; }
+                        if (v[a] > kMaxTranslation || v[a] < -kMaxTranslation) { set_error("nTRN translation out of range"); return VXRT_E_SCENE; }
                         s = end;
                     }
                     for (int a = 0; a < 3; a++) nd.xf.t[a] = v[a];
@@ -329,6 +333,8 @@ int decode_vox_scene(const uint8_t* bytes, size_t len, uint32_t flags, VoxScene*
     }
     if (out->voxels.empty()) { for (int a = 0; a < 3; a++) pl.lo[a] = pl.hi[a] = 0; }
     if ((flags & VXRT_VOX_REBASE) && !out->voxels.empty()) {
+        for (int a = 0; a < 3; a++)
+            if (pl.hi[a] - pl.lo[a] > 32767) { set_error("re-based scene does not fit 16-bit voxel coordinates"); return VXRT_E_SCENE; }
         for (Voxel& v : out->voxels) { v.x = int16_t(v.x - pl.lo[0]); v.y = int16_t(v.y - pl.lo[2]); v.z = int16_t(v.z - pl.lo[1]); }
         for (int a = 0; a < 3; a++) { pl.hi[a] -= pl.lo[a]; pl.lo[a] = 0; }
     }

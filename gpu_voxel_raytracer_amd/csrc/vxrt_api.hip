@@ -130,9 +130,18 @@ struct vxrt_ctx {
         unsigned launches = 0;
         RayQueue rq{};                          // variant 3
         void* rq_block = nullptr;
+        // tail queue sized by need (variants 4 / 5): the counters trace_kernel wrote, copied back after every launch
+        unsigned* host_counts = nullptr;        // pinned, one set: 64 counters, 16 uints apart
+        hipEvent_t counts_ready = nullptr;
+        bool counts_pending = false;
     };
     std::vector<StreamQueues> queues;
-    unsigned shard_capacity = 0;
+    unsigned shard_capacity = 0;        // records per shard of the path queues
+    unsigned shard_capacity_max = 0;    // ... in the worst case: every pixel of every frame of a launch hands its path over
+    int tail_capacity_override = 0;     // test hook (VXRT_TAIL_CAPACITY / vxrt_set_option): > 0 pins the capacity
+    uint64_t queue_overflow_paths = 0;  // paths that found their shard full and stayed in the head kernel
+    uint64_t queue_bytes = 0;
+    int denoise_mode = 0;               // VXRT_OPT_DENOISE_MODE: 0 exact (bit-identical to the oracle), 1 tolerant (post.hip)
     // 0 = monolithic trace_kernel (all bounces in one launch; default), 2 = wavefront launches per path segment,
     // 3 = ray queues: shade / trace launches with per-lane ray refill
     int trace_variant = 0;
@@ -199,8 +208,11 @@ void free_images(vxrt_ctx* c) {
         for (float4** p : {&sq.hitq[0], &sq.hitq[1]}) { if (*p) (void)hipFree(*p); *p = nullptr; }
         if (sq.counts3) (void)hipFree(sq.counts3);
         if (sq.rq_block) (void)hipFree(sq.rq_block);
+        if (sq.host_counts) (void)hipHostFree(sq.host_counts);
+        if (sq.counts_ready) (void)hipEventDestroy(sq.counts_ready);
     }
     c->queues.clear();
+    c->queue_bytes = 0;
 }
 
 int alloc_images(vxrt_ctx* c) {
@@ -228,15 +240,36 @@ int alloc_images(vxrt_ctx* c) {
         HIP_TRY(hipMemsetAsync(*p, 0, bytes, c->stream));
     }
     // path queues: every 8x8-pixel wave of the primary launch appends to shard (wave index % 64)
+    // Worst case: all 64 lanes of each of a shard's waves append (a launch's waves are dealt to the 64 shards round robin).
     const size_t waves = size_t((c->band.width + 15) / 16) * size_t((c->band.local_rows + 15) / 16) * 4 * size_t(c->batch);
-    c->shard_capacity = unsigned((waves + 63) / 64 * 64);
+    c->shard_capacity_max = unsigned((waves + 63) / 64 * 64);
+    c->shard_capacity = c->shard_capacity_max;
+    if (c->trace_variant >= 4) {
+        // The compacted tail takes the paths that are alive at their second hit: 5 % of the bench frame's pixels, about half of a
+        // frame filled with geometry.  An eighth of the worst case to start with (worst case: 64 B x pixels x frames per launch
+        // per queue and stream = 8.5 GB for 1080p at 16 x 2); a launch that wants more keeps the excess paths in the head kernel
+        // (queue_reserve) and the queues grow before the stream's next launch (grow_tail_queues).
+        unsigned cap = c->shard_capacity_max / 8u;
+        cap = cap < 4096u ? 4096u : cap;
+        if (c->tail_capacity_override > 0) cap = unsigned(c->tail_capacity_override);
+        c->shard_capacity = cap < c->shard_capacity_max ? (cap + 63u) / 64u * 64u : c->shard_capacity_max;
+    }
     if (c->trace_variant != 0) {
         c->queues.resize(size_t(c->inflight));
         for (vxrt_ctx::StreamQueues& sq : c->queues) {
             const size_t hit_bytes = (size_t(c->shard_capacity) * 64 + 1) * 64;
-            for (int i = 0; i < (c->trace_variant == 3 ? 1 : 2); i++) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sq.hitq[i]), hit_bytes));
+            // the second queue: the wavefront tracer's ping-pong partner; for the compacted tail only when it compacts again
+            const int nq = c->trace_variant == 3 ? 1 : ((c->trace_variant >= 4 && c->tail_split == 0u) ? 1 : 2);
+            for (int i = 0; i < nq; i++) {
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sq.hitq[i]), hit_bytes));
+                c->queue_bytes += hit_bytes;
+            }
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sq.counts3), 3 * 64 * 64));
             HIP_TRY(hipMemsetAsync(sq.counts3, 0, 3 * 64 * 64, c->stream));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sq.host_counts), 64 * 64, hipHostMallocDefault));
+            memset(sq.host_counts, 0, 64 * 64);
+            HIP_TRY(hipEventCreateWithFlags(&sq.counts_ready, hipEventDisableTiming));
+            sq.counts_pending = false;
             sq.launches = 0;
             if (c->trace_variant == 3) {
                 // Dense queues in kSegments segments.  A shade launch of G blocks (G a multiple of 8) hands every segment
@@ -405,6 +438,46 @@ int upload_scene(vxrt_ctx* c, const Voxel* voxels, size_t n) {
     return upload_svo(c, recs, leaves, tree.depth);
 }
 
+// new capacity (records per shard) for the path queues of every stream; waits for the GPU first
+int resize_tail_queues(vxrt_ctx* c, unsigned want) {
+    want = want > c->shard_capacity_max ? c->shard_capacity_max : (want + 63u) / 64u * 64u;
+    if (want == c->shard_capacity) return VXRT_OK;
+    if (int rc = sync_all(c)) return rc;
+    const size_t hit_bytes = (size_t(want) * 64 + 1) * 64;
+    for (vxrt_ctx::StreamQueues& q : c->queues)
+        for (float4*& p : q.hitq)
+            if (p) {
+                (void)hipFree(p);
+                p = nullptr;
+                c->queue_bytes -= (size_t(c->shard_capacity) * 64 + 1) * 64;
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p), hit_bytes));
+                c->queue_bytes += hit_bytes;
+            }
+    c->shard_capacity = want;
+    return VXRT_OK;
+}
+
+// Tail queues sized by need: look at what the stream's last launch wanted (its shard counters, copied back after the launch) and,
+// if that did not fit, make the stream's queues larger before its next launch.  Paths that did not fit were followed by the head
+// kernel itself, so no frame was wrong — only slower.
+int grow_tail_queues(vxrt_ctx* c, size_t lane, hipStream_t ts) {
+    vxrt_ctx::StreamQueues& sq = c->queues[lane];
+    if (!sq.counts_pending || hipEventQuery(sq.counts_ready) != hipSuccess) return VXRT_OK;
+    sq.counts_pending = false;
+    unsigned peak = 0;
+    for (unsigned s = 0; s < 64; s++) {
+        const unsigned n = sq.host_counts[s * 16];
+        peak = n > peak ? n : peak;
+        if (n > c->shard_capacity) c->queue_overflow_paths += n - c->shard_capacity;
+    }
+    if (peak <= c->shard_capacity || c->tail_capacity_override > 0 || c->shard_capacity >= c->shard_capacity_max) return VXRT_OK;
+    // every stream's queues share one capacity (PathQueue::shard_capacity travels with the launch): grow them all, at rest
+    unsigned want = peak + peak / 4u;
+    want = want < 2u * c->shard_capacity ? 2u * c->shard_capacity : want;
+    (void)ts;
+    return resize_tail_queues(c, want);
+}
+
 bool valid_ctx(const vxrt_ctx* c) {
     if (!c) { set_error("null context"); return false; }
     return true;
@@ -414,7 +487,7 @@ bool valid_ctx(const vxrt_ctx* c) {
 
 extern "C" {
 
-uint32_t vxrt_abi_version(void) { return 2; }
+uint32_t vxrt_abi_version(void) { return 3; }
 
 const char* vxrt_last_error(void) { return vxrt::last_error().c_str(); }
 
@@ -495,6 +568,7 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) try {
     if (const char* v = getenv("VXRT_TAIL_FROM")) c->tail_from = atoi(v);
     if (c->tail_from < 0 || c->tail_from >= int(cfg->max_bounces)) c->tail_from = 1;
     if (const char* v = getenv("VXRT_TAIL_SPLIT")) c->tail_split = unsigned(strtoul(v, nullptr, 0));
+    if (const char* v = getenv("VXRT_TAIL_CAPACITY")) c->tail_capacity_override = atoi(v);   // test hook: force the queue-full path
     if (const char* v = getenv("VXRT_SHADE_BLOCKS")) c->shade_blocks = atoi(v);
     if (const char* v = getenv("VXRT_RAYS_PER_WAVE")) c->rays_per_wave = unsigned(atoi(v));
     c->shade_blocks = (c->shade_blocks < 8 ? 8 : (c->shade_blocks > 2048 ? 2048 : c->shade_blocks) + 7) / 8 * 8;
@@ -612,6 +686,24 @@ int vxrt_set_denoise(vxrt_ctx* c, const vxrt_denoise* d) try {
     if (d->radius > 8) { set_error("denoise radius must be 0..8"); return VXRT_E_INVALID; }
     c->denoise = *d;
     return VXRT_OK;
+} VXRT_CATCH
+
+int vxrt_set_option(vxrt_ctx* c, vxrt_option option, uint32_t value) try {
+    if (!valid_ctx(c)) return VXRT_E_INVALID;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    switch (option) {
+        case VXRT_OPT_DENOISE_MODE:
+            if (value > 1) { set_error("denoise mode must be 0 (exact) or 1 (tolerant)"); return VXRT_E_INVALID; }
+            c->denoise_mode = int(value);
+            return VXRT_OK;
+        case VXRT_OPT_TAIL_CAPACITY:
+            if (c->trace_variant < 4) return VXRT_OK;   // the other tracers' queues are sized for the worst case
+            c->tail_capacity_override = int(value > 0x7fffffffu ? 0x7fffffffu : value);
+            return resize_tail_queues(c, value == 0 ? (c->shard_capacity_max / 8u < 4096u ? 4096u : c->shard_capacity_max / 8u) : value);
+        default:
+            set_error("unknown option");
+            return VXRT_E_INVALID;
+    }
 } VXRT_CATCH
 
 int vxrt_reset_history(vxrt_ctx* c) try {
@@ -743,6 +835,7 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
         if (variant == 0 || variant >= 4) {
             if (variant >= 4) {
                 // count sets rotate as in launch_trace_wavefront: launch J reads set J%3, writes (J+1)%3, clears (J+2)%3
+                if (int rc = grow_tail_queues(c, lane, ts)) return rc;
                 vxrt_ctx::StreamQueues& sq = c->queues[lane];
                 unsigned* sets[3] = {sq.counts3, sq.counts3 + 64 * 16, sq.counts3 + 2 * 64 * 16};
                 const unsigned J = sq.launches;
@@ -751,12 +844,18 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
                 a.tail_from = c->tail_from;
                 HIP_TRY(launch_trace(a, ts));
                 sq.launches = J + 1;
+                if (!sq.counts_pending) {   // how much room this launch wanted (the set stays untouched until launch J + 2 clears it)
+                    HIP_TRY(hipMemcpyAsync(sq.host_counts, sets[(J + 1) % 3], 64 * 64, hipMemcpyDeviceToHost, ts));
+                    HIP_TRY(hipEventRecord(sq.counts_ready, ts));
+                    sq.counts_pending = true;
+                }
                 if (c->trace_variant == 5) {
                     HIP_TRY(launch_paths(a, a.tail, sets[J % 3], c->tail_from, c->path_blocks, ts));
                     sq.launches = J + 2;
                 } else {
-                    PathQueue queues[2] = {{sq.hitq[0], nullptr, c->shard_capacity}, {sq.hitq[1], nullptr, c->shard_capacity}};
-                    HIP_TRY(launch_bounces(a, queues, sets, &sq.launches, c->trace_blocks, c->tail_split, c->tail_from, ts));
+                    // without a second queue (tail_split == 0) nothing is appended to queues[1]: its capacity 0 says so
+                    PathQueue queues[2] = {{sq.hitq[0], nullptr, c->shard_capacity}, {sq.hitq[1], nullptr, sq.hitq[1] ? c->shard_capacity : 0u}};
+                    HIP_TRY(launch_bounces(a, queues, sets, &sq.launches, c->trace_blocks, sq.hitq[1] ? c->tail_split : 0u, c->tail_from, ts));
                 }
             } else {
                 HIP_TRY(launch_trace(a, ts));
@@ -863,6 +962,7 @@ int post_stages(vxrt_ctx* c, uint32_t flags, bool timed) {
         a.sigma_distance_2 = 2.0f * (c->denoise.sigma_distance * c->denoise.sigma_distance);  // denoise.comp:39-40
         a.sigma_range_2 = 2.0f * (c->denoise.sigma_range * c->denoise.sigma_range);
         a.albedo_factor = c->denoise.albedo_factor;
+        a.mode = c->denoise_mode;
         if (c->band.local_rows > 0) {
             EventPair p;
             if (timed) { p = take_pair(c, 2); HIP_TRY(hipEventRecord(p.a, c->stream)); }
@@ -1064,6 +1164,10 @@ int vxrt_get_stats(vxrt_ctx* c, vxrt_stats* out) try {
     out->local_rows = uint32_t(c->band.local_rows);
     out->octree_depth = c->depth;
     out->octree_nodes = c->svo_count;
+    for (size_t lane = 0; lane < c->queues.size(); lane++)   // fold in what the last launches wanted (the GPU is idle here)
+        if (c->trace_variant >= 4) { if (int rc = grow_tail_queues(c, lane, nullptr)) return rc; }
+    out->queue_bytes = c->queue_bytes;
+    out->queue_overflow_paths = c->queue_overflow_paths;
     return VXRT_OK;
 } VXRT_CATCH
 
@@ -1075,6 +1179,7 @@ int vxrt_reset_stats(vxrt_ctx* c) try {
     HIP_TRY(hipMemsetAsync(c->d_rays, 0, kRaySlots * 64, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->frames = c->pixels = c->timed_frames = c->timed_launches = 0;
+    c->queue_overflow_paths = 0;
     c->ms[0] = c->ms[1] = c->ms[2] = 0.0;
     return VXRT_OK;
 } VXRT_CATCH
@@ -1175,6 +1280,8 @@ int vxrt_halo_import(vxrt_ctx* c, const void* dev_from_prev, const void* dev_fro
         HIP_TRY(hipMemcpyAsync(c->halo + size_t(lb * 2 + 1) * per_side, static_cast<const float4*>(dev_from_next) + size_t(lb) * per_side,
                                per_side * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
     }
+    // the caller's buffers are borrowed for this call only (they are torch tensors that may be freed or re-used at once)
+    HIP_TRY(hipStreamSynchronize(c->stream));
     c->halo_radius = uint32_t(r);
     c->halo_valid = true;
     c->halo_epoch = c->temporal_count;

@@ -100,7 +100,11 @@ class Stats(C.Structure):
     _fields_ = [("frames", C.c_uint64), ("rays", C.c_uint64), ("pixels", C.c_uint64), ("trace_ms", C.c_double),
                 ("temporal_ms", C.c_double), ("denoise_ms", C.c_double), ("timed_frames", C.c_uint64),
                 ("timed_launches", C.c_uint64), ("scene_bytes", C.c_uint64), ("noise_bytes", C.c_uint64), ("local_rows", C.c_uint32),
-                ("octree_depth", C.c_uint32), ("octree_nodes", C.c_uint64)]
+                ("octree_depth", C.c_uint32), ("octree_nodes", C.c_uint64), ("queue_bytes", C.c_uint64),
+                ("queue_overflow_paths", C.c_uint64)]
+
+
+OPT_DENOISE_MODE, OPT_TAIL_CAPACITY = 1, 2
 
 
 class Camera:
@@ -122,14 +126,14 @@ class Camera:
 
 
 def lib():
-    """Load libvxrt.so (building it with hipcc first if it is stale or missing)."""
+    """Load libvxrt.so, building it with hipcc first if it is missing or was built from other sources than the tree holds
+    (compared by content hash, _build.needs_build: a stale binary must never run silently).  No fallback: without the
+    library there is no product."""
     global _LIB
     if _LIB is None:
         path = os.environ.get("VXRT_LIB")  # A/B builds of the library (scripts/ab_build.sh); the product build otherwise
         if not path:
-            path = _build.LIB
-            if not os.path.exists(path):
-                path = _build.build()
+            path = _build.build()
         L = C.CDLL(path)
         L.vxrt_last_error.restype = C.c_char_p
         L.vxrt_status_string.restype = C.c_char_p
@@ -397,6 +401,10 @@ class Context:
     def render_stage(self, flags):
         """vxrt_render without re-pushing parameters (multi-GPU: DENOISE after the halo exchange)."""
         _check(lib().vxrt_render(self._h, C.c_uint32(flags)), "vxrt_render")
+
+    def set_option(self, option, value):
+        """vxrt_set_option: OPT_DENOISE_MODE (0 exact, 1 tolerant), OPT_TAIL_CAPACITY (records per queue shard; 0 = automatic)."""
+        _check(lib().vxrt_set_option(self._h, C.c_int(option), C.c_uint32(value)), "vxrt_set_option")
 
     def sync(self):
         _check(lib().vxrt_sync(self._h), "vxrt_sync")

@@ -147,7 +147,20 @@ typedef struct vxrt_stats {
     uint32_t local_rows;      /* rows owned by this context                                             */
     uint32_t octree_depth;
     uint64_t octree_nodes;
+    uint64_t queue_bytes;     /* device bytes of the tracer's path queues (sized by need for tracers 4 / 5)             */
+    uint64_t queue_overflow_paths; /* paths that found their queue shard full and were followed by the head kernel
+                                 instead (same image; the queues grow before the stream's next launch)               */
 } vxrt_stats;
+
+/* Run-time options (none of them changes what a frame means; defaults are the reference's behaviour).
+ *   VXRT_OPT_DENOISE_MODE  0 (default): denoise.comp evaluated exactly as the oracle restates it (bit-identical).
+ *                          1: tolerant — the per-tap weight exp(-(..)/sigma_range_2 - (..)/sigma_distance_2) (denoise.comp:64-80)
+ *                             with a reciprocal multiply and the hardware's exp2; within BASELINE's RMSE <= 1e-3 of mode 0
+ *                             (tests/test_gpu_pipeline.py), about twice as fast for radius >= 4.
+ *   VXRT_OPT_TAIL_CAPACITY records per shard of the compacted tail's path queue (test hook: a small value forces the
+ *                          queue-full path); 0 = back to automatic sizing.                                               */
+typedef enum vxrt_option { VXRT_OPT_DENOISE_MODE = 1, VXRT_OPT_TAIL_CAPACITY = 2 } vxrt_option;
+int vxrt_set_option(vxrt_ctx* ctx, vxrt_option option, uint32_t value);
 
 /* ---- context: replaces Context::new / create_bindings / resize (src/context.rs:595-660, 936-1016,
  *      1430-1461).  resize drops the temporal history like the reference (:1440-1448). -------------- */
@@ -209,6 +222,7 @@ int vxrt_reset_stats(vxrt_ctx* ctx);
 int vxrt_halo_bytes(vxrt_ctx* ctx, size_t* bytes_per_neighbour);
 int vxrt_halo_export(vxrt_ctx* ctx, void* dev_to_prev, void* dev_to_next);
 int vxrt_halo_import(vxrt_ctx* ctx, const void* dev_from_prev, const void* dev_from_next);
+/* Both calls return after their device copies have finished: the caller's buffers are borrowed for the call only. */
 
 /* ---- host-side scene preparation, callable without a GPU (src/vox.rs, src/context.rs:710-834,
  *      913-933, src/camera.rs).  Counts are returned through *n; nothing is written past cap. ------ */

@@ -11,6 +11,8 @@
 // Parity status: UNPINNED by the reference.
 #include <cmath>
 #include <cstring>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "oracle.h"
@@ -195,28 +197,36 @@ using namespace orc;
 
 extern "C" {
 
-// CpuBackend::from_voxels + ::render (src/cpu.rs:13-72).  coords: n x 3 u16, rgb: n x 3 u8.
-// basis9 = right, up, forward_ray from Camera::axis_scaled.  pixels: width*height*3 u8 (row-major).
-// Also returns, per pixel, the primary hit (time, normal, 0x00RRGGBB or -1 for a miss) so the
-// shader-path traversal can be cross-checked against this independent octree.
-void orc_cpu_rs_render(const uint16_t* coords, const uint8_t* rgb, size_t n, const float* cam_pos, const float* basis9,
-                       int width, int height, float time, uint8_t* pixels, float* hit_time, float* hit_normal,
-                       int32_t* hit_value) {
+// CpuBackend::from_voxels (src/cpu.rs:13-30): the octree, kept between frames as the reference keeps its backend.
+struct CpuBackend { CpuOctree tree; };
+
+void* orc_cpu_rs_create(const uint16_t* coords, const uint8_t* rgb, size_t n) {
     uint16_t max_coord = 0;
     for (size_t i = 0; i < 3 * n; i++) if (coords[i] > max_coord) max_coord = coords[i];
     int max_depth = 0;
     if (max_coord != 0) { uint32_t p = 1; while (p < (uint32_t)max_coord + 1) { p <<= 1; max_depth++; } }
-    CpuOctree tree;
-    tree.depth = max_depth;
+    CpuBackend* b = new CpuBackend();
+    b->tree.depth = max_depth;
     for (size_t i = 0; i < n; i++)
-        tree.insert(coords[3 * i], coords[3 * i + 1], coords[3 * i + 2],
-                    ((uint32_t)rgb[3 * i] << 16) | ((uint32_t)rgb[3 * i + 1] << 8) | rgb[3 * i + 2]);
+        b->tree.insert(coords[3 * i], coords[3 * i + 1], coords[3 * i + 2],
+                       ((uint32_t)rgb[3 * i] << 16) | ((uint32_t)rgb[3 * i + 1] << 8) | rgb[3 * i + 2]);
+    return b;
+}
+void orc_cpu_rs_destroy(void* backend) { delete static_cast<CpuBackend*>(backend); }
 
+// CpuBackend::render (src/cpu.rs:32-72).  basis9 = right, up, forward_ray from Camera::axis_scaled.  pixels: width*height*3 u8
+// (row-major).  The reference renders the pixels with rayon's par_iter_mut over all host cores (src/cpu.rs:43-46); here the rows
+// are dealt to `nthreads` std::threads (pixels are independent: the image does not depend on the thread count).
+// Also returns, per pixel, the primary hit (time, normal, 0x00RRGGBB or -1 for a miss) so the
+// shader-path traversal can be cross-checked against this independent octree (hit_time may be null).
+void orc_cpu_rs_render_frame(const void* backend, const float* cam_pos, const float* basis9, int width, int height, float time,
+                             uint8_t* pixels, float* hit_time, float* hit_normal, int32_t* hit_value, int nthreads) {
+    const CpuOctree& tree = static_cast<const CpuBackend*>(backend)->tree;
     float c = 127.0f / 2.0f;
     V3 light_pos = v3(c - 10.0f * std::cos(0.3f * time), 15.0f + 8.0f * std::sin(3.0f * time), c - 13.0f * std::sin(0.3f * time));
     V3 origin = v3(cam_pos[0], cam_pos[1], cam_pos[2]);
     V3 R = v3(basis9[0], basis9[1], basis9[2]), U = v3(basis9[3], basis9[4], basis9[5]), F = v3(basis9[6], basis9[7], basis9[8]);
-    for (int y = 0; y < height; y++) {
+    auto render_row = [&](int y) {
         for (int x = 0; x < width; x++) {
             size_t p = (size_t)y * width + x;
             V3 dir = normalize(((float)x * R - (float)y * U) + F);
@@ -242,7 +252,22 @@ void orc_cpu_rs_render(const uint16_t* coords, const uint8_t* rgb, size_t n, con
             }
             pixels[3 * p] = r; pixels[3 * p + 1] = g; pixels[3 * p + 2] = b;
         }
-    }
+    };
+    if (nthreads <= 1) { for (int y = 0; y < height; y++) render_row(y); return; }
+    std::atomic<int> next(0);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthreads; t++)
+        pool.emplace_back([&] { for (;;) { int y = next.fetch_add(1); if (y >= height) break; render_row(y); } });
+    for (auto& th : pool) th.join();
+}
+
+// from_voxels + one render (the form the parity tests use)
+void orc_cpu_rs_render(const uint16_t* coords, const uint8_t* rgb, size_t n, const float* cam_pos, const float* basis9,
+                       int width, int height, float time, uint8_t* pixels, float* hit_time, float* hit_normal,
+                       int32_t* hit_value) {
+    void* b = orc_cpu_rs_create(coords, rgb, n);
+    orc_cpu_rs_render_frame(b, cam_pos, basis9, width, height, time, pixels, hit_time, hit_normal, hit_value, 1);
+    orc_cpu_rs_destroy(b);
 }
 
 }  // extern "C"

@@ -336,6 +336,36 @@ def cpu_rs_render(coords_u16, rgb_u8, cam_pos, basis9, width, height, time=0.0):
     return pixels, ht, hn, hv
 
 
+class CpuRsBackend:
+    """CpuBackend (src/cpu.rs:9-72): from_voxels once, render per frame over `nthreads` host threads (the reference: rayon)."""
+
+    def __init__(self, coords_u16, rgb_u8):
+        coords = np.ascontiguousarray(coords_u16, np.uint16)
+        rgb = np.ascontiguousarray(rgb_u8, np.uint8)
+        lib().orc_cpu_rs_create.restype = C.c_void_p
+        self._h = C.c_void_p(lib().orc_cpu_rs_create(_p(coords), _p(rgb), C.c_size_t(len(coords))))
+
+    def render(self, cam_pos, basis9, width, height, time=0.0, nthreads=None):
+        pixels = np.zeros((height, width, 3), np.uint8)
+        pos = np.asarray(cam_pos, np.float32)
+        b9 = np.asarray(basis9, np.float32)
+        nthreads = nthreads or os.cpu_count() or 1
+        lib().orc_cpu_rs_render_frame(self._h, _p(pos), _p(b9), C.c_int(width), C.c_int(height), C.c_float(time), _p(pixels),
+                                      None, None, None, C.c_int(nthreads))
+        return pixels
+
+    def close(self):
+        if self._h:
+            lib().orc_cpu_rs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def detmath(fn, x, y=None):
     names = {"sin": 0, "cos": 1, "exp": 2, "log": 3, "pow": 4, "sqrt": 5, "div": 6, "tan": 7, "hemi_y": 9, "hemi_z": 10, "mul": 11, "sub": 12, "flip": 13, "min": 14, "max": 15, "max0": 16, "sign": 17, "clamp": 18, "min0": 19}
     x = np.ascontiguousarray(x, np.float32)

@@ -11,12 +11,35 @@
 
 #include <cstdio>
 #include <cmath>
+#include <cctype>
 #include <cstring>
 #include <map>
 #include <string>
 #include <vector>
 
 namespace orc {
+
+// `value.parse::<f32>()` (src/vox.rs:93-96): core::num::dec2flt accepts  [+-]? ( "inf" | "infinity" | "nan" )  in any case, or
+// [+-]? digits* [ "." digits* ] [ (e|E) [+-]? digits+ ]  with at least one mantissa digit — and nothing else (no blanks, no hex).
+static bool parses_as_rust_f32(const std::string& v) {
+    std::string t = v;
+    if (!t.empty() && (t[0] == '+' || t[0] == '-')) t.erase(0, 1);
+    std::string low = t;
+    for (char& ch : low) if (ch >= 'A' && ch <= 'Z') ch = char(ch - 'A' + 'a');
+    if (low == "inf" || low == "infinity" || low == "nan") return true;
+    size_t i = 0, mant = 0;
+    for (; i < t.size() && isdigit((unsigned char)t[i]); i++) mant++;
+    if (i < t.size() && t[i] == '.') for (i++; i < t.size() && isdigit((unsigned char)t[i]); i++) mant++;
+    if (mant == 0) return false;
+    if (i == t.size()) return true;
+    if (t[i] != 'e' && t[i] != 'E') return false;
+    i++;
+    if (i < t.size() && (t[i] == '+' || t[i] == '-')) i++;
+    if (i == t.size()) return false;
+    for (; i < t.size(); i++) if (!isdigit((unsigned char)t[i])) return false;
+    return true;
+}
+
 
 // ---- byte cursor (src/vox.rs:252-296: read / split / read_u32 / read_str, all little endian) ----
 struct Cur {
@@ -143,10 +166,7 @@ static int parse_vox(const uint8_t* bytes, size_t len, Vox* vox) {
                     else if (val == "_diffuse") kind = 0;
                     else return ORC_E_MATERIAL;
                 } else if (key == "_flux") {  // src/vox.rs:93-96: must parse as f32
-                    char* end = nullptr;
-                    std::string z = val;
-                    (void)strtof(z.c_str(), &end);
-                    if (z.empty() || end == z.c_str() || *end != 0) return ORC_E_MATERIAL;
+                    if (!parses_as_rust_f32(val)) return ORC_E_MATERIAL;
                 }
             }
             vox->materials[id] = kind;

@@ -1,0 +1,71 @@
+"""Worker of tests/test_gpu_distributed.py (not collected by pytest): one of N ranks that SHARE this box's GPU, launched with
+torch.distributed.run over gloo.  Every rank renders its bands of each frame through gpu_voxel_raytracer_amd.distributed
+(trace + temporal -> halo exchange, staged through host memory because gloo carries CPU tensors -> denoise); rank 0 stitches
+the ranks' rows, renders the same frames in a single context and prints one JSON line with the comparison."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    from gpu_voxel_raytracer_amd import ACCUM_COLOR, ALL, DENOISED, SAMPLED_COLOR, Camera, Context, distributed, scenes
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    w, h, bounces, radius, band = 320, 200, 3, int(os.environ.get("VXRT_TEST_RADIUS", "3")), 16
+    pos, mrgb, size = scenes.load_scene("castle")
+    p0, d0, fov = scenes.close_camera(size)
+    layout = distributed.BandLayout(w, h, world, band, radius=radius)
+    # camera paths: at rest, a slow drift (reprojection stays within the halo rows), a fast pan (it does not)
+    paths = {"rest": [(p0, d0)] * 3,
+             "slow": [(p0 + np.float32(0.01 * k) * np.array([1, 0.5, 0], np.float32), d0) for k in range(4)],
+             "fast": [(p0, d0 + np.float32(0.12 * k) * np.array([0, -1, 0], np.float32)) for k in range(3)]}
+    out = {}
+    for name, path in paths.items():
+        ctx = Context(w, h, device=0, max_bounces=bounces, rank=rank, nranks=world, band_rows=band)
+        ctx.recreate_octree(pos, mrgb)
+        ctx.denoise_uniforms.radius = radius
+        halo = distributed.HaloExchange(ctx, dist, rank, world, torch.device("cuda", 0), torch, comm_device="cpu")
+        for cp, cd in path:
+            ctx.camera = Camera(cp, cd, fov)
+            distributed.render_frame(ctx, dist, rank, world, torch.device("cuda", 0), torch, radius, halo=halo)
+        imgs = {k: distributed.gather_image(ctx.read(i), layout, rank, dist, torch, "cpu")
+                for k, i in (("sampled", SAMPLED_COLOR), ("accum", ACCUM_COLOR), ("denoised", DENOISED))}
+        rays = torch.tensor([ctx.stats().rays])
+        dist.all_reduce(rays)
+        ctx.close()
+        if rank == 0:
+            single = Context(w, h, device=0, max_bounces=bounces)
+            single.recreate_octree(pos, mrgb)
+            single.denoise_uniforms.radius = radius
+            for cp, cd in path:
+                single.camera = Camera(cp, cd, fov)
+                single.render(ALL)
+            want = {"sampled": single.read(SAMPLED_COLOR), "accum": single.read(ACCUM_COLOR), "denoised": single.read(DENOISED)}
+            res = {"rays_equal": int(rays.item()) == single.stats().rays}
+            for k in want:
+                a, b = imgs[k], want[k]
+                same = (a == b) | (np.isnan(a) & np.isnan(b))
+                res[k + "_differing_pixels"] = int((~same.all(-1)).sum())
+            # a reprojection that leaves the rank's rows (+ halo) is a disocclusion: blending 1, i.e. accumulated = sampled colour,
+            # and the next frame's blending factor is clamp(0.5 * 1) = 0.5
+            diff = ~((imgs["accum"] == want["accum"]) | (np.isnan(imgs["accum"]) & np.isnan(want["accum"]))).all(-1)
+            res["accum_differs_only_where_treated_as_disocclusion"] = bool(
+                (imgs["accum"][diff][:, :3] == imgs["sampled"][diff][:, :3]).all() and (imgs["accum"][diff][:, 3] == 0.5).all())
+            res["geometry_pixels"] = int((single.read(1)[..., 3] >= 0).sum())
+            single.close()
+            out[name] = res
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -20,7 +20,7 @@ def test_every_declared_symbol_is_exported(H):
     lib = H.lib()
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.vxrt_abi_version() == 2
+    assert lib.vxrt_abi_version() == 3
     assert lib.vxrt_status_string(-13) == b"unexpected end of file"
 
 
@@ -42,9 +42,18 @@ def test_product_does_not_touch_the_oracle():
                     text = open(os.path.join(dirpath, f), errors="replace").read()
                     assert "liboracle" not in text and "from oracle" not in text and "import oracle" not in text, f
                     assert not re.search(r'#include\s+"[^"]*oracle/', text), f
-    # bench.py: only inside cpu_baseline()
+    # bench.py: only inside its cpu_baseline*() legs
+    import ast
     bench = open(os.path.join(ROOT, "bench.py")).read()
-    outside = bench[:bench.index("def cpu_baseline(")] + bench[bench.index("def main("):]
+    tree = ast.parse(bench)
+    legs = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name.startswith("cpu_baseline")]
+    assert {n.name for n in legs} == {"cpu_baseline", "cpu_baseline_cpu_rs"}
+    lines = bench.splitlines()
+    for n in legs:
+        for i in range(n.lineno - 1, n.end_lineno):
+            lines[i] = ""
+    outside = "\n".join(lines)
+    assert "oracle" not in outside.replace("oracle/", "").replace("CPU oracle", "") or "import oracle" not in outside
     assert "from oracle" not in outside and "import oracle" not in outside
     from gpu_voxel_raytracer_amd import _build
     ldd = subprocess.run(["ldd", _build.LIB], capture_output=True, text=True).stdout

@@ -50,3 +50,14 @@ def test_config1_primary_hits_agree_with_shader_walk(O, scenes, noise):
     single = np.abs(nd[..., :3]).sum(-1) == 1
     m = both & single
     assert (hn[m] == nd[..., :3][m]).all(-1).mean() > 0.999               # same entry face
+
+
+def test_config1_threaded_render_is_the_same_image(O, scenes):
+    """src/cpu.rs:43-46 renders with rayon's par_iter_mut over the pixels; the restatement deals rows to std::threads
+    (bench.py times it that way, next to the GPU number).  Pixels are independent: any thread count gives the golden image."""
+    pos, mrgb, cam_pos, basis = config1(O, scenes)
+    z = np.load(os.path.join(GOLDEN, "config1_3x3x3_256.npz"))
+    backend = O.CpuRsBackend(pos.astype(np.uint16), mrgb[:, 1:])
+    for threads in (1, 3, 8):
+        assert np.array_equal(backend.render(cam_pos * 2, basis, W, H_, time=0.0, nthreads=threads), z["pixels"])
+    backend.close()

@@ -147,3 +147,14 @@ def test_band_layout_matches_library(H):
     L = D.BandLayout(1920, 1080, 8)
     sizes = [len(L.rows(r)) for r in range(8)]
     assert sum(sizes) == 1080 and max(sizes) - min(sizes) <= 16            # interleaving balances the ranks
+
+
+def test_band_layout_row_rule_is_the_librarys():
+    """vxrt_create takes bands that are multiples of 8 rows (the tracer's tiles); only a denoise window (radius > 0) needs 16."""
+    from gpu_voxel_raytracer_amd import distributed as D
+    L = D.BandLayout(1920, 1080, 8, 8, radius=0)
+    assert sum(len(L.rows(r)) for r in range(8)) == 1080 and max(len(L.rows(r)) for r in range(8)) - min(len(L.rows(r)) for r in range(8)) <= 8
+    for bad in ((8, None), (8, 2), (24, 8), (12, 0), (0, 0)):
+        with pytest.raises(ValueError):
+            D.BandLayout(1920, 1080, 8, bad[0], radius=bad[1])
+    D.BandLayout(1920, 1080, 8, 32, radius=8)

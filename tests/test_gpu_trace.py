@@ -344,3 +344,57 @@ def test_tracer_field_of_the_config(O, H, scenes, noise):
         assert_bits_equal(im, imgs[0], "tracer variants")
     with pytest.raises(VxrtError):
         Context(64, 64, tracer=7)
+
+
+def test_tail_queue_full_and_growth(O, H, scenes, noise):
+    """The compacted tail's path queue is sized by need (an eighth of the worst case to start with), not for the worst case:
+    a path that finds its shard full stays in the head kernel — same image — and the queues grow before the stream's next launch.
+    (a) a capacity of 64 records per shard forces the queue-full path on most paths of every launch: bit-exact against the oracle;
+    (b) a view filled with geometry overflows the initial sizing, the queues grow, and later launches fit."""
+    from gpu_voxel_raytracer_amd import TRACE, Camera, Context
+    pos, mrgb, size = scenes.load_scene("castle")
+    cam = scenes.close_camera(size)
+    w, h, bounces = 256, 160, 6                 # 6 bounces: the tail compacts a second time (second queue)
+    octree = O.create_octree(pos, mrgb)
+    u = O.Uniforms.default()
+    u.set_camera(cam[0], O.camera_axis_scaled(cam[0], cam[1], cam[2], w, h))
+    for batch, inflight in ((1, 1), (4, 2)):
+        with Context(w, h, max_bounces=bounces, noise=noise, tracer=4, frames_per_launch=batch, frames_in_flight=inflight) as ctx:
+            ctx.recreate_octree(pos, mrgb)
+            ctx.camera = Camera(*cam)
+            ctx.set_option(H.OPT_TAIL_CAPACITY, 64)
+            ctx.render_frames(TRACE, 2 * batch)
+            st = ctx.stats()
+            assert st.queue_overflow_paths > 1000 and st.queue_bytes <= inflight * 2 * (64 * 64 + 1) * 64
+            u.frame_number = 2 * batch
+            ref = O.trace(octree, noise, u, w, h, bounces, crop=(0, 0, w, h))
+            for i, label in enumerate(("colour", "nd", "albedo")):
+                assert_bits_equal(ctx.read(i), ref[i], f"{label} with full queues")
+            assert st.rays == sum(O.trace(octree, noise, (setattr(u, "frame_number", f) or u), w, h, bounces, crop=(0, 0, w, h))[3]
+                                  for f in range(1, 2 * batch + 1))
+    # (b) automatic sizing: menger from close by at 1920x1080 — more than an eighth of the pixels are alive at their second hit
+    pos, mrgb, size = scenes.load_scene("menger")
+    cam = scenes.close_camera(size)
+    W, Hh, B = 1920, 1080, 4
+    with Context(W, Hh, max_bounces=B, noise=noise, frames_per_launch=16, frames_in_flight=2) as ctx:
+        ctx.recreate_octree(pos, mrgb)
+        ctx.camera = Camera(*cam)
+        first = ctx.stats().queue_bytes
+        assert first <= 1 << 30                    # <= 1 GB at 1080p, 16 frames per launch x 2 in flight (worst case: 8.5 GB)
+        ctx.render_frames(TRACE, 32)
+        a = ctx.stats()
+        ctx.reset_stats()
+        ctx.render_frames(TRACE, 64)
+        b = ctx.stats()
+        assert a.queue_overflow_paths > 0 and a.queue_bytes > first     # the first launches did not fit, the queues grew ...
+        assert b.queue_overflow_paths == 0 and b.queue_bytes == a.queue_bytes    # ... and now everything fits
+        ctx.set_frame_number(0)
+        ctx.render(TRACE)
+        u = O.Uniforms.default()
+        u.set_camera(cam[0], O.camera_axis_scaled(cam[0], cam[1], cam[2], W, Hh))
+        u.frame_number = 1
+        c, d, al, _ = O.trace(octree := O.create_octree(pos, mrgb), noise, u, W, Hh, B, crop=(0, 500, W, 516))
+        assert_bits_equal(ctx.read(0)[500:516], c, "colour after the queues grew")
+    # an 8K single context with 32 frames per launch x 3 in flight can be created (worst-case queues would need 204 GB)
+    with Context(7680, 4320, max_bounces=4, frames_per_launch=32, frames_in_flight=3) as ctx:
+        assert ctx.stats().queue_bytes < 40 << 30

@@ -145,11 +145,14 @@ def test_bench_schedule_choice():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     assert bench.pick_schedule(1, 1000) == (2, 16) and bench.pick_schedule(2, 1000) == (3, 16)
-    assert bench.pick_schedule(4, 1000) == (3, 32) and bench.pick_schedule(8, 1000) == (3, 32)   # never a 5th stream: 4 hardware queues
+    assert bench.pick_schedule(4, 1000) == (3, 32) and bench.pick_schedule(8, 1000) == (3, 32)   # never more than 3 trace streams
+    assert bench.pick_schedule(1, 20) == (2, 10)                    # the driver's --steps 20: two launches of 10 frames side by side
     for world in (1, 2, 4, 8):
         for steps in (1, 2, 5, 20, 63, 64, 100):
             inflight, batch = bench.pick_schedule(world, steps)
             assert 1 <= batch <= 32 and 1 <= inflight <= 16
-            assert batch == 1 or batch * inflight * 2 <= steps      # a short run still holds two rounds of launches
+            assert batch * inflight < steps + inflight or batch == 1    # a short block is dealt to the launches in equal parts
+    assert bench.block_count(0.0025, 0) == 400 and bench.block_count(0.12, 0) == 50 and bench.block_count(5.0, 0) == 50
+    assert bench.block_count(0.12, 7) == 7
     assert bench.pick_schedule(8, 1000, inflight=2, batch=4) == (2, 4)   # explicit values are kept
     assert bench.algorithmic_bytes(1920 * 1080, 4, 359016 + 640000) == 48 * 1920 * 1080 + 999016 + 32 * 65536

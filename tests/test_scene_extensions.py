@@ -266,3 +266,51 @@ def test_oracle_blue_noise_known_answer(O):
 
 
 BLUE_NOISE_LAYER0_SHA256 = "9a30192a9871f35e68cbcbbc57ad9a94a9369f07426a9fa652de7b9b8fb08c7e"
+
+
+def test_untrusted_scene_limits(H):
+    """Damaged or hostile scene graphs end in a status code, never in wrapped coordinates, undefined arithmetic or an
+    allocation the file's size does not justify."""
+    model = ((2, 2, 2), [(0, 0, 0, 1), (1, 1, 1, 1)])
+    # a cloud wider than 16-bit coordinates can hold once re-based: two instances 40 000 apart (each fits on its own)
+    wide = ntrn(0, 1) + ngrp(1, [2, 4]) + ntrn(2, 3, t=(-20000, 0, 0)) + nshp(3, [0]) + ntrn(4, 5, t=(20000, 0, 0)) + nshp(5, [0])
+    pos, _, (lo, hi) = H.vox_scene_to_voxels(scene_file([model], wide), H.VOX_ALL_MODELS)
+    assert hi[0] - lo[0] > 32767
+    with pytest.raises(H.VxrtError) as e:
+        H.vox_scene_to_voxels(scene_file([model], wide), H.VOX_ALL_MODELS | H.VOX_REBASE)
+    assert e.value.status == H.E_SCENE
+    # a translation no 16-bit scene can use (it would overflow the 64-bit composition a few levels down)
+    for t in ((2 ** 40, 0, 0), (0, -(2 ** 62), 0)):
+        with pytest.raises(H.VxrtError) as e:
+            H.vox_scene_to_voxels(scene_file([model], ntrn(0, 1, t=t) + nshp(1, [0])), H.VOX_ALL_MODELS)
+        assert e.value.status == H.E_SCENE
+    # one 64^3-cell model instanced 1 024 times = 2^28 voxels: refused before the vector grows that far
+    cells = [(x, y, z, 1) for x in range(64) for y in range(64) for z in range(64)]
+    big = ((64, 64, 64), cells)
+    graph = ntrn(0, 1) + ngrp(1, [2]) + ntrn(2, 3) + nshp(3, [0] * 1024)
+    with pytest.raises(H.VxrtError) as e:
+        H.vox_scene_to_voxels(scene_file([big], graph), H.VOX_ALL_MODELS)
+    assert e.value.status == H.E_SCENE
+
+
+@pytest.mark.parametrize("text,ok", [("1.5", True), ("-0.25e-3", True), ("+7", True), (".5", True), ("5.", True), ("1E10", True), ("inf", True),
+                                     ("-Infinity", True), ("NaN", True), ("", False), (" 1.0", False), ("1.0 ", False), ("0x1p3", False),
+                                     ("nan(0x1)", False), (".", False), ("1e", False), ("1e+", False), ("--1", False), ("1.5f", False), ("e5", False)])
+def test_flux_follows_rusts_f32_grammar(O, H, text, ok):
+    """MATL `_flux` is validated with value.parse::<f32>() in the reference (src/vox.rs:93-96): Rust's grammar, not C's strtof
+    (which also takes blanks, hex floats and nan(...)).  Library, whole-scene decoder and oracle agree on every case."""
+    body = struct.pack("<II", 5, 2) + vstr(b"_type") + vstr(b"_diffuse") + vstr(b"_flux") + vstr(text.encode())
+    data = make_vox(matls=(), extra=chunk(b"MATL", body))
+    for decode in (H.vox_to_voxels, lambda d: H.vox_scene_to_voxels(d, H.VOX_ALL_MODELS)):
+        if ok:
+            assert len(decode(data)[0]) == 1
+        else:
+            with pytest.raises(H.VxrtError) as e:
+                decode(data)
+            assert e.value.status == H.E_VOX_MATERIAL
+    if ok:
+        assert len(O.voxels_from_vox(data)[0]) == 1
+    else:
+        with pytest.raises(O.OracleError) as e:
+            O.voxels_from_vox(data)
+        assert e.value.code == -6
