@@ -312,7 +312,7 @@ def pipeline_bench(args):
     world, rank, device, dist, torch, backend = init_dist()
     args.gpus = world
     red_dev = "cuda" if backend == "nccl" else "cpu"
-    from gpu_voxel_raytracer_amd import DENOISE, TEMPORAL, TRACE, Camera, Context, distributed, scenes
+    from gpu_voxel_raytracer_amd import DENOISE, TEMPORAL, TIMED, TRACE, Camera, Context, distributed, scenes
     w, h, bounces, spp, radius, band = 3840, 2160, 8, 4, args.radius, 16
     pos, mrgb, size = scenes.load_scene("castle")
     cam = scenes.close_camera(size)
@@ -330,13 +330,13 @@ def pipeline_bench(args):
     xchg = [0.0]
 
     def frame():
-        ctx.render_spp(TRACE | TEMPORAL, spp)
+        ctx.render_spp(TRACE | TEMPORAL | TIMED, spp)
         if halo is not None and radius > 0:
             ctx.sync()
             t0 = time.perf_counter()
             halo.exchange()
             xchg[0] += time.perf_counter() - t0
-        ctx.render_stage(DENOISE)
+        ctx.render_stage(DENOISE | TIMED)
 
     def barrier():
         ctx.sync()

@@ -67,11 +67,9 @@ __global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const Trac
 
     uint32_t rays = 0;
     const unsigned tail_shard = (blockIdx.x * unsigned(kTB / 64) + unsigned(wave)) % kShards;
-    uint32_t tail_slot = kNoSlot;  // != kNoSlot: this lane's path continues in bounce_kernel (TraceArgs::tail), from that record
-    PathRec rec;
-    rec.node = 0; rec.normal_ambient = 0; rec.rng_index = 0; rec.pix = 0;
-    rec.hit_pos = rec.dir = rec.sample = rec.blend = splat3(0.0f);
+    if (a.tail.recs != nullptr) zero_counts(a.tail_zero, tid);
     if (active) {
+        bool handed_over = false;  // this lane's path continues in bounce_kernel (TraceArgs::tail)
         const SceneView sc = make_scene(a);
         uint2* stack = lds_stack + tid;
         const size_t pix = size_t(lrow) * a.band.width + x;
@@ -130,18 +128,25 @@ __global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const Trac
                 f3 alb = (hit.node & kEmitBit) == 0 ? node_color(hit.node) : splat3(1.0f);
                 store_out(fo.albedo + pix, make_float4(alb.x, alb.y, alb.z, __int_as_float(hit.node)));
             }
-            // hand the path over, in the state bounce_kernel resumes from — unless the queue is full (it is sized from what
-            // earlier launches queued): then this lane goes on as in the all-in-one kernel
-            if (a.tail.recs != nullptr && bounce == a.tail_from && (tail_slot = queue_reserve(a.tail, tail_shard)) != kNoSlot) {
-                rec.hit_pos = hit_pos;
-                rec.node = hit.node;
-                rec.dir = d;
-                rec.normal_ambient = pack_axis(n.x) | pack_axis(n.y) << 2 | pack_axis(n.z) << 4 | ambient_rays << 8;
-                rec.sample = sample;
-                rec.blend = blend;
-                rec.rng_index = rng.index;
-                rec.pix = uint32_t(pix) | fb << kPixBits;
-                break;
+            // Hand the path over, in the state bounce_kernel resumes from — unless the queue is full (it is sized from what earlier
+            // launches queued, not for the worst case): then this lane goes on as in the all-in-one kernel.  The record is stored
+            // right here, so that no register holds it while the wave's other lanes go on looping.
+            if (a.tail.recs != nullptr && bounce == a.tail_from) {
+                const uint32_t slot = queue_reserve(a.tail, tail_shard);
+                if (slot != kNoSlot) {
+                    PathRec rec;
+                    rec.hit_pos = hit_pos;
+                    rec.node = hit.node;
+                    rec.dir = d;
+                    rec.normal_ambient = pack_axis(n.x) | pack_axis(n.y) << 2 | pack_axis(n.z) << 4 | ambient_rays << 8;
+                    rec.sample = sample;
+                    rec.blend = blend;
+                    rec.rng_index = rng.index;
+                    rec.pix = uint32_t(pix) | fb << kPixBits;
+                    queue_store(a.tail, tail_shard, slot, rec);
+                    handed_over = true;
+                    break;
+                }
             }
 
             if (rng.next() < a.specularity) {  // specular                     voxels.comp:326-334
@@ -178,14 +183,10 @@ __global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const Trac
             if (++bounce >= a.max_bounces) break;
         }
 
-        if (tail_slot == kNoSlot) {
+        if (!handed_over) {
             f3 out = sample / float(ambient_rays);  // voxels.comp:391
             store_out(fo.color + pix, make_float4(out.x, out.y, out.z, 1.0f));
         }
-    }
-    if (a.tail.recs != nullptr) {
-        zero_counts(a.tail_zero, tid);
-        if (tail_slot != kNoSlot) queue_store(a.tail, tail_shard, tail_slot, rec);
     }
 
     count_rays(a.ray_counter, rays, lane);

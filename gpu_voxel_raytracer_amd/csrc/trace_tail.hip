@@ -45,7 +45,6 @@ __global__ __launch_bounds__(kTailBlock, VXRT_BOUNCE_WAVES) void bounce_kernel(c
         const unsigned entry = (c - first) * 64u + unsigned(lane);
         const bool valid = entry < count_q;
 
-        uint32_t out_slot = kNoSlot;   // != kNoSlot: the path goes on in the next launch, from that record of `out`
         PathRec rec;
         rec.node = 0; rec.normal_ambient = 0; rec.rng_index = 0; rec.pix = 0;
         rec.hit_pos = rec.dir = rec.sample = rec.blend = splat3(0.0f);
@@ -113,13 +112,16 @@ __global__ __launch_bounds__(kTailBlock, VXRT_BOUNCE_WAVES) void bounce_kernel(c
                     break;
                 }
                 // compact again: to the next queue — unless that is full, then this lane simply goes on
-                if (bounce == last_bounce && (out_slot = queue_reserve(out, c % kShards)) != kNoSlot) {
-                    rec.rng_index = rng.index;
-                    break;
+                if (bounce == last_bounce) {
+                    const uint32_t slot = queue_reserve(out, c % kShards);
+                    if (slot != kNoSlot) {
+                        rec.rng_index = rng.index;
+                        queue_store(out, c % kShards, slot, rec);
+                        break;
+                    }
                 }
             }
         }
-        if (out_slot != kNoSlot) queue_store(out, c % kShards, out_slot, rec);
     }
     count_rays(a.ray_counter, rays, lane);
 }

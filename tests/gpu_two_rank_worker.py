@@ -22,10 +22,11 @@ def main():
     pos, mrgb, size = scenes.load_scene("castle")
     p0, d0, fov = scenes.close_camera(size)
     layout = distributed.BandLayout(w, h, world, band, radius=radius)
-    # camera paths: at rest, a slow drift (reprojection stays within the halo rows), a fast pan (it does not)
+    # camera paths: at rest; a slow drift (every reprojection stays within the halo rows: the nearest geometry, 0.6 units from the
+    # camera, moves by 0.3 rows per frame); one fast pan (reprojections leave the rank's rows + halo: the frame after the jump)
     paths = {"rest": [(p0, d0)] * 3,
-             "slow": [(p0 + np.float32(0.01 * k) * np.array([1, 0.5, 0], np.float32), d0) for k in range(4)],
-             "fast": [(p0, d0 + np.float32(0.12 * k) * np.array([0, -1, 0], np.float32)) for k in range(3)]}
+             "slow": [(p0 + np.float32(0.001 * k) * np.array([1, 0.5, 0], np.float32), d0) for k in range(4)],
+             "fast": [(p0, d0), (p0, d0 + np.float32(0.12) * np.array([0, -1, 0], np.float32))]}
     out = {}
     for name, path in paths.items():
         ctx = Context(w, h, device=0, max_bounces=bounces, rank=rank, nranks=world, band_rows=band)
