@@ -18,6 +18,21 @@ struct SvoRecord {
     uint32_t base;
 };
 
+// The same tree, TWO LEVELS PER RECORD ("wide" records, 16 bytes): a node of an even-numbered pairing level (the record's "top")
+// together with its up to eight children (its "subs").  Levels are paired from the bottom, so the leaf parents are always subs —
+// the most numerous nodes of a tree never exist as records of their own — and when the number of node levels is odd the root is
+// the only sub of a virtual top above it.
+//   .mlo/.mhi  64 bits: byte s = the 8-bit occupancy mask of sub s (children, or leaves when the subs are the leaf parents);
+//              byte s == 0 <=> slot s of the top is empty
+//   .base      index of the record's first grandchild (a wide record two levels down), or of its first leaf word
+//   .top       bits 0-7: slot s of the top is occupied (= byte s != 0), kept so that no lane has to derive it
+// Grandchild (s, o) is  base + popcount(mask64 & ((1 << (8 s + o)) - 1)).  A descent top -> sub reads no memory at all and a
+// descent sub -> child one 16-byte record: half the dependent loads of the 8-byte format, and for a scene that lives in HBM
+// (BASELINE config 5) a third of the bytes — the leaf parents' records, 85 % of that tree's nodes, are gone.
+struct WideRec {
+    uint32_t mlo, mhi, base, top;
+};
+
 constexpr unsigned kRaySlots = 2048;  // ray counters, one per 64-byte line (TraceArgs::ray_counter)
 
 struct Cam {  // first 64 bytes of Uniforms, without padding
@@ -44,6 +59,9 @@ struct FrameOut {                  // the three voxels.comp outputs of one frame
 };
 
 struct TraceArgs {
+    const WideRec* wide;   // the scene as wide records (null: only the 8-byte format was built) — trace_kernel<true> / bounce_kernel<true>
+    WideRec wide_root;     // wide[0]
+    int node_levels;       // node levels of the tree (octree depth + 1): the root is level 0, the leaf parents level node_levels - 1
     const SvoRecord* svo;
     SvoRecord root_rec;    // svo[0]: every cast begins with it, so it travels with the kernel arguments instead of being loaded
     const int32_t* leaves;
@@ -72,6 +90,7 @@ struct TraceArgs {
     float sun_color[3];      // SUN_COLOR               voxels.comp:6
     float sky_color[3];
     float sun_exponent;      // 1.0 / pow(sun_size, 2)  voxels.comp:380
+    float sun_zero_below;    // pow(x, sun_exponent) is exactly +0 for 0 <= x < this (0: unknown; see sun_power_of)
     float sun_size, sun_strength, emit_strength, specularity;
     // monolithic kernel with a compacted tail (tracer 4): a path that is still alive when it reaches hit number
     // `tail_from` (0 = the first hit; tail.recs == nullptr: off) is appended to `tail` instead of being followed; bounce_kernel finishes those paths
@@ -129,10 +148,11 @@ struct RayQueue {
     unsigned seg_capacity;
 };
 
-hipError_t launch_trace(const TraceArgs& a, hipStream_t s);
+// `wide`: walk the wide records (TraceArgs::wide) instead of the 8-byte ones; same results
+hipError_t launch_trace(const TraceArgs& a, bool wide, hipStream_t s);
 // test hook: the walk (cast_ray) for caller-given rays; out = 8 floats per ray (hit, time, bits(leaf word), normal, 0, 0)
-hipError_t launch_path_log(const TraceArgs& a, int x, int y, float* log, hipStream_t s);
-hipError_t launch_cast_probe(const TraceArgs& a, const float* origins, const float* dirs, float* out, unsigned n, hipStream_t s);
+hipError_t launch_path_log(const TraceArgs& a, bool wide, int x, int y, float* log, hipStream_t s);
+hipError_t launch_cast_probe(const TraceArgs& a, bool wide, const float* origins, const float* dirs, float* out, unsigned n, hipStream_t s);
 unsigned trace_tile_count(int width, int local_rows);  // blocks per frame of trace_kernel = entries of a tile schedule
 void trace_tile_dims(int* w, int* h);                  // pixels per block  // monolithic: one pixel per lane, all bounces
 // ray queues: primary_kernel, then shade / trace-rays launches per path segment with per-lane ray refill
@@ -145,7 +165,7 @@ hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t* last_cos
 hipError_t launch_trace_wavefront(const TraceArgs& a, const PathQueue queues[2], unsigned* count_sets[3], unsigned* launch_counter,
                                   int blocks, unsigned split_mask, hipStream_t s);
 // bounce_kernel launches for path segments from.. of the paths queued in queues[0] (tracer 2 and the tail of tracer 4)
-hipError_t launch_bounces(const TraceArgs& a, const PathQueue queues[2], unsigned* count_sets[3], unsigned* launch_counter, int blocks,
+hipError_t launch_bounces(const TraceArgs& a, bool wide, const PathQueue queues[2], unsigned* count_sets[3], unsigned* launch_counter, int blocks,
                           unsigned split_mask, int from, hipStream_t s);
 // tracer 5: path_kernel (trace_paths.hip) follows the paths queued in `in` to their end, refilling each lane with a new path
 hipError_t launch_paths(const TraceArgs& a, const PathQueue& in, unsigned* zero, int first_bounce, int blocks, hipStream_t s);

@@ -43,8 +43,9 @@ namespace {
 constexpr int kTB = VXRT_TRACE_BLOCK;
 constexpr int kTileW = kTB == 64 ? 8 : 16, kTileH = kTB == 256 ? 16 : 8;
 
+template <bool kWide>
 __global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const TraceArgs a) {
-    extern __shared__ uint2 lds_stack[];  // [stack_levels][kTB]
+    extern __shared__ uint4 lds_stack[];  // the threads' frames: Caster<kWide>
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     // One kTileW x kTileH pixel tile per block, an 8x8 sub-tile per wave.  Blocks take tiles in the order of tile_order
@@ -70,8 +71,7 @@ __global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const Trac
     if (a.tail.recs != nullptr) zero_counts(a.tail_zero, tid);
     if (active) {
         bool handed_over = false;  // this lane's path continues in bounce_kernel (TraceArgs::tail)
-        const SceneView sc = make_scene(a);
-        uint2* stack = lds_stack + tid;
+        const Caster<kWide> caster(a, lds_stack, tid);
         const size_t pix = size_t(lrow) * a.band.width + x;
 
         Rng rng;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const Trac
         for (;;) {
             RayHit hit;
             rays++;
-            const bool is_hit = cast_ray(sc, o, d, kAlmostInfinity, stack, hit);
+            const bool is_hit = caster.cast(o, d, hit);
 
             if (sun_phase) {  // back from the sun shadow ray                 voxels.comp:357-371
                 if (!is_hit) sample = sample + pend_sun;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const Trac
             if (!is_hit) {  // sky                                              voxels.comp:373-388
                 if (bounce == 0) {
                     blend = splat3(1.0f);
-                    float sun_power = vx_pow(vx_max(0.0f, dot3(d, ld3(a.neg_sun_dir_n))), a.sun_exponent);
+                    float sun_power = sun_power_of(a, d);
                     sample = sample + (sky + sun_color * sun_power) * blend;
                     if (gbuf) {
                         store_out(fo.nd + pix, make_float4(kAlmostInfinity, kAlmostInfinity, kAlmostInfinity, -1.0f));
@@ -262,23 +262,25 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(uint32_t* cost, uint3
 namespace {
 // Test hook (vxrt_debug_cast_rays): cast_ray — the walk every tracer uses — for caller-given rays, one lane per ray.
 // out: 8 floats per ray = hit flag, time, bits(leaf word), normal xyz, 0, 0.
+template <bool kWide>
 __global__ __launch_bounds__(kTB) void cast_probe_kernel(const TraceArgs a, const float* origins, const float* dirs, float* out, unsigned n) {
-    extern __shared__ uint2 lds_stack[];
+    extern __shared__ uint4 lds_stack[];
     const unsigned i = blockIdx.x * kTB + threadIdx.x;
     if (i >= n) return;
-    const SceneView sc = make_scene(a);
+    const Caster<kWide> caster(a, lds_stack, int(threadIdx.x));
     RayHit hit;
     hit.time = 0.0f; hit.node = 0; hit.normal = splat3(0.0f);
-    const bool ok = cast_ray(sc, ld3(origins + 3 * i), ld3(dirs + 3 * i), kAlmostInfinity, lds_stack + threadIdx.x, hit);
+    const bool ok = caster.cast(ld3(origins + 3 * i), ld3(dirs + 3 * i), hit);
     float* o = out + 8 * size_t(i);
     o[0] = ok ? 1.0f : 0.0f; o[1] = hit.time; o[2] = __int_as_float(hit.node);
     o[3] = hit.normal.x; o[4] = hit.normal.y; o[5] = hit.normal.z; o[6] = 0.0f; o[7] = 0.0f;
 }
 // Test hook (vxrt_debug_path_log): one pixel's path with every cast logged — cast_ray and shade_hit, the code of all tracers, in one lane.
+template <bool kWide>
 __global__ __launch_bounds__(kTB) void path_log_kernel(const TraceArgs a, int x, int y, float* log) {
-    extern __shared__ uint2 lds_stack[];
+    extern __shared__ uint4 lds_stack[];
     if (threadIdx.x != 0) return;
-    const SceneView sc = make_scene(a);
+    const Caster<kWide> caster(a, lds_stack, 0);
     Rng rng;
     rng.noise = a.noise;
     rng.index = uint32_t(x) % 128u + (uint32_t(y) % 128u) * 128u + (a.frame_number % 512u) * kNoiseLayer;
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(kTB) void path_log_kernel(const TraceArgs a, int x,
     int casts = 0;
     auto cast = [&](f3 ro, f3 rd, RayHit& hit) {
         hit.time = 0.0f; hit.node = 0; hit.normal = splat3(0.0f);
-        const bool ok = cast_ray(sc, ro, rd, kAlmostInfinity, lds_stack, hit);
+        const bool ok = caster.cast(ro, rd, hit);
         if (casts < 32) {
             float* r = log + 12 * casts++;
             r[0] = ro.x; r[1] = ro.y; r[2] = ro.z; r[3] = rd.x; r[4] = rd.y; r[5] = rd.z; r[6] = ok ? 1.0f : 0.0f; r[7] = hit.time;
@@ -314,15 +316,21 @@ __global__ __launch_bounds__(kTB) void path_log_kernel(const TraceArgs a, int x,
 }
 }  // namespace
 
-hipError_t launch_cast_probe(const TraceArgs& a, const float* origins, const float* dirs, float* out, unsigned n, hipStream_t s) {
-    size_t lds = size_t(a.stack_levels) * kTB * sizeof(uint2);
-    hipLaunchKernelGGL(cast_probe_kernel, dim3((n + kTB - 1) / kTB), dim3(kTB), lds, s, a, origins, dirs, out, n);
+hipError_t launch_cast_probe(const TraceArgs& a, bool wide, const float* origins, const float* dirs, float* out, unsigned n, hipStream_t s) {
+    const size_t lds = caster_lds_bytes(a, wide, kTB);
+    if (wide)
+        hipLaunchKernelGGL(cast_probe_kernel<true>, dim3((n + kTB - 1) / kTB), dim3(kTB), lds, s, a, origins, dirs, out, n);
+    else
+        hipLaunchKernelGGL(cast_probe_kernel<false>, dim3((n + kTB - 1) / kTB), dim3(kTB), lds, s, a, origins, dirs, out, n);
     return hipGetLastError();
 }
 
-hipError_t launch_path_log(const TraceArgs& a, int x, int y, float* log, hipStream_t s) {
-    size_t lds = size_t(a.stack_levels) * kTB * sizeof(uint2);
-    hipLaunchKernelGGL(path_log_kernel, dim3(1), dim3(kTB), lds, s, a, x, y, log);
+hipError_t launch_path_log(const TraceArgs& a, bool wide, int x, int y, float* log, hipStream_t s) {
+    const size_t lds = caster_lds_bytes(a, wide, kTB);
+    if (wide)
+        hipLaunchKernelGGL(path_log_kernel<true>, dim3(1), dim3(kTB), lds, s, a, x, y, log);
+    else
+        hipLaunchKernelGGL(path_log_kernel<false>, dim3(1), dim3(kTB), lds, s, a, x, y, log);
     return hipGetLastError();
 }
 
@@ -333,10 +341,13 @@ unsigned trace_tile_count(int width, int local_rows) {
 
 void trace_tile_dims(int* w, int* h) { *w = kTileW; *h = kTileH; }
 
-hipError_t launch_trace(const TraceArgs& a, hipStream_t s) {
+hipError_t launch_trace(const TraceArgs& a, bool wide, hipStream_t s) {
     dim3 grid(trace_tile_count(a.band.width, a.band.local_rows) * unsigned(a.batch));
-    size_t lds = size_t(a.stack_levels) * kTB * sizeof(uint2);
-    hipLaunchKernelGGL(trace_kernel, grid, dim3(kTB), lds, s, a);
+    const size_t lds = caster_lds_bytes(a, wide, kTB);
+    if (wide)
+        hipLaunchKernelGGL(trace_kernel<true>, grid, dim3(kTB), lds, s, a);
+    else
+        hipLaunchKernelGGL(trace_kernel<false>, grid, dim3(kTB), lds, s, a);
     return hipGetLastError();
 }
 

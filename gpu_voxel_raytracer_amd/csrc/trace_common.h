@@ -507,6 +507,9 @@ __device__ __forceinline__ bool cast_ray(const SceneView& sc, f3 o, f3 d, float 
     return finish_ray(sc, status, o, d, time, center, lvl, octant, leaf, hit);
 }
 
+__device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+#include "walk_wide.h"
+
 __device__ __forceinline__ f3 node_rgb(int32_t node) {
     return mk3(float((node >> 16) & 0xff), float((node >> 8) & 0xff), float(node & 0xff));
 }
@@ -549,7 +552,6 @@ __device__ __forceinline__ f3 random_hemisphere(f3 n, Rng& rng) {
     return r - n * vx_min0(2.0f * dot3(n, r));  // min(0.0, .): see vx_min0
 }
 
-__device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 __device__ __forceinline__ f3 xyz4(float4 v) { return mk3(v.x, v.y, v.z); }
 
 // Rays cast by this wave -> one atomic on one of kRaySlots counters, each on a 64-byte line of its own.
@@ -674,6 +676,18 @@ __device__ __forceinline__ Shaded shade_hit(const TraceArgs& a, int bounce, f3 h
     return r;
 }
 
+// pow(max(0, dot(dir, -sun)), 1 / sun_size^2) of voxels.comp:378-381 — exponent 400 by default, so the sun's disc is a few degrees
+// wide and the power is EXACTLY zero for every direction further from the sun: vx_pow = vx_exp(y * vx_log(x)), and vx_exp
+// returns +0 for every argument below -87.3.  TraceArgs::sun_zero_below is a bound (made on the host with a safety margin three
+// orders of magnitude above vx_log's error) below which that is certain, so most sky pixels skip the ~90 instructions of log and
+// exp; the result is the same bit pattern either way (tests/test_gpu_detmath.py::test_sun_power_shortcut).
+__device__ __forceinline__ float sun_power_of(const TraceArgs& a, f3 d) {
+    const float x = vx_max(0.0f, dot3(d, ld3(a.neg_sun_dir_n)));
+    float p = 0.0f;
+    if (!(x < a.sun_zero_below)) p = vx_pow(x, a.sun_exponent);
+    return p;
+}
+
 // The G-buffer is written once and never read back by the tracer: stream it (global_store ... nt) so that the SVO records
 // and noise layers keep their cache lines.  With plain stores rocprofv3's WRITE_SIZE read 1.45 x the bytes stored (dirty
 // lines written back more than once); with nt stores 1.06 x, and the frame is 2 % faster.
@@ -695,6 +709,28 @@ __device__ __forceinline__ SceneView make_scene(const TraceArgs& a) {
     sc.cell = __builtin_ldexpf(a.root_size, -a.stack_levels);
     sc.inv_cell = 1.0f / sc.cell;
     return sc;
+}
+
+// cast_ray over either scene format, with the thread's column of the block's LDS frames (`lds`: the kernel's dynamic shared memory;
+// 8 bytes per tree level and thread for the 8-byte records, 16 bytes per PAIR of levels for the wide ones).
+template <bool kWide> struct Caster;
+template <> struct Caster<false> {
+    SceneView sc;
+    uint2* stack;
+    __device__ __forceinline__ Caster(const TraceArgs& a, uint4* lds, int tid) : sc(make_scene(a)), stack(reinterpret_cast<uint2*>(lds) + tid) {}
+    __device__ __forceinline__ bool cast(f3 o, f3 d, RayHit& hit) const { return cast_ray(sc, o, d, kAlmostInfinity, stack, hit); }
+};
+template <> struct Caster<true> {
+    SceneW sc;
+    uint4* stack;
+    __device__ __forceinline__ Caster(const TraceArgs& a, uint4* lds, int tid) : sc(make_scene_w(a)), stack(lds + tid) {}
+    __device__ __forceinline__ bool cast(f3 o, f3 d, RayHit& hit) const { return cast_ray_w(sc, o, d, kAlmostInfinity, stack, hit); }
+};
+// dynamic shared memory a block of `threads` threads needs for its frames
+inline size_t caster_lds_bytes(const TraceArgs& a, bool wide, int threads) {
+    if (!wide) return size_t(a.stack_levels) * size_t(threads) * sizeof(uint2);
+    const int slots = (a.node_levels + (a.node_levels & 1)) / 2;
+    return size_t(slots < 1 ? 1 : slots) * size_t(threads) * sizeof(uint4);
 }
 
 __device__ __forceinline__ void zero_counts(unsigned* counts, int tid) {

@@ -15,15 +15,15 @@ constexpr int kTailBlock = VXRT_TAIL_BLOCK;
 #ifndef VXRT_BOUNCE_WAVES
 #define VXRT_BOUNCE_WAVES 5
 #endif
+template <bool kWide>
 __global__ __launch_bounds__(kTailBlock, VXRT_BOUNCE_WAVES) void bounce_kernel(const TraceArgs a, const PathQueue in, const PathQueue out, unsigned* zero,
                                                         int first_bounce, int last_bounce) {
-    extern __shared__ uint2 lds_stack[];
+    extern __shared__ uint4 lds_stack[];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     zero_counts(zero, tid);
-    const SceneView sc = make_scene(a);
+    const Caster<kWide> caster(a, lds_stack, tid);
     const f3 sun_dir = ld3(a.sun_dir), sun_color = ld3(a.sun_color), sky = ld3(a.sky_color);
-    uint2* stack = lds_stack + tid;
 
     // chunk table: lane q owns shard q
     const unsigned my_count = queue_count(in, unsigned(lane));
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kTailBlock, VXRT_BOUNCE_WAVES) void bounce_kernel(c
                     ambient_rays++;
                     RayHit sun_hit;
                     rays++;
-                    if (!cast_ray(sc, o, to_light, kAlmostInfinity, stack, sun_hit))
+                    if (!caster.cast(o, to_light, sun_hit))
                         sample = sample + ((sun_color * color) * blend) * vx_max(0.0f, dot3(n, to_light));
                     d = random_hemisphere(n, rng);
                     sample = sample + emit * blend;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kTailBlock, VXRT_BOUNCE_WAVES) void bounce_kernel(c
                 if (bounce + 1 < a.max_bounces) {  // next path segment                        voxels.comp:309-313
                     RayHit hit;
                     rays++;
-                    if (cast_ray(sc, o, d, kAlmostInfinity, stack, hit)) {
+                    if (caster.cast(o, d, hit)) {
                         const f3 hn = hit.normal;
                         rec.hit_pos = o + d * hit.time;
                         rec.node = hit.node;
@@ -132,9 +132,9 @@ __global__ __launch_bounds__(kTailBlock, VXRT_BOUNCE_WAVES) void bounce_kernel(c
 // bounce_kernel launches for the path segments from..max_bounces-1 of the paths in queues[0] (written by launch J-1 with
 // count set J%3).  Bit k of split_mask set: a new launch (with compaction of the live paths) starts at path segment k.
 // Launch J reads count set J%3, writes (J+1)%3 and clears (J+2)%3 (the set launch J-1 consumed).
-hipError_t launch_bounces(const TraceArgs& a, const PathQueue queues[2], unsigned* count_sets[3], unsigned* launch_counter, int blocks,
+hipError_t launch_bounces(const TraceArgs& a, bool wide, const PathQueue queues[2], unsigned* count_sets[3], unsigned* launch_counter, int blocks,
                           unsigned split_mask, int from, hipStream_t s) {
-    size_t lds = size_t(a.stack_levels) * kTailBlock * sizeof(uint2);
+    const size_t lds = caster_lds_bytes(a, wide, kTailBlock);
     blocks *= kBlock / kTailBlock;  // `blocks` counts 4-wave blocks
     unsigned J = *launch_counter;
     int stage = 0;
@@ -145,7 +145,10 @@ hipError_t launch_bounces(const TraceArgs& a, const PathQueue queues[2], unsigne
         in.counts = count_sets[J % 3];
         PathQueue out = queues[(stage & 1) ^ 1];
         out.counts = count_sets[(J + 1) % 3];
-        hipLaunchKernelGGL(bounce_kernel, dim3(blocks), dim3(kTailBlock), lds, s, a, in, out, count_sets[(J + 2) % 3], first, last);
+        if (wide)
+            hipLaunchKernelGGL(bounce_kernel<true>, dim3(blocks), dim3(kTailBlock), lds, s, a, in, out, count_sets[(J + 2) % 3], first, last);
+        else
+            hipLaunchKernelGGL(bounce_kernel<false>, dim3(blocks), dim3(kTailBlock), lds, s, a, in, out, count_sets[(J + 2) % 3], first, last);
         J++;
         stage++;
         first = last + 1;

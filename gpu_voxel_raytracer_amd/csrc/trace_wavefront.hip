@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const TraceArgs a, cons
             rec.pix = pix;
             keep = true;
         } else {  // sky on the primary ray                                               voxels.comp:373-382,391
-            float sun_power = vx_pow(vx_max(0.0f, dot3(d, ld3(a.neg_sun_dir_n))), a.sun_exponent);
+            float sun_power = sun_power_of(a, d);
             f3 out = (splat3(0.0f) + (ld3(a.sky_color) + ld3(a.sun_color) * sun_power) * splat3(1.0f)) / 1.0f;
             a.out_color[pix] = make_float4(out.x, out.y, out.z, 1.0f);
             a.out_nd[pix] = make_float4(kAlmostInfinity, kAlmostInfinity, kAlmostInfinity, -1.0f);
@@ -343,7 +343,7 @@ hipError_t launch_trace_wavefront(const TraceArgs& a, const PathQueue queues[2],
     out.counts = count_sets[(J + 1) % 3];
     hipLaunchKernelGGL(primary_kernel, grid, dim3(kBlock), lds, s, a, out, count_sets[(J + 2) % 3]);
     *launch_counter = J + 1;
-    return launch_bounces(a, queues, count_sets, launch_counter, blocks, split_mask, 0, s);
+    return launch_bounces(a, false, queues, count_sets, launch_counter, blocks, split_mask, 0, s);
 }
 
 

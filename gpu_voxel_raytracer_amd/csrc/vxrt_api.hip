@@ -3,6 +3,7 @@
 // call site it replaces in vxrt.h.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -71,6 +72,10 @@ struct vxrt_ctx {
     bool has_scene = false;
     SvoRecord* d_svo = nullptr;
     SvoRecord root_rec{0, 0};  // d_svo[0], passed to the kernels by value (every cast starts with it)
+    WideRec* d_wide = nullptr; // the same tree as wide records (kernels.h): two levels per 16-byte record
+    WideRec wide_root{0, 0, 0, 0};
+    size_t wide_count = 0;
+    int scene_format = -1;     // VXRT_OPT_SCENE_FORMAT: -1 auto (wide records once the scene outgrows the Infinity Cache), 0 8-byte, 1 wide
     int32_t* d_leaves = nullptr;
     size_t svo_count = 0, leaf_count = 0;
     float root_center[3] = {0, 0, 0};
@@ -407,14 +412,69 @@ int flatten_svo(const Octree& tree, std::vector<SvoRecord>* recs, std::vector<in
     return VXRT_OK;
 }
 
+// 8-byte records (breadth first, children contiguous) -> wide records (kernels.h: WideRec).  Levels are paired from the bottom; the
+// wide records are the nodes of the pairs' upper levels in the same breadth-first order, so a record's grandchildren are contiguous in
+// (sub, slot) order, and the leaf words keep their order (the leaf parents under one node are neighbours in breadth-first order).
+int widen_svo(const std::vector<SvoRecord>& recs, uint32_t depth, std::vector<WideRec>* out) {
+    const uint32_t L = depth + 1;      // node levels: root 0 .. leaf parents L-1
+    const uint32_t parity = L & 1u;    // odd: the root is the one sub of a virtual top
+    out->clear();
+    if (recs.empty()) { out->push_back(WideRec{0, 0, 0, 0}); return VXRT_OK; }
+    std::vector<size_t> start(L + 1, recs.size());   // level l = recs[start[l] .. start[l+1])
+    start[0] = 0;
+    for (uint32_t l = 0; l + 1 < L; l++) {
+        if (start[l] >= recs.size() || (recs[start[l]].masks & 0xffu) == 0u) break;   // no nodes below (an empty scene)
+        start[l + 1] = recs[start[l]].base;
+    }
+    std::vector<size_t> woff(L + 2, 0);   // index of the first wide record whose top is level l
+    size_t total = parity;
+    for (uint32_t l = parity; l + 1 < L; l += 2) { woff[l] = total; total += start[l + 1] - start[l]; }
+    if (total >= (size_t(1) << 32)) { set_error("too many nodes"); return VXRT_E_SCENE; }
+    out->resize(total == 0 ? 1 : total);
+    if (parity) {
+        const SvoRecord& root = recs[0];
+        const uint32_t byte = L == 1 ? (root.masks >> 8) & 0xffu : root.masks & 0xffu;
+        (*out)[0] = WideRec{byte, 0u, L == 1 ? root.base : uint32_t(woff[1]), byte != 0u ? 1u : 0u};
+    }
+    for (uint32_t l = parity; l + 1 < L; l += 2) {
+        const bool subs_are_leaf_parents = l + 2 == L;
+        for (size_t i = start[l]; i < start[l + 1]; i++) {
+            const SvoRecord& top = recs[i];
+            const uint32_t cm = top.masks & 0xffu;
+            uint64_t mask = 0;
+            uint32_t k = 0;
+            for (uint32_t s = 0; s < 8; s++)
+                if (cm >> s & 1u) {
+                    const SvoRecord& sub = recs[size_t(top.base) + k++];
+                    mask |= uint64_t(subs_are_leaf_parents ? (sub.masks >> 8) & 0xffu : sub.masks & 0xffu) << (8u * s);
+                }
+            uint32_t base = 0;
+            if (cm != 0u) {
+                const SvoRecord& first = recs[top.base];
+                base = subs_are_leaf_parents ? first.base : uint32_t(woff[l + 2] + (size_t(first.base) - start[l + 2]));
+            }
+            (*out)[woff[l] + (i - start[l])] = WideRec{uint32_t(mask), uint32_t(mask >> 32), base, cm};
+        }
+    }
+    return VXRT_OK;
+}
+
 int upload_svo(vxrt_ctx* c, std::vector<SvoRecord>& recs, std::vector<int32_t>& leaves, uint32_t depth) {
     if (leaves.empty()) leaves.push_back(0);
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = sync_all(c)) return rc;
+    std::vector<WideRec> wide;
+    if (int rc = widen_svo(recs, depth, &wide)) return rc;
     if (c->d_svo) (void)hipFree(c->d_svo);
     if (c->d_leaves) (void)hipFree(c->d_leaves);
+    if (c->d_wide) (void)hipFree(c->d_wide);
     c->d_svo = nullptr;
     c->d_leaves = nullptr;
+    c->d_wide = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_wide), wide.size() * sizeof(WideRec)));
+    HIP_TRY(hipMemcpy(c->d_wide, wide.data(), wide.size() * sizeof(WideRec), hipMemcpyHostToDevice));
+    c->wide_count = wide.size();
+    c->wide_root = wide[0];
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_svo), recs.size() * sizeof(SvoRecord)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_leaves), leaves.size() * sizeof(int32_t)));
     HIP_TRY(hipMemcpy(c->d_svo, recs.data(), recs.size() * sizeof(SvoRecord), hipMemcpyHostToDevice));
@@ -436,6 +496,15 @@ int upload_scene(vxrt_ctx* c, const Voxel* voxels, size_t n) {
     std::vector<int32_t> leaves;
     if (int rc = flatten_svo(tree, &recs, &leaves)) return rc;
     return upload_svo(c, recs, leaves, tree.depth);
+}
+
+// Which records trace_kernel / bounce_kernel walk.  Automatic: the 8-byte records while the scene sits in the caches (its descents
+// are served by L1 / L2 and the wide walk's longer instruction sequence costs more than the loads it saves), the wide records once
+// the scene lives in HBM (half the dependent loads, a third of the record bytes).  VXRT_OPT_SCENE_FORMAT / VXRT_WIDE override.
+bool use_wide(const vxrt_ctx* c) {
+    if (c->d_wide == nullptr) return false;
+    if (c->scene_format >= 0) return c->scene_format == 1;
+    return c->svo_count * sizeof(SvoRecord) + c->leaf_count * sizeof(int32_t) > (size_t(256) << 20);
 }
 
 // new capacity (records per shard) for the path queues of every stream; waits for the GPU first
@@ -568,7 +637,8 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) try {
     if (const char* v = getenv("VXRT_TAIL_FROM")) c->tail_from = atoi(v);
     if (c->tail_from < 0 || c->tail_from >= int(cfg->max_bounces)) c->tail_from = 1;
     if (const char* v = getenv("VXRT_TAIL_SPLIT")) c->tail_split = unsigned(strtoul(v, nullptr, 0));
-    if (const char* v = getenv("VXRT_TAIL_CAPACITY")) c->tail_capacity_override = atoi(v);   // test hook: force the queue-full path
+    if (const char* v = getenv("VXRT_TAIL_CAPACITY")) c->tail_capacity_override = atoi(v);
+    if (const char* v = getenv("VXRT_WIDE")) c->scene_format = atoi(v);   // A/B: 0 the 8-byte records, 1 the wide records, -1 automatic   // test hook: force the queue-full path
     if (const char* v = getenv("VXRT_SHADE_BLOCKS")) c->shade_blocks = atoi(v);
     if (const char* v = getenv("VXRT_RAYS_PER_WAVE")) c->rays_per_wave = unsigned(atoi(v));
     c->shade_blocks = (c->shade_blocks < 8 ? 8 : (c->shade_blocks > 2048 ? 2048 : c->shade_blocks) + 7) / 8 * 8;
@@ -610,6 +680,7 @@ int vxrt_destroy(vxrt_ctx* c) try {
         for (EventPair& p : *v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     free_images(c);
     if (c->d_svo) (void)hipFree(c->d_svo);
+    if (c->d_wide) (void)hipFree(c->d_wide);
     if (c->d_leaves) (void)hipFree(c->d_leaves);
     if (c->d_noise) (void)hipFree(c->d_noise);
     if (c->d_rays) (void)hipFree(c->d_rays);
@@ -696,6 +767,10 @@ int vxrt_set_option(vxrt_ctx* c, vxrt_option option, uint32_t value) try {
             if (value > 1) { set_error("denoise mode must be 0 (exact) or 1 (tolerant)"); return VXRT_E_INVALID; }
             c->denoise_mode = int(value);
             return VXRT_OK;
+        case VXRT_OPT_SCENE_FORMAT:
+            if (value > 2) { set_error("scene format must be 0 (8-byte records), 1 (wide records) or 2 (automatic)"); return VXRT_E_INVALID; }
+            c->scene_format = value == 2 ? -1 : int(value);
+            return VXRT_OK;
         case VXRT_OPT_TAIL_CAPACITY:
             if (c->trace_variant < 4) return VXRT_OK;   // the other tracers' queues are sized for the worst case
             c->tail_capacity_override = int(value > 0x7fffffffu ? 0x7fffffffu : value);
@@ -759,6 +834,9 @@ void frame_constants(const vxrt_ctx* c, TraceArgs& a) {
     const vxrt_uniforms& u = c->uniforms;
     a.svo = c->d_svo; a.leaves = c->d_leaves; a.noise = c->d_noise;
     a.root_rec = c->root_rec;
+    a.wide = c->d_wide;
+    a.wide_root = c->wide_root;
+    a.node_levels = int(c->depth) + 1;
     memcpy(a.root_center, c->root_center, sizeof a.root_center);
     a.root_size = c->root_size;
     a.band = c->band;
@@ -775,6 +853,10 @@ void frame_constants(const vxrt_ctx* c, TraceArgs& a) {
     a.sun_color[0] = sun_color.x; a.sun_color[1] = sun_color.y; a.sun_color[2] = sun_color.z;
     a.sky_color[0] = u.sky_color[0]; a.sky_color[1] = u.sky_color[1]; a.sky_color[2] = u.sky_color[2];
     a.sun_exponent = 1.0f / (u.sun_size * u.sun_size);
+    // vx_pow(x, y) = vx_exp(y * vx_log(x)) is +0 once y * log(x) < -87.3: certain for x < exp(-88 / y) * (1 - 1e-4), which leaves
+    // 0.7 + 1e-4 y of margin in the exponent against vx_log's error of ~1e-6 |log x| and the product's rounding.
+    a.sun_zero_below = 0.0f;
+    if (a.sun_exponent > 1.0f && a.sun_exponent < 1e6f) a.sun_zero_below = float(exp(-88.0 / double(a.sun_exponent)) * (1.0 - 1e-4));
     a.sun_size = u.sun_size; a.sun_strength = u.sun_strength; a.emit_strength = u.emit_strength; a.specularity = u.specularity;
 }
 
@@ -842,7 +924,7 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
                 a.tail = PathQueue{sq.hitq[0], sets[(J + 1) % 3], c->shard_capacity};
                 a.tail_zero = sets[(J + 2) % 3];
                 a.tail_from = c->tail_from;
-                HIP_TRY(launch_trace(a, ts));
+                HIP_TRY(launch_trace(a, use_wide(c) && c->trace_variant == 4, ts));
                 sq.launches = J + 1;
                 if (!sq.counts_pending) {   // how much room this launch wanted (the set stays untouched until launch J + 2 clears it)
                     HIP_TRY(hipMemcpyAsync(sq.host_counts, sets[(J + 1) % 3], 64 * 64, hipMemcpyDeviceToHost, ts));
@@ -855,10 +937,10 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
                 } else {
                     // without a second queue (tail_split == 0) nothing is appended to queues[1]: its capacity 0 says so
                     PathQueue queues[2] = {{sq.hitq[0], nullptr, c->shard_capacity}, {sq.hitq[1], nullptr, sq.hitq[1] ? c->shard_capacity : 0u}};
-                    HIP_TRY(launch_bounces(a, queues, sets, &sq.launches, c->trace_blocks, sq.hitq[1] ? c->tail_split : 0u, c->tail_from, ts));
+                    HIP_TRY(launch_bounces(a, use_wide(c), queues, sets, &sq.launches, c->trace_blocks, sq.hitq[1] ? c->tail_split : 0u, c->tail_from, ts));
                 }
             } else {
-                HIP_TRY(launch_trace(a, ts));
+                HIP_TRY(launch_trace(a, use_wide(c), ts));
             }
             if (timed) HIP_TRY(hipEventRecord(p.b, ts));
             // Re-sort the tiles for this stream's coming frames from the costs just measured: after its first
@@ -1166,6 +1248,8 @@ int vxrt_get_stats(vxrt_ctx* c, vxrt_stats* out) try {
     out->octree_nodes = c->svo_count;
     for (size_t lane = 0; lane < c->queues.size(); lane++)   // fold in what the last launches wanted (the GPU is idle here)
         if (c->trace_variant >= 4) { if (int rc = grow_tail_queues(c, lane, nullptr)) return rc; }
+    out->wide_nodes = c->wide_count;
+    out->scene_format = use_wide(c) ? 1u : 0u;
     out->queue_bytes = c->queue_bytes;
     out->queue_overflow_paths = c->queue_overflow_paths;
     return VXRT_OK;
@@ -1317,6 +1401,31 @@ int vxrt_build_octree(const int16_t (*pos)[3], const uint8_t (*mrgb)[4], size_t 
     *n_words = tree.words.size();
     if (depth) *depth = tree.depth;
     if (words && cap >= tree.words.size()) memcpy(words, tree.words.data(), tree.words.size() * sizeof(int32_t));
+    return VXRT_OK;
+} VXRT_CATCH
+
+// The scene as the kernels read it, for a voxel list (host only): 8-byte records, wide records, leaf words.  Arrays may be null
+// (sizes only); nothing is written past the caps.
+int vxrt_build_records(const int16_t (*pos)[3], const uint8_t (*mrgb)[4], size_t n, uint32_t* svo, size_t svo_cap, size_t* n_svo,
+                       uint32_t* wide, size_t wide_cap, size_t* n_wide, int32_t* leaves, size_t leaf_cap, size_t* n_leaves, uint32_t* depth) try {
+    if (!n_svo || !n_wide || !n_leaves || (n != 0 && (!pos || !mrgb))) { set_error("null argument"); return VXRT_E_INVALID; }
+    std::vector<Voxel> v(n);
+    for (size_t i = 0; i < n; i++) {
+        v[i].x = pos[i][0]; v[i].y = pos[i][1]; v[i].z = pos[i][2];
+        v[i].m = mrgb[i][0]; v[i].r = mrgb[i][1]; v[i].g = mrgb[i][2]; v[i].b = mrgb[i][3];
+    }
+    Octree tree;
+    if (int rc = build_octree(v.data(), n, &tree)) return rc;
+    std::vector<SvoRecord> recs;
+    std::vector<int32_t> lw;
+    std::vector<WideRec> wr;
+    if (int rc = flatten_svo(tree, &recs, &lw)) return rc;
+    if (int rc = widen_svo(recs, tree.depth, &wr)) return rc;
+    *n_svo = recs.size(); *n_wide = wr.size(); *n_leaves = lw.size();
+    if (depth) *depth = tree.depth;
+    if (svo && svo_cap >= recs.size()) memcpy(svo, recs.data(), recs.size() * sizeof(SvoRecord));
+    if (wide && wide_cap >= wr.size()) memcpy(wide, wr.data(), wr.size() * sizeof(WideRec));
+    if (leaves && leaf_cap >= lw.size()) memcpy(leaves, lw.data(), lw.size() * sizeof(int32_t));
     return VXRT_OK;
 } VXRT_CATCH
 
@@ -1473,10 +1582,13 @@ int vxrt_debug_cast_rays(vxrt_ctx* c, const float* origins, const float* dirs, s
     TraceArgs a{};
     a.svo = c->d_svo; a.leaves = c->d_leaves;
     a.root_rec = c->root_rec;
+    a.wide = c->d_wide;
+    a.wide_root = c->wide_root;
+    a.node_levels = int(c->depth) + 1;
     memcpy(a.root_center, c->root_center, sizeof a.root_center);
     a.root_size = c->root_size;
     a.stack_levels = c->depth < 1 ? 1 : int(c->depth);
-    HIP_TRY(launch_cast_probe(a, d_o, d_d, d_out, unsigned(n), c->stream));
+    HIP_TRY(launch_cast_probe(a, use_wide(c), d_o, d_d, d_out, unsigned(n), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::vector<float> out(n * 8);
     HIP_TRY(hipMemcpy(out.data(), d_out, n * 32, hipMemcpyDeviceToHost));
@@ -1510,7 +1622,7 @@ int vxrt_debug_path_log(vxrt_ctx* c, int32_t x, int32_t y, float* log, int32_t* 
     ScratchBuffer b_log;
     HIP_TRY(b_log.alloc((12 * 32 + 1) * sizeof(float)));
     float* d_log = b_log.as<float>();
-    HIP_TRY(launch_path_log(a, x, y, d_log, c->stream));
+    HIP_TRY(launch_path_log(a, use_wide(c), x, y, d_log, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::vector<float> out(12 * 32 + 1);
     HIP_TRY(hipMemcpy(out.data(), d_log, out.size() * sizeof(float), hipMemcpyDeviceToHost));

@@ -100,11 +100,12 @@ class Stats(C.Structure):
     _fields_ = [("frames", C.c_uint64), ("rays", C.c_uint64), ("pixels", C.c_uint64), ("trace_ms", C.c_double),
                 ("temporal_ms", C.c_double), ("denoise_ms", C.c_double), ("timed_frames", C.c_uint64),
                 ("timed_launches", C.c_uint64), ("scene_bytes", C.c_uint64), ("noise_bytes", C.c_uint64), ("local_rows", C.c_uint32),
-                ("octree_depth", C.c_uint32), ("octree_nodes", C.c_uint64), ("queue_bytes", C.c_uint64),
+                ("octree_depth", C.c_uint32), ("octree_nodes", C.c_uint64), ("wide_nodes", C.c_uint64), ("scene_format", C.c_uint32),
+                ("reserved0", C.c_uint32), ("queue_bytes", C.c_uint64),
                 ("queue_overflow_paths", C.c_uint64)]
 
 
-OPT_DENOISE_MODE, OPT_TAIL_CAPACITY = 1, 2
+OPT_DENOISE_MODE, OPT_TAIL_CAPACITY, OPT_SCENE_FORMAT = 1, 2, 3
 
 
 class Camera:
@@ -179,6 +180,22 @@ def build_octree(pos, mrgb):
     _check(lib().vxrt_build_octree(_p(pos), _p(mrgb), C.c_size_t(len(pos)), _p(words), C.c_size_t(n.value),
                                    C.byref(n), C.byref(depth)), "vxrt_build_octree")
     return words, int(depth.value)
+
+
+def build_records(pos, mrgb):
+    """The device scene formats of a voxel list, built on the host (vxrt_build_records) ->
+    (svo uint32[n,2] = masks, base; wide uint32[m,4] = mask lo, mask hi, base, top; leaves int32[k]; depth)."""
+    pos = np.ascontiguousarray(pos, np.int16)
+    mrgb = np.ascontiguousarray(mrgb, np.uint8)
+    ns, nw, nl, depth = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_uint32(0)
+    call = lambda svo, wide, leaves: _check(lib().vxrt_build_records(  # noqa: E731
+        _p(pos), _p(mrgb), C.c_size_t(len(pos)), _p(svo), C.c_size_t(0 if svo is None else len(svo)), C.byref(ns), _p(wide),
+        C.c_size_t(0 if wide is None else len(wide)), C.byref(nw), _p(leaves), C.c_size_t(0 if leaves is None else len(leaves)),
+        C.byref(nl), C.byref(depth)), "vxrt_build_records")
+    call(None, None, None)
+    svo, wide, leaves = np.zeros((ns.value, 2), np.uint32), np.zeros((nw.value, 4), np.uint32), np.zeros(nl.value, np.int32)
+    call(svo, wide, leaves)
+    return svo, wide, leaves, int(depth.value)
 
 
 def noise_table(seed=DEFAULT_NOISE_SEED, n=NOISE_LEN):

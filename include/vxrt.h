@@ -147,6 +147,9 @@ typedef struct vxrt_stats {
     uint32_t local_rows;      /* rows owned by this context                                             */
     uint32_t octree_depth;
     uint64_t octree_nodes;
+    uint64_t wide_nodes;      /* records of the scene's two-levels-per-record form (16 bytes each), kept beside the 8-byte ones */
+    uint32_t scene_format;    /* which of the two the default tracer walks right now: 0 8-byte records, 1 wide records      */
+    uint32_t reserved0;
     uint64_t queue_bytes;     /* device bytes of the tracer's path queues (sized by need for tracers 4 / 5)             */
     uint64_t queue_overflow_paths; /* paths that found their queue shard full and were followed by the head kernel
                                  instead (same image; the queues grow before the stream's next launch)               */
@@ -158,8 +161,11 @@ typedef struct vxrt_stats {
  *                             with a reciprocal multiply and the hardware's exp2; within BASELINE's RMSE <= 1e-3 of mode 0
  *                             (tests/test_gpu_pipeline.py), about twice as fast for radius >= 4.
  *   VXRT_OPT_TAIL_CAPACITY records per shard of the compacted tail's path queue (test hook: a small value forces the
- *                          queue-full path); 0 = back to automatic sizing.                                               */
-typedef enum vxrt_option { VXRT_OPT_DENOISE_MODE = 1, VXRT_OPT_TAIL_CAPACITY = 2 } vxrt_option;
+ *                          queue-full path); 0 = back to automatic sizing.
+ *   VXRT_OPT_SCENE_FORMAT  which scene records tracers 1 and 4 walk: 0 the 8-byte records (one tree level each), 1 the wide records
+ *                          (two levels per 16-byte record: half the dependent loads), 2 automatic (default: wide once the scene is
+ *                          larger than the 256 MB Infinity Cache).  Same image either way.                                 */
+typedef enum vxrt_option { VXRT_OPT_DENOISE_MODE = 1, VXRT_OPT_TAIL_CAPACITY = 2, VXRT_OPT_SCENE_FORMAT = 3 } vxrt_option;
 int vxrt_set_option(vxrt_ctx* ctx, vxrt_option option, uint32_t value);
 
 /* ---- context: replaces Context::new / create_bindings / resize (src/context.rs:595-660, 936-1016,
@@ -226,6 +232,10 @@ int vxrt_halo_import(vxrt_ctx* ctx, const void* dev_from_prev, const void* dev_f
 
 /* ---- host-side scene preparation, callable without a GPU (src/vox.rs, src/context.rs:710-834,
  *      913-933, src/camera.rs).  Counts are returned through *n; nothing is written past cap. ------ */
+/* The device scene formats for a voxel list (csrc/kernels.h: SvoRecord = 2 words, WideRec = 4 words per record; leaf words as in
+ * src/context.rs:732-735), built on the host exactly as vxrt_set_voxels builds them: for tools and tests.  Null arrays: sizes only. */
+int vxrt_build_records(const int16_t (*pos)[3], const uint8_t (*mrgb)[4], size_t n, uint32_t* svo, size_t svo_cap, size_t* n_svo,
+                       uint32_t* wide, size_t wide_cap, size_t* n_wide, int32_t* leaves, size_t leaf_cap, size_t* n_leaves, uint32_t* depth);
 int vxrt_vox_to_voxels(const uint8_t* bytes, size_t len, int16_t (*pos)[3], uint8_t (*mrgb)[4], size_t cap,
                        size_t* n, uint32_t size_xyz[3]);
 int vxrt_build_octree(const int16_t (*pos)[3], const uint8_t (*mrgb)[4], size_t n, int32_t* words, size_t cap,

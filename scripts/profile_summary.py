@@ -56,7 +56,7 @@ if traffic:
     except Exception:  # noqa: BLE001
         fpl, alg = None, None
     out["traffic"] = {
-        "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --output-format csv -- python3 bench.py --steps 96 --warmup 32 --no-cpu-baseline",
+        "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --output-format csv -- python3 bench.py --steps 96 --warmup 32 --blocks 2 --no-cpu-baseline",
         "frames_per_launch": fpl, "algorithmic_bytes_per_launch": alg, "per_kernel": traffic,
         "hbm_bytes_per_launch_raw": sum(t["bytes_raw"] for t in traffic.values()),
         "hbm_bytes_per_launch_corrected": sum(t["bytes_read_doubled"] for t in traffic.values()),

@@ -66,3 +66,25 @@ int main(void) {
     subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip().endswith("bad 0"), out.stdout
+
+
+def test_sun_power_is_exactly_zero_below_the_kernels_bound(O):
+    """The tracer skips pow(x, 1/sun_size^2) (voxels.comp:378-381) for x below TraceArgs::sun_zero_below =
+    float(exp(-88 / y) * (1 - 1e-4)) (csrc/vxrt_api.hip frame_constants, csrc/trace_common.h sun_power_of) because
+    vx_pow(x, y) = vx_exp(y * vx_log(x)) is +0 there.  Checked on the contract's own vx_pow: the 2^21 binary32 values just below
+    the bound, a log-uniform sample of everything below it, zero and the denormals — for the default exponent 400 and others."""
+    rng = np.random.default_rng(3)
+    for y in (400.0, 1.0 / (0.05 * 0.05), 1.5, 10.0, 123.456, 1e4, 9.9e5):
+        y32 = np.float32(y)
+        bound = np.float32(np.exp(-88.0 / float(y32)) * (1.0 - 1e-4))
+        assert 0 < bound < 1
+        top = (bound.view(np.uint32) - np.arange(1, 1 << 21, dtype=np.uint32)).view(np.float32)    # the floats just below the bound
+        sample = np.exp(rng.uniform(np.log(1e-38), np.log(float(bound)), 1 << 20)).astype(np.float32)
+        sample = sample[sample < bound]
+        small = np.concatenate([[0.0], np.float32(1e-45) * np.arange(1, 1000, dtype=np.float32)]).astype(np.float32)
+        for x in (top, sample, small):
+            p = O.detmath("pow", x, np.full_like(x, y32))
+            assert (p.view(np.uint32) == 0).all(), (y, float(x[(p != 0) | np.signbit(p)][0]))
+        # and the bound is not absurdly conservative: two units of the exponent above it the power is positive
+        above = np.float32(np.exp(-86.0 / float(y32)))
+        assert O.detmath("pow", np.array([above]), np.array([y32]))[0] > 0

@@ -156,3 +156,74 @@ def test_bench_schedule_choice():
     assert bench.block_count(0.12, 7) == 7
     assert bench.pick_schedule(8, 1000, inflight=2, batch=4) == (2, 4)   # explicit values are kept
     assert bench.algorithmic_bytes(1920 * 1080, 4, 359016 + 640000) == 48 * 1920 * 1080 + 999016 + 32 * 65536
+
+
+def decode_wide(wide, leaves, depth):
+    """Every (x, y, z, leaf word) a walk over the wide records (csrc/kernels.h: WideRec) can reach — written from the format's
+    description, independently of the kernels: levels paired from the bottom, byte s of the 64-bit mask = occupancy of sub s,
+    grandchild (s, o) = base + popcount(mask below bit 8s+o); with an odd number of node levels the root is sub 0 of a virtual top."""
+    L = depth + 1
+    out = []
+
+    def rank(mask, pos):
+        return bin(mask & ((1 << pos) - 1)).count("1")
+
+    def visit_sub(rec, s, cx, cy, cz, extent, level):
+        # node at `level` (a sub of rec) centred (cx, cy, cz) with half-size `extent` (src/context.rs:749-753 geometry)
+        mask = int(rec[0]) | int(rec[1]) << 32
+        byte = (mask >> (8 * s)) & 0xff
+        for o in range(8):
+            if not byte >> o & 1:
+                continue
+            dx, dy, dz = o >> 2 & 1, o >> 1 & 1, o & 1
+            idx = int(rec[2]) + rank(mask, 8 * s + o)
+            if level == L - 1:      # leaf parent: unit voxels at c - 1 + d
+                out.append((cx - 1 + dx, cy - 1 + dy, cz - 1 + dz, int(leaves[idx])))
+            else:
+                h = extent // 2
+                visit_top(wide[idx], cx - h + dx * extent, cy - h + dy * extent, cz - h + dz * extent, h, level + 1)
+
+    def visit_top(rec, cx, cy, cz, extent, level):
+        mask = int(rec[0]) | int(rec[1]) << 32
+        for s in range(8):
+            occupied = (mask >> (8 * s)) & 0xff != 0
+            assert occupied == bool(int(rec[3]) >> s & 1)          # .top mirrors "byte s != 0"
+            if occupied:
+                h = extent // 2
+                visit_sub(rec, s, cx - h + (s >> 2 & 1) * extent, cy - h + (s >> 1 & 1) * extent, cz - h + (s & 1) * extent, h, level + 1)
+
+    if L % 2:
+        visit_sub(wide[0], 0, 0, 0, 0, 1 << depth, 0)
+    else:
+        visit_top(wide[0], 0, 0, 0, 1 << depth, 0)
+    return sorted(out)
+
+
+@pytest.mark.parametrize("case", ["castle", "8x8x8", "single", "empty", "negative", "depth4", "depth10", "depth15"])
+def test_wide_records_hold_the_voxel_set(H, scenes, case):
+    """The two-levels-per-record scene format (16-byte WideRec) decodes to exactly the voxel list it was built from — for even and odd
+    numbers of tree levels (odd: the root hangs under a virtual top), an empty scene, one voxel, all eight root octants."""
+    rng = np.random.default_rng(9)
+    if case in ("castle", "8x8x8"):
+        pos, mrgb, _ = scenes.load_scene(case)
+    elif case == "single":
+        pos, mrgb = np.array([[0, 0, 0]], np.int16), np.array([[0x40, 1, 2, 3]], np.uint8)
+    elif case == "empty":
+        pos, mrgb = np.zeros((0, 3), np.int16), np.zeros((0, 4), np.uint8)
+    elif case == "negative":
+        pos, mrgb = rng.integers(-40, 40, (3000, 3)).astype(np.int16), rng.integers(0, 256, (3000, 4)).astype(np.uint8)
+    else:
+        hi = {"depth4": 15, "depth10": 1000, "depth15": 32767}[case]
+        pos = np.concatenate([rng.integers(0, hi + 1, (500, 3)), [[hi, 0, 3]]]).astype(np.int16)
+        mrgb = rng.integers(0, 256, (len(pos), 4)).astype(np.uint8)
+    svo, wide, leaves, depth = H.build_records(pos, mrgb)
+    if case.startswith("depth"):
+        assert depth == int(case[5:])
+    # the reference's overwrite rule: the last voxel at a position wins (src/context.rs:732-735)
+    want = {}
+    for p, m in zip(pos.tolist(), mrgb.tolist()):
+        want[tuple(p)] = -2 ** 31 | (m[0] & 0x7f) << 24 | m[1] << 16 | m[2] << 8 | m[3]
+    got = decode_wide(wide, leaves, depth)
+    assert [(x, y, z) for x, y, z, _ in got] == sorted(want)
+    assert all(want[(x, y, z)] == w for x, y, z, w in got)
+    assert len(wide) <= len(svo) and (len(svo) < 16 or 16 * len(wide) < 8 * len(svo))     # fewer bytes than the 8-byte records
