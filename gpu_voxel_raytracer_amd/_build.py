@@ -5,9 +5,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvxrt.so")
-SOURCES = ["vxrt_api.hip", "trace.hip", "trace_wavefront.hip", "trace_tail.hip", "trace_paths.hip", "post.hip", "noise.hip", "scene_host.cpp", "scene_procedural.cpp",
+SOURCES = ["vxrt_api.hip", "trace.hip", "trace_wavefront.hip", "trace_tail.hip", "trace_paths.hip", "post.hip", "noise.hip", "scene_device.hip", "scene_host.cpp", "scene_procedural.cpp",
            "noise_zip.cpp", "vox_scene.cpp"]
-HEADERS = ["kernels.h", "trace_common.h", "scene_host.h", "vx_vec.h", os.path.join("..", "..", "include", "vxrt.h"),
+HEADERS = ["kernels.h", "trace_common.h", "walk_wide.h", "scene_host.h", "vx_vec.h", os.path.join("..", "..", "include", "vxrt.h"),
            os.path.join("..", "..", "include", "vxrt_detmath.h"),
            os.path.join("..", "..", "include", "vxrt_bluenoise.h")]
 

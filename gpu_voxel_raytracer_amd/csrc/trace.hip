@@ -37,6 +37,13 @@ namespace vxrt {
 namespace {
 
 
+// What is kept while a hit's sun ray is out.  0: the shader's order — everything about the hit is computed before the sun ray
+// (pend_sun, pend_emit, next_dir: 9 registers alive during the cast).  1: only the packed normal and the leaf word are kept and the
+// rest of the shading runs after the cast (87 instead of 93 VGPRs) — measured 5 % SLOWER at 5 waves per SIMD: the colour table
+// loads and the hemisphere's noise loads then sit in a second wait between two casts.  2: as 1 with the colour carried.
+#ifndef VXRT_DEFER_SHADING
+#define VXRT_DEFER_SHADING 0
+#endif
 #ifndef VXRT_TRACE_WAVES
 #define VXRT_TRACE_WAVES 5   // waves per SIMD the register allocation aims for (96 VGPRs)
 #endif
@@ -88,13 +95,23 @@ __global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const Trac
         uint32_t ambient_rays = 1;
         int bounce = 0;
         bool sun_phase = false;
-        f3 pend_sun = splat3(0.0f), pend_emit = splat3(0.0f), next_dir = splat3(0.0f);
+#if VXRT_DEFER_SHADING
+        uint32_t held = 0;        // while a sun ray is out: the hit's normal, 2 bits per axis (pack_axis)
+        int32_t held_node = 0;    // ... and its leaf word
+#endif
+#if VXRT_DEFER_SHADING == 2
+        f3 held_color = splat3(1.0f);
+#endif
+#if !VXRT_DEFER_SHADING
+        f3 pend_sun = splat3(0.0f), pend_emit = splat3(0.0f), next_dir = splat3(0.0f);   // what the deferral replaces
+#endif
 
         for (;;) {
             RayHit hit;
             rays++;
             const bool is_hit = caster.cast(o, d, hit);
 
+#if !VXRT_DEFER_SHADING
             if (sun_phase) {  // back from the sun shadow ray                 voxels.comp:357-371
                 if (!is_hit) sample = sample + pend_sun;
                 sample = sample + pend_emit;
@@ -103,6 +120,27 @@ __global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const Trac
                 if (++bounce >= a.max_bounces) break;
                 continue;
             }
+#else
+            if (sun_phase) {  // back from the sun shadow ray: the rest of the hit's shading       voxels.comp:357-371
+                // (what the shader computes before the cast is computed here, after it, from the packed normal and the leaf word:
+                // the same operations on the same operands, but seven registers fewer are alive while the sun ray walks)
+                const f3 n = mk3(unpack_axis(held & 3u), unpack_axis((held >> 2) & 3u), unpack_axis((held >> 4) & 3u));
+#if VXRT_DEFER_SHADING == 2
+                const f3 color = held_color;   // carried: no table loads on the way from the sun ray to the bounce ray
+#else
+                const f3 color = bounce == 0 ? splat3(1.0f) : node_color(held_node);
+#endif
+                const f3 emit = node_emittance(held_node, a.emit_strength);
+                if (!is_hit) sample = sample + ((sun_color * color) * blend) * vx_max(0.0f, dot3(n, d));   // d is still the sun ray
+                const f3 refl = random_hemisphere(n, rng);
+                sample = sample + emit * blend;
+                blend = blend * (color * dot3(n, refl));
+                d = refl;
+                sun_phase = false;
+                if (++bounce >= a.max_bounces) break;
+                continue;
+            }
+#endif
 
             if (!is_hit) {  // sky                                              voxels.comp:373-388
                 if (bounce == 0) {
@@ -164,12 +202,20 @@ __global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const Trac
                 f3 light_dir = ld3(a.sun_dir_n) + (dx * right_dir + dy * up_dir) * a.sun_size;
                 f3 to_light = norm3(-light_dir);
                 ambient_rays++;
+#if VXRT_DEFER_SHADING
+                held = pack_axis(n.x) | pack_axis(n.y) << 2 | pack_axis(n.z) << 4;
+                held_node = hit.node;
+#if VXRT_DEFER_SHADING == 2
+                held_color = color;
+#endif
+#else
                 pend_sun = ((sun_color * color) * blend) * vx_max(0.0f, dot3(n, to_light));
                 f3 refl = random_hemisphere(n, rng);
                 pend_emit = emit * blend;
                 blend = blend * (color * dot3(n, refl));
-                o = hit_pos + 1e-5f * n;
                 next_dir = refl;
+#endif
+                o = hit_pos + 1e-5f * n;
                 d = to_light;
                 sun_phase = true;
                 continue;

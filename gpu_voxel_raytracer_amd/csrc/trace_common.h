@@ -683,9 +683,16 @@ __device__ __forceinline__ Shaded shade_hit(const TraceArgs& a, int bounce, f3 h
 // exp; the result is the same bit pattern either way (tests/test_gpu_detmath.py::test_sun_power_shortcut).
 __device__ __forceinline__ float sun_power_of(const TraceArgs& a, f3 d) {
     const float x = vx_max(0.0f, dot3(d, ld3(a.neg_sun_dir_n)));
+#ifndef VXRT_SUN_SHORTCUT
+#define VXRT_SUN_SHORTCUT 1
+#endif
+#if VXRT_SUN_SHORTCUT
     float p = 0.0f;
     if (!(x < a.sun_zero_below)) p = vx_pow(x, a.sun_exponent);
     return p;
+#else
+    return vx_pow(x, a.sun_exponent);
+#endif
 }
 
 // The G-buffer is written once and never read back by the tracer: stream it (global_store ... nt) so that the SVO records

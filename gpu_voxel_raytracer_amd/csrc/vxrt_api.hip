@@ -25,6 +25,9 @@ const std::string& last_error();
 int build_menger_svo(uint32_t level, uint32_t clip, const uint8_t mrgb[4], uint32_t emissive_period, std::vector<SvoRecord>* recs,
                      std::vector<int32_t>* leaves, uint32_t* depth_out);
 int32_t procedural_leaf_word(uint32_t x, uint32_t y, uint32_t z, const uint8_t mrgb[4], uint32_t emissive_period);
+bool menger_device_build_supported(uint32_t level, uint32_t clip);
+int build_menger_svo_device(uint32_t level, uint32_t clip, const uint8_t mrgb[4], uint32_t emissive_period, hipStream_t stream,
+                            SvoRecord** d_svo, size_t* svo_count, int32_t** d_leaves, size_t* leaf_count, uint32_t* depth_out, SvoRecord* root);
 }
 using namespace vxrt;
 
@@ -75,7 +78,7 @@ struct vxrt_ctx {
     WideRec* d_wide = nullptr; // the same tree as wide records (kernels.h): two levels per 16-byte record
     WideRec wide_root{0, 0, 0, 0};
     size_t wide_count = 0;
-    int scene_format = -1;     // VXRT_OPT_SCENE_FORMAT: -1 auto (wide records once the scene outgrows the Infinity Cache), 0 8-byte, 1 wide
+    int scene_format = 0;      // VXRT_OPT_SCENE_FORMAT: 0 the 8-byte records (default), 1 also build and walk the wide records
     int32_t* d_leaves = nullptr;
     size_t svo_count = 0, leaf_count = 0;
     float root_center[3] = {0, 0, 0};
@@ -463,18 +466,24 @@ int upload_svo(vxrt_ctx* c, std::vector<SvoRecord>& recs, std::vector<int32_t>& 
     if (leaves.empty()) leaves.push_back(0);
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = sync_all(c)) return rc;
+    // The wide records are built only when asked for (VXRT_OPT_SCENE_FORMAT 1 before the scene is set): measured on MI355X the walk
+    // over them is slower than the walk over the 8-byte records on every scene tried, cache-resident or not, so the
+    // default never uses them and does not pay for their memory.
     std::vector<WideRec> wide;
-    if (int rc = widen_svo(recs, depth, &wide)) return rc;
+    if (c->scene_format == 1) { if (int rc = widen_svo(recs, depth, &wide)) return rc; }
     if (c->d_svo) (void)hipFree(c->d_svo);
     if (c->d_leaves) (void)hipFree(c->d_leaves);
     if (c->d_wide) (void)hipFree(c->d_wide);
     c->d_svo = nullptr;
     c->d_leaves = nullptr;
     c->d_wide = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_wide), wide.size() * sizeof(WideRec)));
-    HIP_TRY(hipMemcpy(c->d_wide, wide.data(), wide.size() * sizeof(WideRec), hipMemcpyHostToDevice));
     c->wide_count = wide.size();
-    c->wide_root = wide[0];
+    c->wide_root = WideRec{0, 0, 0, 0};
+    if (!wide.empty()) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_wide), wide.size() * sizeof(WideRec)));
+        HIP_TRY(hipMemcpy(c->d_wide, wide.data(), wide.size() * sizeof(WideRec), hipMemcpyHostToDevice));
+        c->wide_root = wide[0];
+    }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_svo), recs.size() * sizeof(SvoRecord)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_leaves), leaves.size() * sizeof(int32_t)));
     HIP_TRY(hipMemcpy(c->d_svo, recs.data(), recs.size() * sizeof(SvoRecord), hipMemcpyHostToDevice));
@@ -498,14 +507,11 @@ int upload_scene(vxrt_ctx* c, const Voxel* voxels, size_t n) {
     return upload_svo(c, recs, leaves, tree.depth);
 }
 
-// Which records trace_kernel / bounce_kernel walk.  Automatic: the 8-byte records while the scene sits in the caches (its descents
-// are served by L1 / L2 and the wide walk's longer instruction sequence costs more than the loads it saves), the wide records once
-// the scene lives in HBM (half the dependent loads, a third of the record bytes).  VXRT_OPT_SCENE_FORMAT / VXRT_WIDE override.
-bool use_wide(const vxrt_ctx* c) {
-    if (c->d_wide == nullptr) return false;
-    if (c->scene_format >= 0) return c->scene_format == 1;
-    return c->svo_count * sizeof(SvoRecord) + c->leaf_count * sizeof(int32_t) > (size_t(256) << 20);
-}
+// Which records trace_kernel / bounce_kernel walk: the wide ones only when VXRT_OPT_SCENE_FORMAT 1 (or VXRT_WIDE=1) asked for them
+// before the scene was set.  (They halve the dependent loads of a descent, but the walk over them executes ~35 % more instructions
+// per trip, and the stage is bound by instruction issue, not by those loads — measured: menger 1080p 21.0 vs 27.0 Gray/s, the
+// 2048^3 scene 2.68 vs 2.22 ms per 4K frame.)
+bool use_wide(const vxrt_ctx* c) { return c->d_wide != nullptr && c->scene_format == 1; }
 
 // new capacity (records per shard) for the path queues of every stream; waits for the GPU first
 int resize_tail_queues(vxrt_ctx* c, unsigned want) {
@@ -638,7 +644,7 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) try {
     if (c->tail_from < 0 || c->tail_from >= int(cfg->max_bounces)) c->tail_from = 1;
     if (const char* v = getenv("VXRT_TAIL_SPLIT")) c->tail_split = unsigned(strtoul(v, nullptr, 0));
     if (const char* v = getenv("VXRT_TAIL_CAPACITY")) c->tail_capacity_override = atoi(v);
-    if (const char* v = getenv("VXRT_WIDE")) c->scene_format = atoi(v);   // A/B: 0 the 8-byte records, 1 the wide records, -1 automatic   // test hook: force the queue-full path
+    if (const char* v = getenv("VXRT_WIDE")) c->scene_format = atoi(v) == 1 ? 1 : 0;   // A/B and tests: 1 = the wide records   // test hook: force the queue-full path
     if (const char* v = getenv("VXRT_SHADE_BLOCKS")) c->shade_blocks = atoi(v);
     if (const char* v = getenv("VXRT_RAYS_PER_WAVE")) c->rays_per_wave = unsigned(atoi(v));
     c->shade_blocks = (c->shade_blocks < 8 ? 8 : (c->shade_blocks > 2048 ? 2048 : c->shade_blocks) + 7) / 8 * 8;
@@ -768,8 +774,12 @@ int vxrt_set_option(vxrt_ctx* c, vxrt_option option, uint32_t value) try {
             c->denoise_mode = int(value);
             return VXRT_OK;
         case VXRT_OPT_SCENE_FORMAT:
-            if (value > 2) { set_error("scene format must be 0 (8-byte records), 1 (wide records) or 2 (automatic)"); return VXRT_E_INVALID; }
-            c->scene_format = value == 2 ? -1 : int(value);
+            if (value > 1) { set_error("scene format must be 0 (8-byte records) or 1 (wide records)"); return VXRT_E_INVALID; }
+            if (value == 1 && c->has_scene && c->d_wide == nullptr) {
+                set_error("the wide records are built when a scene is set: choose the format before vxrt_set_voxels / vxrt_set_menger");
+                return VXRT_E_INVALID;
+            }
+            c->scene_format = int(value);
             return VXRT_OK;
         case VXRT_OPT_TAIL_CAPACITY:
             if (c->trace_variant < 4) return VXRT_OK;   // the other tracers' queues are sized for the worst case
@@ -1482,11 +1492,47 @@ int vxrt_set_menger(vxrt_ctx* c, uint32_t level, uint32_t clip, const uint8_t mr
     uint32_t side = 1;
     for (uint32_t l = 0; l < level && l < 10; l++) side *= 3;
     if (clip == 0 || clip > side) clip = side;
+    uint32_t depth = 0;
+    // On the device when the scene fits its dense sweep (side <= 2048: 1.15 GB of scratch) and only the 8-byte records are wanted:
+    // the 2048^3 scene in a fraction of a second instead of ~9 s of host threads + a 5.6 GB upload.  VXRT_HOST_BUILD=1: the host builder.
+    if (menger_device_build_supported(level, clip) && c->scene_format != 1 && getenv("VXRT_HOST_BUILD") == nullptr) {
+        HIP_TRY(hipSetDevice(c->cfg.device));
+        if (int rc = sync_all(c)) return rc;
+        SvoRecord* svo = nullptr;
+        int32_t* lw = nullptr;
+        size_t nsvo = 0, nlw = 0;
+        SvoRecord root{0, 0};
+        if (int rc = build_menger_svo_device(level, clip, mrgb, emissive_period, c->stream, &svo, &nsvo, &lw, &nlw, &depth, &root)) return rc;
+        if (c->d_svo) (void)hipFree(c->d_svo);
+        if (c->d_leaves) (void)hipFree(c->d_leaves);
+        if (c->d_wide) (void)hipFree(c->d_wide);
+        c->d_svo = svo; c->d_leaves = lw; c->d_wide = nullptr;
+        c->svo_count = nsvo; c->leaf_count = nlw; c->wide_count = 0;
+        c->root_rec = root;
+        c->wide_root = WideRec{0, 0, 0, 0};
+        c->root_center[0] = c->root_center[1] = c->root_center[2] = 0.0f;
+        c->root_size = float(1u << depth);
+        c->depth = depth;
+        c->has_scene = true;
+        return VXRT_OK;
+    }
     std::vector<SvoRecord> recs;
     std::vector<int32_t> leaves;
-    uint32_t depth = 0;
     if (int rc = build_menger_svo(level, clip, mrgb, emissive_period, &recs, &leaves, &depth)) return rc;
     return upload_svo(c, recs, leaves, depth);
+} VXRT_CATCH
+
+// Test hook: the scene as the device holds it (8-byte records: 2 words each; leaf words).  Null arrays: sizes only.
+int vxrt_debug_read_scene(vxrt_ctx* c, uint32_t* svo, size_t svo_cap, size_t* n_svo, int32_t* leaves, size_t leaf_cap, size_t* n_leaves) try {
+    if (!valid_ctx(c) || !n_svo || !n_leaves) { set_error("null argument"); return VXRT_E_INVALID; }
+    if (!c->has_scene) { set_error("no scene set"); return VXRT_E_NOSCENE; }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = sync_all(c)) return rc;
+    *n_svo = c->svo_count;
+    *n_leaves = c->leaf_count;
+    if (svo && svo_cap >= c->svo_count) HIP_TRY(hipMemcpy(svo, c->d_svo, c->svo_count * sizeof(SvoRecord), hipMemcpyDeviceToHost));
+    if (leaves && leaf_cap >= c->leaf_count) HIP_TRY(hipMemcpy(leaves, c->d_leaves, c->leaf_count * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return VXRT_OK;
 } VXRT_CATCH
 
 // ---- blue noise (include/vxrt_bluenoise.h, csrc/noise.hip, csrc/noise_zip.cpp) ----------------------------------

@@ -337,6 +337,15 @@ class Context:
         _check(lib().vxrt_set_menger(self._h, C.c_uint32(level), C.c_uint32(clip), _p(m), C.c_uint32(emissive_period)),
                "vxrt_set_menger")
 
+    def read_scene(self):
+        """Test hook (vxrt_debug_read_scene): the device's scene -> (svo uint32[n,2] = masks, base; leaves int32[k])."""
+        ns, nl = C.c_size_t(0), C.c_size_t(0)
+        _check(lib().vxrt_debug_read_scene(self._h, None, C.c_size_t(0), C.byref(ns), None, C.c_size_t(0), C.byref(nl)), "vxrt_debug_read_scene")
+        svo, leaves = np.zeros((ns.value, 2), np.uint32), np.zeros(nl.value, np.int32)
+        _check(lib().vxrt_debug_read_scene(self._h, _p(svo), C.c_size_t(len(svo)), C.byref(ns), _p(leaves), C.c_size_t(len(leaves)), C.byref(nl)),
+               "vxrt_debug_read_scene")
+        return svo, leaves
+
     def load_vox(self, path, flags=0):
         """vox::load + voxels_from_vox + recreate_octree (src/context.rs:1817-1821); flags: VOX_* for whole scenes."""
         if flags == 0:

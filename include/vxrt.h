@@ -147,7 +147,7 @@ typedef struct vxrt_stats {
     uint32_t local_rows;      /* rows owned by this context                                             */
     uint32_t octree_depth;
     uint64_t octree_nodes;
-    uint64_t wide_nodes;      /* records of the scene's two-levels-per-record form (16 bytes each), kept beside the 8-byte ones */
+    uint64_t wide_nodes;      /* records of the scene's two-levels-per-record form (16 bytes each); 0 unless VXRT_OPT_SCENE_FORMAT 1 */
     uint32_t scene_format;    /* which of the two the default tracer walks right now: 0 8-byte records, 1 wide records      */
     uint32_t reserved0;
     uint64_t queue_bytes;     /* device bytes of the tracer's path queues (sized by need for tracers 4 / 5)             */
@@ -162,9 +162,10 @@ typedef struct vxrt_stats {
  *                             (tests/test_gpu_pipeline.py), about twice as fast for radius >= 4.
  *   VXRT_OPT_TAIL_CAPACITY records per shard of the compacted tail's path queue (test hook: a small value forces the
  *                          queue-full path); 0 = back to automatic sizing.
- *   VXRT_OPT_SCENE_FORMAT  which scene records tracers 1 and 4 walk: 0 the 8-byte records (one tree level each), 1 the wide records
- *                          (two levels per 16-byte record: half the dependent loads), 2 automatic (default: wide once the scene is
- *                          larger than the 256 MB Infinity Cache).  Same image either way.                                 */
+ *   VXRT_OPT_SCENE_FORMAT  which scene records tracers 1 and 4 walk: 0 (default) the 8-byte records, one tree level each; 1 the wide
+ *                          records, two levels per 16-byte record (half the dependent loads of a descent, ~35 % more instructions
+ *                          per step: slower on MI355X for every scene measured, kept for comparison).  Same image either way.
+ *                          Must be chosen before the scene is set (the wide records are built with the scene).              */
 typedef enum vxrt_option { VXRT_OPT_DENOISE_MODE = 1, VXRT_OPT_TAIL_CAPACITY = 2, VXRT_OPT_SCENE_FORMAT = 3 } vxrt_option;
 int vxrt_set_option(vxrt_ctx* ctx, vxrt_option option, uint32_t value);
 
@@ -232,6 +233,8 @@ int vxrt_halo_import(vxrt_ctx* ctx, const void* dev_from_prev, const void* dev_f
 
 /* ---- host-side scene preparation, callable without a GPU (src/vox.rs, src/context.rs:710-834,
  *      913-933, src/camera.rs).  Counts are returned through *n; nothing is written past cap. ------ */
+/* Test hook: the scene as the device holds it right now (8-byte records, 2 words each; leaf words).  Null arrays: sizes only. */
+int vxrt_debug_read_scene(vxrt_ctx* ctx, uint32_t* svo, size_t svo_cap, size_t* n_svo, int32_t* leaves, size_t leaf_cap, size_t* n_leaves);
 /* The device scene formats for a voxel list (csrc/kernels.h: SvoRecord = 2 words, WideRec = 4 words per record; leaf words as in
  * src/context.rs:732-735), built on the host exactly as vxrt_set_voxels builds them: for tools and tests.  Null arrays: sizes only. */
 int vxrt_build_records(const int16_t (*pos)[3], const uint8_t (*mrgb)[4], size_t n, uint32_t* svo, size_t svo_cap, size_t* n_svo,

@@ -19,10 +19,13 @@ pytestmark = pytest.mark.gpu
 W, HH, BOUNCES, SPP, NRANKS, RANK, BAND = 7680, 4320, 8, 16, 8, 5, 16
 
 
-def make_context(noise, tracer, rank=RANK):
+def make_context(noise, tracer, rank=RANK, wide=False):
     from gpu_voxel_raytracer_amd import Context
+    from gpu_voxel_raytracer_amd.host import OPT_SCENE_FORMAT
     ctx = Context(W, HH, max_bounces=BOUNCES, noise=noise, rank=rank, nranks=NRANKS, band_rows=BAND, frames_per_launch=SPP,
                   frames_in_flight=1, tracer=tracer)
+    if wide:
+        ctx.set_option(OPT_SCENE_FORMAT, 1)     # also build and walk the two-levels-per-record form of the scene
     ctx.set_menger(*FULL)
     return ctx
 
@@ -41,9 +44,11 @@ def test_config5_one_rank_of_the_8k_frame_vs_oracle(O, H, noise):
     cam = full_size_cameras()["outside"]
     u = oracle_uniforms(O, cam)
     results = {}
-    for tracer in (0, 1, 4):   # 0: what the library picks for a scene of this size; 1: all-in-one kernel; 4: head + compacted tail
-        with make_context(noise, tracer) as ctx:
+    # 0: what the library picks for a scene of this size; 1: all-in-one kernel; 4: head + compacted tail; "wide": the wide scene records
+    for tracer in (0, 1, 4, "wide"):
+        with make_context(noise, 4 if tracer == "wide" else tracer, wide=tracer == "wide") as ctx:
             st = ctx.stats()
+            assert (st.scene_format, st.wide_nodes > 30_000_000) == ((1, True) if tracer == "wide" else (0, False))
             assert st.octree_depth == 11 == O.menger_depth(level, clip) and st.octree_nodes > 250_000_000
             assert st.octree_nodes * 8 < 2 ** 31                       # voxels.comp:175 would still index it with an int
             assert st.scene_bytes > 5 * 2 ** 30                        # HBM-resident, far beyond the 256 MB Infinity Cache
@@ -60,7 +65,7 @@ def test_config5_one_rank_of_the_8k_frame_vs_oracle(O, H, noise):
             results[tracer] = (one, rays_one, [ctx.read(i) for i in (SAMPLED_COLOR, NORMAL_DEPTH, ALBEDO_NODE, ACCUM_COLOR)], ctx.stats().rays, rows)
 
     one, rays_one, shown, rays_shown, rows = results[0]
-    for tracer in (1, 4):
+    for tracer in (1, 4, "wide"):
         for a, b, label in zip(results[0][0] + results[0][2], results[tracer][0] + results[tracer][2],
                                ("colour", "nd", "albedo", "mean colour", "nd16", "albedo16", "accum")):
             assert_bits_equal(a, b, f"config 5: tracer {tracer} vs default, {label}")

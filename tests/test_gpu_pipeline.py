@@ -331,7 +331,7 @@ def test_bench_two_ranks_on_one_gpu():
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 96 and d["scaling"] == "strong" and "x2" in d["config"]["parallelism"]
-    assert abs(d["config"]["rays_per_frame"] - 3320514) < 64          # the single-context frame's count (sum over the ranks' bands)
+    assert abs(d["config"]["rays_per_frame"] - 3320514) < 1500        # the single-context frames' count (sum over the ranks' bands; +- the noise of the block's frames)
     assert d["value"] > 1000.0
 
 

@@ -164,6 +164,9 @@ def test_full_size_bench_config_crops(O, H, scenes, noise):
     {"VXRT_TRACE_VARIANT": "5"},                                                        # monolithic head + path_kernel (lanes refilled path by path)
     {"VXRT_TRACE_VARIANT": "5", "VXRT_PATH_BLOCKS": "1", "VXRT_INFLIGHT": "2"},         # ... four waves take the whole queue: many refills per lane
     {"VXRT_TRACE_VARIANT": "5", "VXRT_TAIL_FROM": "2", "VXRT_BATCH": "4"},              # ... tail from hit 2 (the API calls here are single frames)
+    {"VXRT_WIDE": "1"},                                                                 # the wide scene records (two levels per record), default tracer
+    {"VXRT_WIDE": "1", "VXRT_TRACE_VARIANT": "0"},                                      # ... all-in-one kernel
+    {"VXRT_WIDE": "1", "VXRT_TRACE_VARIANT": "4", "VXRT_TAIL_SPLIT": "0xc", "VXRT_INFLIGHT": "3", "VXRT_TAIL_CAPACITY": "128"},
 ])
 def test_every_trace_variant_is_bit_exact(O, H, scenes, noise, monkeypatch, env):
     """The scheduling variants of the tracer (read from the environment when a context is created) change
@@ -217,7 +220,9 @@ def _render_voxels(O, noise, pos, mrgb, cam, w, h, bounces, frames=(1,)):
     return out
 
 
-def test_empty_scene_and_single_voxel(O, H, noise):
+@pytest.mark.parametrize("wide", ["0", "1"])     # the 8-byte scene records / the wide ones (odd and even numbers of tree levels)
+def test_empty_scene_and_single_voxel(O, H, noise, monkeypatch, wide):
+    monkeypatch.setenv("VXRT_WIDE", wide)
     """Edge cases of the scene format: no voxels at all (root node of eight empty slots, depth 0) and one voxel."""
     f32 = np.float32
     cam = (np.array([3, 2, -4], f32), np.array([-3, -2, 4], f32), 1.0)
@@ -232,7 +237,9 @@ def test_empty_scene_and_single_voxel(O, H, noise):
                 assert (g[1][..., 3] == -1).all()
 
 
-def test_deep_octree_negative_coordinates_and_depth_limit(O, H, noise):
+@pytest.mark.parametrize("wide", ["0", "1"])     # the 8-byte scene records / the wide ones (odd and even numbers of tree levels)
+def test_deep_octree_negative_coordinates_and_depth_limit(O, H, noise, monkeypatch, wide):
+    monkeypatch.setenv("VXRT_WIDE", wide)
     """Random voxels on both sides of the origin (all eight root octants used), a depth-10 tree, and the deepest
     tree i16 coordinates allow (depth 15)."""
     rng = np.random.default_rng(42)
@@ -266,10 +273,12 @@ def test_deep_octree_negative_coordinates_and_depth_limit(O, H, noise):
             assert rays == ref[3]
 
 
-def test_zero_times_infinity_rays_through_the_gpu(O, H, scenes, noise):
+@pytest.mark.parametrize("wide", ["0", "1"])
+def test_zero_times_infinity_rays_through_the_gpu(O, H, scenes, noise, monkeypatch, wide):
     """An axis-aligned camera on integer coordinates sends its centre rays exactly along +z through node mid-planes:
     (center - origin) * (1/0) = 0 * inf = NaN in the shader (voxels.comp:140,191).  The kernel reproduces the
     oracle's NaNs and everything around them."""
+    monkeypatch.setenv("VXRT_WIDE", wide)
     pos, mrgb, size = scenes.load_scene("8x8x8")
     f32 = np.float32
     cam = (np.array([1, 1, -5], f32), np.array([0, 0, 1], f32), 1.0)
@@ -296,7 +305,7 @@ CAP_RAYS_D = np.array([[1, 0, 0], [1, 1e-5, 1e-5], [1, 1e-4, -2e-5], [1, 0, 1e-6
 
 @pytest.mark.parametrize("env", [{}, {"VXRT_TRACE_VARIANT": "0"}, {"VXRT_TRACE_VARIANT": "2", "VXRT_TRACE_SPLIT": "0x3"},
                                  {"VXRT_TRACE_VARIANT": "3"}, {"VXRT_TRACE_VARIANT": "4", "VXRT_TAIL_FROM": "0"},
-                                 {"VXRT_TRACE_VARIANT": "5"}])
+                                 {"VXRT_TRACE_VARIANT": "5"}, {"VXRT_WIDE": "1"}])
 def test_iteration_cap(O, H, noise, monkeypatch, env):
     """voxels.comp:163-169: the 2 048th trip of the loop returns TRUE with out_node = LEAF_BIT, the time the walk is at, and
     the normal unwritten (defined as 0 here and in the oracle, U1 — the shader leaves it undefined: parity unpinned).
