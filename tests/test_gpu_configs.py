@@ -55,11 +55,12 @@ def test_config3_full_size_pipeline(O, H, scenes, noise):
     assert np.sqrt(np.mean((got[..., :3].astype(np.float64) - want[-1][4][..., :3]) ** 2)) <= 1e-3
 
 
-def test_config4_eight_ranks_with_halo_at_4k(H, scenes, noise):
+def test_config4_eight_ranks_with_halo_at_4k(O, H, scenes, noise):
     from gpu_voxel_raytracer_amd import ALL, DENOISE, TEMPORAL, TRACE, Camera, Context
     w, h, bounces, radius, nranks = 3840, 2160, 4, 8, 8
     pos, mrgb, size = scenes.load_scene("castle")
     cam = Camera(*scenes.close_camera(size))
+    cam_tuple = scenes.close_camera(size)
     rt = hip()
 
     def setup(ctx):
@@ -100,6 +101,34 @@ def test_config4_eight_ranks_with_halo_at_4k(H, scenes, noise):
                 assert_bits_equal(got, want, f"config 4 image {img}, 8 ranks at 4K")
             assert sum(c.stats().rays for c in ctxs) == single.stats().rays
             assert max(len(r) for r in rows) - min(len(r) for r in rows) <= 16
+            # and the frame the ranks agree on is the oracle's: the second displayed frame's 4-sample mean (frames 5..8), first hit
+            # and accumulated colour on three 16-row strips that straddle band edges of different ranks
+            octree = O.create_octree(pos, mrgb)
+            u = O.Uniforms.default()
+            u.set_camera(cam_tuple[0], O.camera_axis_scaled(cam_tuple[0], cam_tuple[1], cam_tuple[2], w, h))
+            cam16 = u.camera16()
+            got_mean, got_nd, got_alb, got_acc = single.read(0), single.read(1), single.read(2), single.read(3)
+            for y0 in (520, 1064, 1720):
+                means = []
+                for first in (1, 5):
+                    total = None
+                    for f in range(first, first + 4):
+                        u.frame_number = f
+                        c, d, a, _ = O.trace(octree, noise, u, w, h, bounces, crop=(0, y0, w, y0 + 16))
+                        total = c.copy() if total is None else (total + c).astype(np.float32)
+                    means.append((total / np.float32(4)).astype(np.float32))
+                assert_bits_equal(got_mean[y0:y0 + 16], means[1], f"config 4 mean colour vs oracle, rows {y0}..")
+                assert_bits_equal(got_nd[y0:y0 + 16], d, f"config 4 normal/depth vs oracle, rows {y0}..")
+                assert_bits_equal(got_alb[y0:y0 + 16], a, f"config 4 albedo/node vs oracle, rows {y0}..")
+                # temporal over the strip: camera at rest, so a strip's history is the strip itself except where the sampler's
+                # 1/512 rounding reaches a neighbouring row — compare the interior rows that do not
+                z = np.zeros_like(d)
+                acc1 = O.temporal(means[0], d, z, z, cam16, cam16, O.Temporal.default(), False)
+                canvas = [np.zeros((h, w, 4), np.float32) for _ in range(4)]
+                for img, src in zip(canvas, (means[1], d, acc1, d)):
+                    img[y0:y0 + 16] = src
+                acc2 = O.temporal(canvas[0], canvas[1], canvas[2], canvas[3], cam16, cam16, O.Temporal.default(), True)
+                assert_bits_equal(got_acc[y0 + 1:y0 + 15], acc2[y0 + 1:y0 + 15], f"config 4 accumulated colour vs oracle, rows {y0 + 1}..")
         finally:
             for c in ctxs:
                 c.close()

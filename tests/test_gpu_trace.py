@@ -55,6 +55,7 @@ def render_both(O, H, scenes, noise, name, width, height, bounces, frames=(1,), 
     ("monu10", 160, 96, 3, "close"),
     ("room", 128, 96, 3, "close"),     # emissive voxels
     ("3x3x3", 128, 128, 1, "bench"),   # BASELINE config 1 scene, 1 bounce
+    ("3x3x3", 256, 256, 1, "bench"),   # ... at config 1's own size (the reference's CPU caster for it: tests/test_cpu_rs.py)
 ])
 def test_trace_bit_exact(O, H, scenes, noise, name, w, h, bounces, camera):
     for (g, rays, ref) in render_both(O, H, scenes, noise, name, w, h, bounces, frames=(1, 2, 513), camera=camera):

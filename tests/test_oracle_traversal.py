@@ -49,7 +49,7 @@ def compare(O, pos, mrgb, o, d):
     return ok, hard, both, t, dt, iters
 
 
-@pytest.mark.parametrize("name,n", [("castle", 200000), ("8x8x8", 100000), ("menger", 200000), ("room", 100000)])
+@pytest.mark.parametrize("name,n", [("castle", 1000000), ("8x8x8", 1000000), ("menger", 1000000), ("room", 1000000), ("monu10", 1000000)])   # SURVEY 8c pin 2: >= 10^6 rays per scene
 def test_octree_walk_matches_dense_dda(O, scenes, name, n):
     pos, mrgb, size = scenes.load_scene(name)
     rng = np.random.default_rng(1234)
