@@ -51,8 +51,8 @@ for k in ("trace_kernel", "bounce_kernel"):
 if traffic:
     try:
         b = json.loads(open(f"{base}/fetch_bench.json").read().strip().splitlines()[-1])
-        fpl = b["roofline"]["frames_per_launch"]
-        alg = b["roofline"]["algorithmic_bytes_per_launch"]
+        fpl = b["roofline"]["launch"]["frames_per_launch"]
+        alg = b["roofline"]["launch"]["algorithmic_bytes_per_launch"]
     except Exception:  # noqa: BLE001
         fpl, alg = None, None
     out["traffic"] = {
