@@ -122,3 +122,95 @@ def test_oracle_shading_against_an_independent_restatement(O, scenes, noise, nam
             hits += first[1] >= 0
         assert total_casts > 250
     assert checked > 400 and hits > 100
+
+
+# ---- denoise.comp and temporal.comp, again from the shaders' text, vectorised numpy binary64 --------------------------------
+def pixel_dirs(cam16, w, h):
+    o, r, u, f = cam16[0:3].astype(np.float64), cam16[4:7].astype(np.float64), cam16[8:11].astype(np.float64), cam16[12:15].astype(np.float64)
+    x, y = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    d = x[..., None] * r - y[..., None] * u + f
+    return o, d / np.sqrt((d * d).sum(-1, keepdims=True))
+
+
+def denoise_independent(colors, nd, alb, cam16, radius, sigma_distance, sigma_range, albedo_factor):
+    """denoise.comp:24-93 (pow(v, 2) read as v*v)."""
+    h, w = colors.shape[:2]
+    _, dirs = pixel_dirs(cam16, w, h)
+    c, n, dep = colors[..., :3].astype(np.float64), nd[..., :3].astype(np.float64), nd[..., 3].astype(np.float64)
+    mat = alb[..., 3].view(np.int32) >> 24
+    bias = np.maximum(0.0, (n * -dirs).sum(-1))
+    sd2, sr2 = 2 * sigma_distance ** 2, 2 * sigma_range ** 2
+    with np.errstate(divide="ignore", invalid="ignore"):
+        logd = np.log(np.abs(dep))
+    norm_, total = np.zeros((h, w)), np.zeros((h, w, 3))
+    for dy in range(-radius, radius + 1):
+        for dx in range(-radius, radius + 1):
+            ys, xs = np.arange(h)[:, None] + dy, np.arange(w)[None, :] + dx
+            ok = (ys >= 0) & (ys < h) & (xs >= 0) & (xs < w)
+            yc, xc = np.clip(ys, 0, h - 1), np.clip(xs, 0, w - 1)
+            wc, wn, wl, wm = c[yc, xc], n[yc, xc], logd[yc, xc], mat[yc, xc]
+            with np.errstate(invalid="ignore", over="ignore"):
+                fr = (((c - wc) ** 2).sum(-1) + 1e4 * ((n - wn) ** 2).sum(-1) + 1e4 * (bias * (logd - wl)) ** 2 + 1e4 * (mat != wm)) / sr2
+                fac = np.where(ok, np.exp(-fr - (dx * dx + dy * dy) / sd2), 0.0)
+            norm_ += fac
+            total += wc * fac[..., None]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        out = c if radius == 0 else total / norm_[..., None]
+    a = alb[..., :3].astype(np.float64)
+    return out * (1 - albedo_factor) + a * out * albedo_factor
+
+
+def temporal_independent_static(sampled, nd, old_color, old_nd, cam16, tu):
+    """temporal.comp:48-125 for a camera AT REST (old camera = camera): the reprojected texel is the pixel itself, so the sampler's
+    filtering (the one thing the shader's text does not define) drops out."""
+    h, w = sampled.shape[:2]
+    o, dirs = pixel_dirs(cam16, w, h)
+    depth = nd[..., 3].astype(np.float64)
+    world = o + depth[..., None] * dirs
+    old_pos = o + old_nd[..., 3].astype(np.float64)[..., None] * dirs
+    to_cam = o - world
+    with np.errstate(invalid="ignore", divide="ignore"):
+        cam_dir = to_cam / np.sqrt((to_cam * to_cam).sum(-1, keepdims=True))
+        bias = np.maximum(0.0, (cam_dir * nd[..., :3].astype(np.float64)).sum(-1))
+    dist = np.sqrt(((old_pos - world) ** 2).sum(-1))
+    accept = (depth >= 0) & (dist < bias * tu.blending_distance_cutoff * depth)
+    blending = np.where(accept, old_color[..., 3].astype(np.float64), 1.0)
+    old_rgb = np.where(accept[..., None], old_color[..., :3].astype(np.float64), 0.0)
+    new = sampled[..., :3].astype(np.float64)
+    blended = np.where((depth >= 0)[..., None], old_rgb * (1 - blending[..., None]) + new * blending[..., None], new)
+    nxt = np.clip((1 - tu.sample_blending) * blending, 1 - tu.maximum_blending, 1)
+    return blended, nxt, accept
+
+
+@pytest.mark.parametrize("name,radius", [("castle", 2), ("room", 5), ("menger", 8)])
+def test_oracle_post_stages_against_independent_restatements(O, scenes, noise, name, radius):
+    pos, mrgb, size = scenes.load_scene(name)
+    octree = O.create_octree(pos, mrgb)
+    w, h, bounces = 80, 56, 3
+    cam = scenes.close_camera(size)
+    u = O.Uniforms.default()
+    u.set_camera(cam[0], O.camera_axis_scaled(cam[0], cam[1], cam[2], w, h))
+    cam16 = u.camera16()
+    tu = O.Temporal.default()
+    accum, old_nd = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
+    for frame in (1, 2, 3):
+        u.frame_number = frame
+        color, nd, alb, _ = O.trace(octree, noise, u, w, h, bounces, crop=(0, 0, w, h))
+        new_accum = O.temporal(color, nd, accum, old_nd, cam16, cam16, tu, frame > 1)
+        if frame > 1:
+            blended, nxt, accept = temporal_independent_static(color, nd, accum, old_nd, cam16, tu)
+            assert accept[nd[..., 3] >= 0].mean() > 0.9                                    # a static camera re-finds its surfaces
+            assert np.allclose(new_accum[..., :3], blended, rtol=1e-5, atol=1e-6)
+            assert np.allclose(new_accum[..., 3], nxt, rtol=1e-6)
+            assert np.isclose(new_accum[..., 3][accept].max(), 0.5 ** frame)                # the blending factor halves per frame (floor 0.02)
+        else:
+            assert np.array_equal(new_accum[..., :3], color[..., :3]) and (new_accum[..., 3] == 0.5).all()
+        accum, old_nd = new_accum, nd
+    du = O.Denoise.default()
+    du.radius = radius
+    got = O.denoise(accum, nd, alb, cam16, du)
+    want = denoise_independent(accum, nd, alb, cam16, radius, du.sigma_distance, du.sigma_range, du.albedo_factor)
+    ok = np.isfinite(want).all(-1)
+    assert ok.mean() > 0.99 and np.array_equal(np.isfinite(got[..., :3]).all(-1), ok)
+    assert np.allclose(got[..., :3][ok], want[ok], rtol=2e-4, atol=2e-6)
+    assert (got[..., 3] == 1).all()
