@@ -7,9 +7,12 @@ set -e
 cd "$(dirname "$0")/.."
 if [ "$1" != "run" ]; then
   scripts/ab_build.sh locate -DVXRT_LOCATE=1
+  scripts/ab_build.sh defer1 -DVXRT_DEFER_SHADING=1
+  scripts/ab_build.sh defer2 -DVXRT_DEFER_SHADING=2
+  scripts/ab_build.sh w6 -DVXRT_TRACE_WAVES=6 -DVXRT_BOUNCE_WAVES=6 -DVXRT_SUN_SHORTCUT=0 -DVXRT_TAIL_REMAT=0
   exit 0
 fi
-for tag in locate; do
+for tag in locate defer1 defer2 w6; do
   lib=$PWD/gpu_voxel_raytracer_amd/libvxrt_$tag.so
   [ -f "$lib" ] || { echo "build first: scripts/test_variants.sh"; exit 2; }
   echo "== $tag"
