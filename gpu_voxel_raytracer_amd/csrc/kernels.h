@@ -135,14 +135,7 @@ struct DenoiseArgs {
     uint32_t radius;
     float sigma_distance_2, sigma_range_2, albedo_factor;
     int mode;   // 0 exact (bit-identical to the oracle), 1 tolerant (vxrt_set_option VXRT_OPT_DENOISE_MODE)
-    // exact mode: x / sigma_range_2 as two multiply-adds around the reciprocal — used only when launch_verify_division has shown,
-    // for THIS divisor and every binary32 dividend below kDivFastBelow, that the result equals the IEEE quotient bit for bit
-    float range_reciprocal;
-    int fast_division;
 };
-constexpr float kDivFastBelow = 1.2676506e30f;   // 2^100: dividends at or above it (and NaN) take the hardware division
-// counts the binary32 values x in [0, kDivFastBelow) for which fma(fma(-q, d, x), r, q), q = x * r, differs from x / d  (r = 1 / d)
-hipError_t launch_verify_division(float d, float r, unsigned* mismatches, hipStream_t s);
 
 // Queue of live paths between two launches of the wavefront tracer (trace.hip): 64-byte records in 64 shards.
 // Ray-queue variant (trace_wavefront.hip): paths and rays of one frame between its shade / trace launches.

@@ -154,33 +154,6 @@ __global__ __launch_bounds__(256) void denoise_passthrough_kernel(const DenoiseA
     a.output[pix] = make_float4(out.x, out.y, out.z, 1.0f);
 }
 
-// x / d for a divisor that is the same for every tap of a launch (denoise.comp:77: ... / sigma_range_2).  The hardware's correctly
-// rounded division is a 9-instruction sequence around a quarter-rate reciprocal; with r = RN(1 / d) the quotient is also
-//     q = RN(x r);  e = RN(x - q d)  (exact in an fma);  RN(q + e r)
-// — for almost every d, but not provably for all (the classic exception are divisors whose significand is all ones), and the result
-// must be the IEEE quotient bit for bit.  So nothing is assumed: verify_division_kernel compares the two for EVERY binary32
-// dividend in [0, 2^100) for the divisor at hand (1.9e9 values, ~2 ms, once per value of sigma_range), and only then `fast` is set.
-__device__ __forceinline__ float divide_by_constant(float x, float d, float r, bool fast) {
-    if (fast && x < kDivFastBelow) {
-        const float q = x * r;
-        return __builtin_fmaf(__builtin_fmaf(-q, d, x), r, q);
-    }
-    return x / d;
-}
-
-__global__ __launch_bounds__(256) void verify_division_kernel(float d, float r, unsigned* mismatches) {
-    const uint32_t end = __float_as_uint(kDivFastBelow);
-    unsigned bad = 0;
-    for (uint32_t b = blockIdx.x * 256u + threadIdx.x; b < end; b += gridDim.x * 256u) {
-        const float x = __uint_as_float(b);
-        const float q = x * r;
-        const float fast = __builtin_fmaf(__builtin_fmaf(-q, d, x), r, q);
-        bad += __float_as_uint(fast) != __float_as_uint(x / d);
-    }
-    for (int off = 32; off > 0; off >>= 1) bad += __shfl_down(bad, off, 64);
-    if ((threadIdx.x & 63) == 0 && bad != 0) atomicAdd(mismatches, bad);
-}
-
 // One 16x16 output tile per block, radius 1..8.
 // kTolerant = false: denoise.comp:64-80 operation for operation (IEEE division by sigma_range_2, the polynomial vx_exp of
 // include/vxrt_detmath.h): bit-identical to the oracle; ~85 instructions per tap, of which the division and the exponential are 40.
@@ -281,9 +254,8 @@ __global__ __launch_bounds__(256) void denoise_kernel(const DenoiseArgs a) {
                 sum = mk3(__builtin_fmaf(wc.x, factor, sum.x), __builtin_fmaf(wc.y, factor, sum.y), __builtin_fmaf(wc.z, factor, sum.z));
                 continue;
             }
-            const float range = ((dot3(color_delta, color_delta) + 1e4f * dot3(normal_delta, normal_delta)) + 1e4f * (bd * bd)) +
-                                1e4f * material_delta;
-            float factor_range = divide_by_constant(range, a.sigma_range_2, a.range_reciprocal, a.fast_division != 0);
+            float factor_range = (((dot3(color_delta, color_delta) + 1e4f * dot3(normal_delta, normal_delta)) + 1e4f * (bd * bd)) +
+                                  1e4f * material_delta) / a.sigma_range_2;
             float arg = -factor_range - rowW[dx];
             // exp(arg) is exactly +0 below -87.3 (vx_exp): such a tap adds +0 to the weight sum and colour * 0 to the
             // colour sum — nothing, unless the colour is inf/NaN (then 0 * colour = NaN must still poison the sum)
@@ -376,11 +348,6 @@ hipError_t launch_denoise(const DenoiseArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(denoise_kernel<true>, grid, dim3(256), lds, s, a);
     else
         hipLaunchKernelGGL(denoise_kernel<false>, grid, dim3(256), lds, s, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_verify_division(float d, float r, unsigned* mismatches, hipStream_t s) {
-    hipLaunchKernelGGL(verify_division_kernel, dim3(8192), dim3(256), 0, s, d, r, mismatches);
     return hipGetLastError();
 }
 

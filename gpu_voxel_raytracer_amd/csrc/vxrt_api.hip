@@ -150,10 +150,6 @@ struct vxrt_ctx {
     uint64_t queue_overflow_paths = 0;  // paths that found their shard full and stayed in the head kernel
     uint64_t queue_bytes = 0;
     int denoise_mode = 0;               // VXRT_OPT_DENOISE_MODE: 0 exact (bit-identical to the oracle), 1 tolerant (post.hip)
-    // exact denoise: the divisor sigma_range_2 for which the multiply-add form of the division was last checked against the
-    // hardware's over every dividend (post.hip divide_by_constant), and what the check said
-    uint32_t div_checked_bits = 0xffffffffu;
-    bool div_fast = false;
     // 0 = monolithic trace_kernel (all bounces in one launch; default), 2 = wavefront launches per path segment,
     // 3 = ray queues: shade / trace launches with per-lane ray refill
     int trace_variant = 0;
@@ -1059,24 +1055,6 @@ int post_stages(vxrt_ctx* c, uint32_t flags, bool timed) {
         a.sigma_range_2 = 2.0f * (c->denoise.sigma_range * c->denoise.sigma_range);
         a.albedo_factor = c->denoise.albedo_factor;
         a.mode = c->denoise_mode;
-        a.range_reciprocal = 1.0f / a.sigma_range_2;
-        a.fast_division = 0;
-        if (a.radius > 0 && a.mode == 0 && c->band.local_rows > 0 && getenv("VXRT_DENOISE_DIV") == nullptr) {
-            uint32_t bits;
-            memcpy(&bits, &a.sigma_range_2, 4);
-            if (bits != c->div_checked_bits) {   // a new sigma_range: compare the two divisions over every dividend, once
-                ScratchBuffer flag;
-                HIP_TRY(flag.alloc(sizeof(unsigned)));
-                HIP_TRY(hipMemsetAsync(flag.p, 0, sizeof(unsigned), c->stream));
-                HIP_TRY(launch_verify_division(a.sigma_range_2, a.range_reciprocal, flag.as<unsigned>(), c->stream));
-                unsigned bad = 1;
-                HIP_TRY(hipMemcpyAsync(&bad, flag.p, sizeof bad, hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(hipStreamSynchronize(c->stream));
-                c->div_checked_bits = bits;
-                c->div_fast = bad == 0 && a.sigma_range_2 > 0.0f && a.range_reciprocal > 0.0f && a.range_reciprocal < 3.0e38f;
-            }
-            a.fast_division = c->div_fast ? 1 : 0;
-        }
         if (c->band.local_rows > 0) {
             EventPair p;
             if (timed) { p = take_pair(c, 2); HIP_TRY(hipEventRecord(p.a, c->stream)); }
@@ -1696,19 +1674,6 @@ int vxrt_debug_path_log(vxrt_ctx* c, int32_t x, int32_t y, float* log, int32_t* 
     HIP_TRY(hipMemcpy(out.data(), d_log, out.size() * sizeof(float), hipMemcpyDeviceToHost));
     *casts = int32_t(out[12 * 32]);
     memcpy(log, out.data(), size_t(*casts) * 12 * sizeof(float));
-    return VXRT_OK;
-} VXRT_CATCH
-
-// Test hook: how many binary32 dividends in [0, 2^100) the multiply-add form of x / d gets wrong for this d (0: the exact denoiser uses it)
-int vxrt_debug_division_check(int32_t device, float d, uint32_t* mismatches) try {
-    if (!mismatches) { set_error("null argument"); return VXRT_E_INVALID; }
-    HIP_TRY(hipSetDevice(device));
-    ScratchBuffer flag;
-    HIP_TRY(flag.alloc(sizeof(unsigned)));
-    HIP_TRY(hipMemset(flag.p, 0, sizeof(unsigned)));
-    HIP_TRY(launch_verify_division(d, 1.0f / d, flag.as<unsigned>(), nullptr));
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(mismatches, flag.p, sizeof(unsigned), hipMemcpyDeviceToHost));
     return VXRT_OK;
 } VXRT_CATCH
 

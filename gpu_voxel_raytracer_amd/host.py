@@ -270,13 +270,6 @@ def menger_voxels(level, mrgb=(0, 0xb0, 0xd0, 0x60), clip=0, emissive_period=0):
     return pos, out
 
 
-def division_check(d, device=0):
-    """Test hook (vxrt_debug_division_check): dividends in [0, 2^100) for which the exact denoiser's multiply-add division by `d` is wrong."""
-    n = C.c_uint32(0)
-    _check(lib().vxrt_debug_division_check(C.c_int32(device), C.c_float(d), C.byref(n)), "vxrt_debug_division_check")
-    return int(n.value)
-
-
 def detmath_probe(fn, x, y=None, device=0):
     names = {"sin": 0, "cos": 1, "exp": 2, "log": 3, "pow": 4, "sqrt": 5, "div": 6, "tan": 7, "chain": 8, "hemi_y": 9, "hemi_z": 10, "mul": 11, "sub": 12, "flip": 13, "min": 14, "max": 15, "max0": 16, "sign": 17, "clamp": 18, "min0": 19}
     x = np.ascontiguousarray(x, np.float32)

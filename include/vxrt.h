@@ -233,9 +233,6 @@ int vxrt_halo_import(vxrt_ctx* ctx, const void* dev_from_prev, const void* dev_f
 
 /* ---- host-side scene preparation, callable without a GPU (src/vox.rs, src/context.rs:710-834,
  *      913-933, src/camera.rs).  Counts are returned through *n; nothing is written past cap. ------ */
-/* Test hook: for how many binary32 dividends in [0, 2^100) the exact denoiser's multiply-add form of x / d differs from the IEEE
- * quotient for this divisor d (the library runs the same check before it uses that form: csrc/post.hip divide_by_constant). */
-int vxrt_debug_division_check(int32_t device, float d, uint32_t* mismatches);
 /* Test hook: the scene as the device holds it right now (8-byte records, 2 words each; leaf words).  Null arrays: sizes only. */
 int vxrt_debug_read_scene(vxrt_ctx* ctx, uint32_t* svo, size_t svo_cap, size_t* n_svo, int32_t* leaves, size_t leaf_cap, size_t* n_leaves);
 /* The device scene formats for a voxel list (csrc/kernels.h: SvoRecord = 2 words, WideRec = 4 words per record; leaf words as in

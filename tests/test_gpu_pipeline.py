@@ -444,40 +444,3 @@ def test_tolerant_denoise_mode_at_4k_radius_8(O, H, scenes, noise):
     assert rmse <= 1e-3                      # BASELINE.json north_star: per-pixel RMSE <= 1e-3
     assert rmse <= 2e-5 and worst <= 2e-3 and rel <= 1e-3
     assert (tolerant[..., 3] == 1).all() and np.isfinite(tolerant).all()
-
-
-def test_exact_denoise_division_by_the_constant_is_verified_not_assumed(O, H, scenes, noise, monkeypatch):
-    """denoise.comp:77 divides by sigma_range_2, the same divisor for every tap.  The exact kernel computes that quotient as two
-    multiply-adds around the reciprocal ONLY after a device pass has compared it with the hardware's IEEE division for every
-    binary32 dividend in [0, 2^100) — for the divisor in use (csrc/post.hip divide_by_constant).  The check itself: no mismatch for
-    the default 2 * 1.5^2 and other ordinary divisors; divisors exist for which it finds mismatches (then the kernel keeps the
-    hardware division); and with the shortcut switched off (VXRT_DENOISE_DIV=0) the frames are the same bits."""
-    from gpu_voxel_raytracer_amd import ALL, DENOISED, Camera, Context
-    assert H.division_check(4.5) == 0 and H.division_check(2.0) == 0 and H.division_check(0.02) == 0
-    hard = [float(np.uint32(b).view(np.float32)) for b in (0x3fffffff, 0x407fffff, 0x3f7fffff, 0x40ffffff)]   # significands of all ones
-    counts = [H.division_check(d) for d in hard]
-    print("division check, all-ones significands:", dict(zip(hard, counts)))
-    pos, mrgb, size = scenes.load_scene("castle")
-    cam = scenes.close_camera(size)
-    w, h = 200, 120
-    for sigma_range in (1.5, 0.37, 3.0):
-        frames = []
-        for off in (False, True):
-            if off:
-                monkeypatch.setenv("VXRT_DENOISE_DIV", "0")
-            else:
-                monkeypatch.delenv("VXRT_DENOISE_DIV", raising=False)
-            with Context(w, h, max_bounces=3, noise=noise) as ctx:
-                ctx.recreate_octree(pos, mrgb)
-                ctx.camera = Camera(*cam)
-                ctx.denoise_uniforms.radius = 4
-                ctx.denoise_uniforms.sigma_range = sigma_range
-                ctx.render(ALL)
-                ctx.render(ALL)
-                frames.append((ctx.read(DENOISED), ctx.read(3), ctx.read(1), ctx.read(2)))
-        assert_bits_equal(frames[0][0], frames[1][0], f"denoised, sigma_range {sigma_range}: shortcut vs hardware division")
-        u = O.Uniforms.default()
-        u.set_camera(cam[0], O.camera_axis_scaled(cam[0], cam[1], cam[2], w, h))
-        du = O.Denoise.default()
-        du.radius, du.sigma_range = 4, sigma_range
-        assert_bits_equal(frames[0][0], O.denoise(frames[0][1], frames[0][2], frames[0][3], u.camera16(), du), f"denoised vs oracle, sigma_range {sigma_range}")
