@@ -302,7 +302,7 @@ def trace_bench(args):
                        "block_ms": {"min": round(min(times) * 1e3, 4), "median": round(elapsed * 1e3, 4), "max": round(max(times) * 1e3, 4)},
                        "timed_region_s_total": round(sum(times), 3),
                        "note": "ms_per_step is reciprocal THROUGHPUT (frames of a camera at rest, several per launch, launches "
-                               "overlapping); the latency of one vxrt_render call is ~0.3 ms (DESIGN.md §7)"},
+                               "overlapping); the latency of one vxrt_render(TRACE) call, one frame at a time, is 0.27 ms (DESIGN.md §7)"},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

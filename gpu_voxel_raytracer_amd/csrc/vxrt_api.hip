@@ -923,7 +923,12 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
         a.tail_zero = nullptr;
         a.tail_from = 0;
         const size_t scene_bytes = c->svo_count * sizeof(SvoRecord) + c->leaf_count * sizeof(int32_t);
-        const int variant = (c->auto_tracer && scene_bytes > (size_t(256) << 20)) ? 0 : c->trace_variant;
+        // tracer 0 (auto) takes the all-in-one kernel (a) for scenes beyond the Infinity Cache (see auto_tracer) and (b) for ONE frame at
+        // a time on one stream — the latency case of a render loop that calls vxrt_render per frame: the head + tail pair waits twice
+        // for a longest wave (0.357 ms per 1080p bench frame), the single kernel once (0.267 ms); with frames in flight or several
+        // frames per launch the pair wins (0.123 ms per frame at 16 x 2)
+        const bool one_at_a_time = g == 1 && c->inflight == 1;
+        const int variant = (c->auto_tracer && (scene_bytes > (size_t(256) << 20) || one_at_a_time)) ? 0 : c->trace_variant;
         if (variant == 0 || variant >= 4) {
             if (variant >= 4) {
                 // count sets rotate as in launch_trace_wavefront: launch J reads set J%3, writes (J+1)%3, clears (J+2)%3
