@@ -196,6 +196,8 @@ class Context {
         check(vxrt_set_denoise(ctx_, &denoise_uniforms), "vxrt_set_denoise");
         check(vxrt_render_spp(ctx_, flags, spp), "vxrt_render_spp");
     }
+    // run-time options (vxrt.h: VXRT_OPT_DENOISE_MODE, VXRT_OPT_TAIL_CAPACITY, VXRT_OPT_SCENE_FORMAT)
+    void set_option(vxrt_option option, uint32_t value) { check(vxrt_set_option(ctx_, option, value), "vxrt_set_option"); }
     void sync() { check(vxrt_sync(ctx_), "vxrt_sync"); }
     std::vector<float> read(vxrt_image which) {
         uint32_t rows = 0;
