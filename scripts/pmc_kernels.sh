@@ -4,13 +4,13 @@ tag=$1; shift
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp
-env "$@" rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS --output-format csv -d $R/gpurun_out/pk_$tag -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --inflight 1 ${BENCH_ARGS} > /dev/null 2>&1
+env "$@" rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS --output-format csv -d $R/gpurun_out/pk_$tag -- python3 $R/bench.py --steps 6 --warmup 2 --blocks 3 --no-cpu-baseline --inflight 1 ${BENCH_ARGS} > /dev/null 2>&1
 cd $R
 python3 - <<PY
 import csv,glob,collections,re
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(glob.glob("gpurun_out/pk_$tag/*/*counter_collection.csv")[0])):
-    m=re.search(r"(primary_kernel|trace_kernel|bounce_kernel|shade_kernel<\w+>|trace_rays_kernel)",r["Kernel_Name"])
+    m=re.search(r"(primary_kernel|trace_kernel|bounce_kernel|path_kernel|shade_kernel<\w+>|trace_rays_kernel)",r["Kernel_Name"])
     if not m: continue
     agg[m[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,c in agg.items():
