@@ -317,15 +317,20 @@ def trace_bench(args):
 
 
 def pipeline_bench(args):
-    """BASELINE configs[3]: vox/castle.vox at 3840x2160, 4 spp, screen bands over the ranks, temporal + denoise (r = 8) with the
-    halo exchange: per displayed frame  render_spp(TRACE | TEMPORAL, 4) -> vxrt_halo_export -> batch_isend_irecv (RCCL) ->
-    vxrt_halo_import -> DENOISE.  One step = one displayed frame; the exchange is timed apart (host clock around a synchronised
-    exchange) and the halo bytes per rank are reported."""
+    """BASELINE configs[3]: vox/castle.vox at 3840x2160, 4 spp, 8 bounces, screen bands over the ranks, temporal + denoise (r = 8) with
+    the halo exchange, as gpu_voxel_raytracer_amd/distributed.py runs it: per displayed frame
+
+        render_spp(TRACE | TEMPORAL, 4) -> halo pack -> [two sends + two receives] -> DENOISE_INTERIOR -> halo unpack -> DENOISE_EDGE
+
+    with band_rows >= 8 r (64 rows at r = 8: the halo is a quarter of a rank's rows) and everything ordered by events.  One step = one
+    displayed frame.  Reported apart: halo bytes per rank and frame, the pack / unpack kernel times (HIP events), and — from a second,
+    synchronised pass in which nothing overlaps — the time of the exchange alone and the frame time without overlap."""
     world, rank, device, dist, torch, backend = init_dist()
     args.gpus = world
     red_dev = "cuda" if backend == "nccl" else "cpu"
     from gpu_voxel_raytracer_amd import DENOISE, TEMPORAL, TIMED, TRACE, Camera, Context, distributed, scenes
-    w, h, bounces, spp, radius, band = 3840, 2160, 8, 4, args.radius, 16
+    w, h, bounces, spp, radius = 3840, 2160, 8, 4, args.radius
+    band = args.band_rows or distributed.band_rows_for(radius)
     pos, mrgb, size = scenes.load_scene("castle")
     cam = scenes.close_camera(size)
     ctx = Context(w, h, device=device, max_bounces=bounces, rank=rank, nranks=world, band_rows=band, frames_in_flight=1,
@@ -341,14 +346,17 @@ def pipeline_bench(args):
                                         comm_device=None if backend == "nccl" else "cpu")
     xchg = [0.0]
 
-    def frame():
+    def frame(overlap=True):
         ctx.render_spp(TRACE | TEMPORAL | TIMED, spp)
-        if halo is not None and radius > 0:
+        if world > 1 and not overlap:      # diagnostic: every part waits for the one before, the exchange on the host clock
             ctx.sync()
             t0 = time.perf_counter()
             halo.exchange()
+            ctx.sync()
             xchg[0] += time.perf_counter() - t0
-        ctx.render_stage(DENOISE | TIMED)
+            ctx.render_stage(DENOISE | TIMED)
+        else:
+            distributed.finish_frame(ctx, world, radius, halo, overlap=True, extra_flags=TIMED)
 
     def barrier():
         ctx.sync()
@@ -357,22 +365,28 @@ def pipeline_bench(args):
             if backend == "nccl":
                 torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        frame()
-    barrier()
-    ctx.reset_stats()
-    xchg[0] = 0.0
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        frame()
-    ctx.sync()
-    if dist is not None and backend == "nccl":
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    st = ctx.stats()
-    elapsed, x = reduce_max(dist, torch, red_dev, [elapsed, xchg[0]])
-    rays = reduce_sum(dist, torch, red_dev, [st.rays])[0]
+    def timed_block(overlap):
+        for _ in range(args.warmup):
+            frame(overlap)
+        barrier()
+        ctx.reset_stats()
+        xchg[0] = 0.0
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            frame(overlap)
+        ctx.sync()
+        if dist is not None and backend == "nccl":
+            torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        st = ctx.stats()
+        elapsed, x = reduce_max(dist, torch, red_dev, [elapsed, xchg[0]])
+        rays = reduce_sum(dist, torch, red_dev, [st.rays])[0]
+        return elapsed, x, rays, st
+
+    elapsed, _, rays, st = timed_block(True)
+    sync_elapsed, x, _, sync_st = timed_block(False) if world > 1 else (elapsed, 0.0, rays, st)
+    info = ctx.halo_info()
     if rank == 0:
         px = w * h
         alg = (48 * spp + 16 * spp + 16 + 80 + 64) * px     # spp trace frames + their average + temporal + denoise
@@ -381,12 +395,22 @@ def pipeline_bench(args):
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"vox/castle.vox {w}x{h}, {spp} spp, {bounces} bounces, temporal + denoise r={radius} "
                                       f"(BASELINE configs[3]); one step = one displayed frame",
-                          "parallelism": f"screen bands x{world} ({band}-row interleave, scene replicated), denoise halo over "
-                                         f"{'RCCL send/recv' if backend == 'nccl' else backend}"},
-               "halo": {"bytes_per_rank_per_frame": 2 * ctx.halo_bytes() if world > 1 else 0,
-                        "exchange_ms_per_frame": round(x / args.steps * 1e3, 4), "share_of_frame": round(x / elapsed, 4)},
+                          "parallelism": f"screen bands x{world} ({band}-row interleave, scene replicated), halo over "
+                                         f"{'RCCL send/recv' if backend == 'nccl' else backend + ' (staged through pinned host memory: a rehearsal)'}"
+                                         f", overlapped with the denoise of the interior tiles"},
+               "halo": {"band_rows": band, "rows": int(info.rows), "bytes_per_pixel": int(info.bytes_per_pixel),
+                        "bytes_per_rank_per_frame": 2 * int(info.message_bytes) if world > 1 else 0,
+                        "interior_tile_rows": int(info.interior_tile_rows), "edge_tile_rows": int(info.edge_tile_rows),
+                        "pack_ms": round(st.halo_pack_ms / max(st.halo_exchanges, 1), 5),
+                        "unpack_ms": round(st.halo_unpack_ms / max(st.halo_exchanges, 1), 5),
+                        "exchange_ms_synchronous": round(x / args.steps * 1e3, 4),
+                        "ms_per_step_synchronous": round(sync_elapsed / args.steps * 1e3, 4),
+                        "note": "pack_ms / unpack_ms: HIP events around the one pack / unpack kernel of an exchange, this rank.  "
+                                "exchange_ms_synchronous: host clock around pack + messages + unpack in a second pass where every part "
+                                "waits for the one before (ms_per_step_synchronous); ms_per_step is the overlapped loop."},
                "stage_ms_per_frame": {"trace": round(st.trace_ms / args.steps, 4), "temporal": round(st.temporal_ms / args.steps, 4),
-                                      "denoise": round(st.denoise_ms / args.steps, 4)},
+                                      "denoise": round(st.denoise_ms / args.steps, 4),
+                                      "denoise_synchronous_pass": round(sync_st.denoise_ms / args.steps, 4)},
                "roofline": {"bound": "valu", "nominal_bound": "hbm", "kernel": "whole frame loop", "achieved": round(alg * args.steps / elapsed / 1e9, 2),
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5), "traffic": None}}
         print(json.dumps(out), flush=True)
@@ -406,6 +430,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", action="store_true", help="time the whole frame loop with the denoise halo exchange (BASELINE configs[3])")
     ap.add_argument("--radius", type=int, default=8, help="--pipeline: denoise radius")
+    ap.add_argument("--band-rows", type=int, default=0, help="--pipeline: rows per band (default: >= 8 radius, a multiple of 16)")
     ap.add_argument("--view", default="bench", choices=["bench", "close", "away"])
     ap.add_argument("--bounces", type=int, default=BOUNCES, help="diagnostic only; the benchmark is 4")
     ap.add_argument("--inflight", type=int, default=0,

@@ -1,13 +1,19 @@
 """Builds libvxrt.so (gfx950) in-tree with hipcc.  No JIT cache: the .so travels with the repo snapshot."""
 import os
 import subprocess
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvxrt.so")
-SOURCES = ["vxrt_api.hip", "trace.hip", "trace_wavefront.hip", "trace_tail.hip", "trace_paths.hip", "post.hip", "noise.hip", "scene_device.hip", "scene_host.cpp", "scene_procedural.cpp",
+# the default library: tracers 1 (all-in-one kernel) and 4 (head + compacted tail) over the 8-byte scene records
+SOURCES = ["api_context.hip", "api_scene.hip", "api_trace.hip", "api_frame.hip", "api_halo.hip", "api_host.cpp", "api_debug.hip",
+           "trace.hip", "trace_tail.hip", "post.hip", "halo.hip", "noise.hip", "scene_device.hip", "scene_host.cpp", "scene_procedural.cpp",
            "noise_zip.cpp", "vox_scene.cpp"]
-HEADERS = ["kernels.h", "trace_common.h", "walk_wide.h", "scene_host.h", "vx_vec.h", os.path.join("..", "..", "include", "vxrt.h"),
+# -DVXRT_VARIANTS=1 (scripts/test_variants.sh): the schedules and the scene format that measured slower and are kept for comparison —
+# tracers 2 (wavefront), 3 (ray queues), 5 (per-lane path refill) and the wide records (two tree levels per 16-byte record)
+VARIANT_SOURCES = ["trace_wavefront.hip", "trace_paths.hip"]
+HEADERS = ["ctx.h", "halo_view.h", "kernels.h", "trace_common.h", "walk_wide.h", "scene_host.h", "vx_vec.h", os.path.join("..", "..", "include", "vxrt.h"),
            os.path.join("..", "..", "include", "vxrt_detmath.h"),
            os.path.join("..", "..", "include", "vxrt_bluenoise.h")]
 
@@ -19,43 +25,106 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
          "-Wno-unused-parameter"]
 
 
-STAMP = LIB + ".srchash"   # what the library was built from (travels with it to the GPU box; modification times do not survive the trip)
+VARIANTS_LIB = os.path.join(HERE, "libvxrt_variants.so")   # the -DVXRT_VARIANTS=1 build (never the product; VXRT_LIB points tests at it)
+OBJ_DIR = os.path.join(HERE, "_obj")                         # per-source objects, keyed by content (not tracked, does not travel)
 
 
-def source_hash(extra_flags=()):
-    """sha256 over the sources, headers and flags that make libvxrt.so."""
+def _stamp(lib):
+    """What a library was built from (travels with it to the GPU box; modification times do not survive the trip)."""
+    return lib + ".srchash"
+
+
+STAMP = _stamp(LIB)
+
+
+def _sources(variants):
+    return SOURCES + (VARIANT_SOURCES if variants else [])
+
+
+def _flags(extra_flags, variants):
+    return FLAGS + (["-DVXRT_VARIANTS=1"] if variants else []) + list(extra_flags)
+
+
+def _headers_digest():
     import hashlib
     h = hashlib.sha256()
-    for name in sorted(SOURCES + HEADERS):
+    for name in sorted(HEADERS):
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read() + b"\0")
-    h.update(" ".join(FLAGS + list(extra_flags)).encode())
     return h.hexdigest()
 
 
-def needs_build(extra_flags=()):
-    """True when libvxrt.so is missing or was built from other sources / flags than the tree holds now (by content)."""
-    if not os.path.exists(LIB) or not os.path.exists(STAMP):
+def source_hash(extra_flags=(), variants=False):
+    """sha256 over the sources, headers and flags that make the library."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(_headers_digest().encode())
+    for name in sorted(_sources(variants)):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read() + b"\0")
+    h.update(" ".join(_flags(extra_flags, variants)).encode())
+    return h.hexdigest()
+
+
+def needs_build(extra_flags=(), variants=False, out=None):
+    """True when the library is missing or was built from other sources / flags than the tree holds now (by content)."""
+    lib = out or (VARIANTS_LIB if variants else LIB)
+    if not os.path.exists(lib) or not os.path.exists(_stamp(lib)):
         return True
     try:
-        return open(STAMP).read().strip() != source_hash(extra_flags)
+        return open(_stamp(lib)).read().strip() != source_hash(extra_flags, variants)
     except OSError:
         return True
 
 
-def build(force=False, verbose=False, extra_flags=()):
+def _compile_one(job):
+    import hashlib
+    hipcc, flags, name, hdr = job
+    src = os.path.join(CSRC, name)
+    with open(src, "rb") as f:
+        key = hashlib.sha256(hdr.encode() + b"\0" + name.encode() + b"\0" + f.read() + b"\0" + " ".join(flags).encode()).hexdigest()[:24]
+    obj = os.path.join(OBJ_DIR, f"{os.path.splitext(name)[0]}.{key}.o")
+    if not os.path.exists(obj):
+        tmp = f"{obj}.{os.getpid()}.tmp"
+        subprocess.check_call([hipcc] + [f for f in flags if f != "-shared"] + ["-x", "hip", "-c", src, "-o", tmp])
+        os.replace(tmp, obj)
+    return obj
+
+
+def build(force=False, verbose=False, extra_flags=(), variants=False, out=None):
+    """Compiles every source to an object (in parallel; objects are kept by content hash, so only what changed is recompiled) and
+    links the library.  Ranks that start together (torchrun) serialise on a lock file and re-check after taking it; the library
+    is written under a per-process name and renamed into place."""
+    import fcntl
+    from concurrent.futures import ThreadPoolExecutor
     extra_flags = list(extra_flags) + os.environ.get("VXRT_HIPCC_FLAGS", "").split()
-    if not force and not needs_build(extra_flags):
-        return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + extra_flags + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp", "-lz"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)      # other processes keep the library they mapped; new ones see a whole file
-    with open(STAMP, "w") as f:
-        f.write(source_hash(extra_flags) + "\n")
-    return LIB
+    lib = out or (VARIANTS_LIB if variants else LIB)     # out: an A/B build under another name (scripts/ab_build.sh; VXRT_LIB selects it)
+    if not force and not needs_build(extra_flags, variants, out):
+        return lib
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    with open(os.path.join(OBJ_DIR, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not needs_build(extra_flags, variants, out):   # another process built it while this one waited
+            return lib
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        flags = _flags(extra_flags, variants)
+        hdr = _headers_digest()
+        jobs = [(hipcc, flags, name, hdr) for name in _sources(variants)]
+        if verbose:
+            print(f"{hipcc} {' '.join(flags)} -c <{len(jobs)} sources> ; link -> {lib}")
+        with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+            objs = list(pool.map(_compile_one, jobs))
+        keep = set(objs)
+        for f in os.listdir(OBJ_DIR):   # objects of older source versions
+            path = os.path.join(OBJ_DIR, f)
+            if f.endswith(".o") and path not in keep and (time.time() - os.path.getmtime(path)) > 6 * 3600:
+                os.remove(path)
+        tmp = f"{lib}.{os.getpid()}.tmp"
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp, "-lz"])
+        os.replace(tmp, lib)      # other processes keep the library they mapped; new ones see a whole file
+        with open(_stamp(lib), "w") as f:
+            f.write(source_hash(extra_flags, variants) + "\n")
+    return lib
 
 
 TOOL = os.path.join(HERE, "vxrt_render")

@@ -1,0 +1,154 @@
+// api_debug.hip — test hooks and diagnostics of libvxrt (include/vxrt.h "Test hook" entries) and the blue-noise generator's entry point.
+#include "../../include/vxrt_bluenoise.h"
+#include "ctx.h"
+
+extern "C" {
+
+// Diagnostics: shader-clock duration of every 16x16 tile in the last traced frame (monolithic kernel).
+int vxrt_debug_tile_costs(vxrt_ctx* c, uint32_t* out, size_t n) try {
+    if (!valid_ctx(c) || !out) { set_error("null argument"); return VXRT_E_INVALID; }
+    // reported per 16x16 pixels whatever the kernel's own tile is: the maximum over the kernel tiles inside
+    const size_t out_x = size_t((c->band.width + 15) / 16), out_y = size_t((c->band.local_rows + 15) / 16);
+    if (n != out_x * out_y || c->schedules.empty()) { set_error("tile count mismatch"); return VXRT_E_INVALID; }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = sync_all(c)) return rc;
+    int tw = 16, th = 16;
+    trace_tile_dims(&tw, &th);
+    const size_t kx = size_t((c->band.width + tw - 1) / tw), ky = size_t((c->band.local_rows + th - 1) / th);
+    std::vector<uint32_t> raw(kx * ky);
+    HIP_TRY(hipMemcpy(raw.data(), c->schedules[size_t(c->last_schedule)].last_cost, raw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) out[i] = 0;
+    for (size_t y = 0; y < ky; y++)
+        for (size_t x = 0; x < kx; x++) {
+            uint32_t& o = out[(y * size_t(th) / 16) * out_x + x * size_t(tw) / 16];
+            o = raw[y * kx + x] > o ? raw[y * kx + x] : o;
+        }
+    return VXRT_OK;
+} VXRT_CATCH
+
+// ---- blue noise (include/vxrt_bluenoise.h, csrc/noise.hip, csrc/noise_zip.cpp) ----------------------------------
+int vxrt_blue_noise(int32_t device, uint32_t seed, uint32_t size, uint32_t first_layer, uint32_t layers, float* out) try {
+    if (!out || layers == 0) { set_error("null argument"); return VXRT_E_INVALID; }
+    if (size < 16 || size > VXBN_MAX_SIZE || (size & (size - 1)) != 0) { set_error("blue-noise size must be a power of two in 16..128"); return VXRT_E_INVALID; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return hip_fail(e == hipSuccess ? hipErrorNoDevice : e, "hipGetDeviceCount");
+    if (device < 0 || device >= ndev) { set_error("device ordinal out of range"); return VXRT_E_INVALID; }
+    HIP_TRY(hipSetDevice(device));
+    const size_t bytes = size_t(layers) * size * size * sizeof(float);
+    ScratchBuffer b;
+    HIP_TRY(b.alloc(bytes));
+    HIP_TRY(launch_blue_noise(b.as<float>(), seed, first_layer, layers, int(size), nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, b.as<float>(), bytes, hipMemcpyDeviceToHost));
+    return VXRT_OK;
+} VXRT_CATCH
+
+int vxrt_noise_zip_read(const char* path, float* out, size_t cap_floats, uint32_t* size, uint32_t* layers) try {
+    if (!path || !size || !layers) { set_error("null argument"); return VXRT_E_INVALID; }
+    std::vector<float> px;
+    if (int rc = noise_zip_read(path, &px, size, layers)) return rc;
+    if (out) {
+        if (cap_floats < px.size()) { set_error("buffer too small for the archive's images"); return VXRT_E_INVALID; }
+        memcpy(out, px.data(), px.size() * sizeof(float));
+    }
+    return VXRT_OK;
+} VXRT_CATCH
+
+int vxrt_noise_zip_write(const char* path, const float* table, uint32_t size, uint32_t layers) try {
+    if (!path || !table) { set_error("null argument"); return VXRT_E_INVALID; }
+    return noise_zip_write(path, table, size, layers);
+} VXRT_CATCH
+
+int vxrt_set_noise(vxrt_ctx* c, const float* table) try {
+    if (!c || !table) { set_error("null argument"); return VXRT_E_INVALID; }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = vxrt_sync(c)) return rc;
+    HIP_TRY(hipMemcpy(c->d_noise, table, kNoiseCount * sizeof(float), hipMemcpyHostToDevice));
+    return VXRT_OK;
+} VXRT_CATCH
+
+// Test hook: cast_bounded_ray (voxels.comp:134-247) as the kernels implement it, for caller-given rays of the current scene.
+int vxrt_debug_cast_rays(vxrt_ctx* c, const float* origins, const float* dirs, size_t n, uint8_t* hit, float* time, int32_t* node, float* normal) try {
+    if (!valid_ctx(c) || !origins || !dirs || !hit || !time || !node || !normal) { set_error("null argument"); return VXRT_E_INVALID; }
+    if (!c->has_scene) { set_error("no scene set"); return VXRT_E_NOSCENE; }
+    if (n == 0) return VXRT_OK;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = vxrt_sync(c)) return rc;
+    ScratchBuffer b_o, b_d, b_out;
+    HIP_TRY(b_o.alloc(n * 12));
+    HIP_TRY(b_d.alloc(n * 12));
+    HIP_TRY(b_out.alloc(n * 32));
+    float *d_o = b_o.as<float>(), *d_d = b_d.as<float>(), *d_out = b_out.as<float>();
+    HIP_TRY(hipMemcpy(d_o, origins, n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_d, dirs, n * 12, hipMemcpyHostToDevice));
+    TraceArgs a{};
+    a.svo = c->d_svo; a.leaves = c->d_leaves;
+    a.root_rec = c->root_rec;
+    a.wide = c->d_wide;
+    a.wide_root = c->wide_root;
+    a.node_levels = int(c->depth) + 1;
+    memcpy(a.root_center, c->root_center, sizeof a.root_center);
+    a.root_size = c->root_size;
+    a.stack_levels = c->depth < 1 ? 1 : int(c->depth);
+    HIP_TRY(launch_cast_probe(a, use_wide(c), d_o, d_d, d_out, unsigned(n), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<float> out(n * 8);
+    HIP_TRY(hipMemcpy(out.data(), d_out, n * 32, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) {
+        hit[i] = out[8 * i] != 0.0f;
+        time[i] = out[8 * i + 1];
+        memcpy(&node[i], &out[8 * i + 2], 4);
+        normal[3 * i] = out[8 * i + 3]; normal[3 * i + 1] = out[8 * i + 4]; normal[3 * i + 2] = out[8 * i + 5];
+    }
+    return VXRT_OK;
+} VXRT_CATCH
+
+// Test hook: the path of ONE pixel of the next frame (frame_number + 1, the camera as set), cast by cast, as the kernels compute it
+// (cast_ray and shade_hit of trace_common.h, in voxels.comp's order).  log: 12 floats per cast = origin, direction, hit flag, time,
+// bits(leaf word), normal; at most 32 casts.  Nothing is rendered and no context state changes, apart from the camera basis.
+int vxrt_debug_path_log(vxrt_ctx* c, int32_t x, int32_t y, float* log, int32_t* casts) try {
+    if (!valid_ctx(c) || !log || !casts) { set_error("null argument"); return VXRT_E_INVALID; }
+    if (!c->has_scene) { set_error("no scene set"); return VXRT_E_NOSCENE; }
+    if (x < 0 || y < 0 || x >= int(c->cfg.width) || y >= int(c->cfg.height)) { set_error("pixel outside the frame"); return VXRT_E_INVALID; }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = vxrt_sync(c)) return rc;
+    const Cam keep_cam = c->cam, keep_old = c->old_cam;
+    const vxrt_uniforms keep_u = c->uniforms;
+    update_bindings(c);
+    TraceArgs a{};
+    frame_constants(c, a);
+    a.frame_number = c->uniforms.frame_number;
+    a.cam = c->cam;
+    a.batch = 1;
+    c->cam = keep_cam; c->old_cam = keep_old; c->uniforms = keep_u;
+    ScratchBuffer b_log;
+    HIP_TRY(b_log.alloc((12 * 32 + 1) * sizeof(float)));
+    float* d_log = b_log.as<float>();
+    HIP_TRY(launch_path_log(a, use_wide(c), x, y, d_log, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<float> out(12 * 32 + 1);
+    HIP_TRY(hipMemcpy(out.data(), d_log, out.size() * sizeof(float), hipMemcpyDeviceToHost));
+    *casts = int32_t(out[12 * 32]);
+    memcpy(log, out.data(), size_t(*casts) * 12 * sizeof(float));
+    return VXRT_OK;
+} VXRT_CATCH
+
+// device-vs-host bit equality probe of include/vxrt_detmath.h (test hook; host arrays in and out)
+int vxrt_detmath_probe(int32_t device, int32_t fn, const float* x, const float* y, float* out, size_t n) try {
+    if (!x || !y || !out) { set_error("null argument"); return VXRT_E_INVALID; }
+    HIP_TRY(hipSetDevice(device));
+    ScratchBuffer bx, by, bout;
+    HIP_TRY(bx.alloc(n * 4));
+    HIP_TRY(by.alloc(n * 4));
+    HIP_TRY(bout.alloc(n * 4));
+    float *dx = bx.as<float>(), *dy = by.as<float>(), *dout = bout.as<float>();
+    HIP_TRY(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(launch_detmath_probe(fn, dx, dy, dout, n, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+    return VXRT_OK;
+} VXRT_CATCH
+
+}  // extern "C"

@@ -1,0 +1,234 @@
+// api_trace.hip — scheduling of the trace stage of libvxrt: which ring slots, stream, tile order and tail queue a launch of
+// trace_kernel (+ bounce_kernel) gets, for 1..32 consecutive frames per launch and several launches in flight.
+#include <cmath>
+
+#include "ctx.h"
+#include "vx_vec.h"
+
+namespace vxrt {
+
+// new capacity (records per shard) for the path queues of every stream; waits for the GPU first
+int resize_tail_queues(vxrt_ctx* c, unsigned want) {
+    want = want > c->shard_capacity_max ? c->shard_capacity_max : (want + 63u) / 64u * 64u;
+    if (want == c->shard_capacity) return VXRT_OK;
+    if (int rc = sync_all(c)) return rc;
+    const size_t hit_bytes = (size_t(want) * 64 + 1) * 64;
+    for (vxrt_ctx::StreamQueues& q : c->queues)
+        for (float4*& p : q.hitq)
+            if (p) {
+                (void)hipFree(p);
+                p = nullptr;
+                c->queue_bytes -= (size_t(c->shard_capacity) * 64 + 1) * 64;
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p), hit_bytes));
+                c->queue_bytes += hit_bytes;
+            }
+    c->shard_capacity = want;
+    return VXRT_OK;
+}
+
+// Tail queues sized by need: look at what the stream's last launch wanted (its shard counters, copied back after the launch) and,
+// if that did not fit, make the stream's queues larger before its next launch.  Paths that did not fit were followed by the head
+// kernel itself, so no frame was wrong — only slower.
+int grow_tail_queues(vxrt_ctx* c, size_t lane) {
+    vxrt_ctx::StreamQueues& sq = c->queues[lane];
+    if (!sq.counts_pending || hipEventQuery(sq.counts_ready) != hipSuccess) return VXRT_OK;
+    sq.counts_pending = false;
+    unsigned peak = 0;
+    for (unsigned s = 0; s < 64; s++) {
+        const unsigned n = sq.host_counts[s * 16];
+        peak = n > peak ? n : peak;
+        if (n > c->shard_capacity) c->queue_overflow_paths += n - c->shard_capacity;
+    }
+    if (peak <= c->shard_capacity || c->tail_capacity_override > 0 || c->shard_capacity >= c->shard_capacity_max) return VXRT_OK;
+    // every stream's queues share one capacity (PathQueue::shard_capacity travels with the launch): grow them all, at rest
+    unsigned want = peak + peak / 4u;
+    want = want < 2u * c->shard_capacity ? 2u * c->shard_capacity : want;
+    return resize_tail_queues(c, want);
+}
+
+Cam make_cam(const float pos[3], const CameraBasis& b) {
+    Cam c;
+    for (int i = 0; i < 3; i++) { c.o[i] = pos[i]; c.r[i] = b.right[i]; c.u[i] = b.up[i]; c.f[i] = b.forward_ray[i]; }
+    return c;
+}
+
+
+// Context::update_bindings for one frame (src/context.rs:2136-2162): old <- current, current <- camera, frame_number + 1
+void update_bindings(vxrt_ctx* c) {
+    c->old_cam = c->cam;
+    CameraBasis basis = camera_axis_scaled(c->cam_dir, c->cam_fov, c->cfg.width, c->cfg.height);
+    c->cam = make_cam(c->cam_pos, basis);
+    for (int i = 0; i < 3; i++) {
+        c->uniforms.camera_origin[i] = c->cam.o[i]; c->uniforms.camera_right[i] = c->cam.r[i];
+        c->uniforms.camera_up[i] = c->cam.u[i]; c->uniforms.camera_forward[i] = c->cam.f[i];
+    }
+    c->uniforms.still_sample += 1;
+    c->uniforms.frame_number += 1;  // wrapping
+}
+
+// The fields of TraceArgs that depend on the scene and the uniforms only (not on the frame slots or the launch).
+void frame_constants(const vxrt_ctx* c, TraceArgs& a) {
+    const vxrt_uniforms& u = c->uniforms;
+    a.svo = c->d_svo; a.leaves = c->d_leaves; a.noise = c->d_noise;
+    a.root_rec = c->root_rec;
+    a.wide = c->d_wide;
+    a.wide_root = c->wide_root;
+    a.node_levels = int(c->depth) + 1;
+    memcpy(a.root_center, c->root_center, sizeof a.root_center);
+    a.root_size = c->root_size;
+    a.band = c->band;
+    a.max_bounces = int(c->cfg.max_bounces);
+    a.launch_index = 0;
+    a.stack_levels = c->depth < 1 ? 1 : int(c->depth);
+    // voxels.comp:296 and the other per-frame constants, evaluated once with the same operations
+    f3 sun_dir = mk3(vx_cos(u.sun_yaw) * vx_cos(u.sun_pitch), -vx_sin(u.sun_pitch), vx_sin(u.sun_yaw) * vx_cos(u.sun_pitch));
+    f3 sun_n = norm3(sun_dir), neg_sun_n = norm3(-sun_dir);
+    f3 sun_color = u.sun_strength * mk3(u.sun_color[0], u.sun_color[1], u.sun_color[2]);
+    a.sun_dir[0] = sun_dir.x; a.sun_dir[1] = sun_dir.y; a.sun_dir[2] = sun_dir.z;
+    a.sun_dir_n[0] = sun_n.x; a.sun_dir_n[1] = sun_n.y; a.sun_dir_n[2] = sun_n.z;
+    a.neg_sun_dir_n[0] = neg_sun_n.x; a.neg_sun_dir_n[1] = neg_sun_n.y; a.neg_sun_dir_n[2] = neg_sun_n.z;
+    a.sun_color[0] = sun_color.x; a.sun_color[1] = sun_color.y; a.sun_color[2] = sun_color.z;
+    a.sky_color[0] = u.sky_color[0]; a.sky_color[1] = u.sky_color[1]; a.sky_color[2] = u.sky_color[2];
+    a.sun_exponent = 1.0f / (u.sun_size * u.sun_size);
+    // vx_pow(x, y) = vx_exp(y * vx_log(x)) is +0 once y * log(x) < -87.3: certain for x < exp(-88 / y) * (1 - 1e-4), which leaves
+    // 0.7 + 1e-4 y of margin in the exponent against vx_log's error of ~1e-6 |log x| and the product's rounding.
+    a.sun_zero_below = 0.0f;
+    if (a.sun_exponent > 1.0f && a.sun_exponent < 1e6f) a.sun_zero_below = float(exp(-88.0 / double(a.sun_exponent)) * (1.0 - 1e-4));
+    a.sun_size = u.sun_size; a.sun_strength = u.sun_strength; a.emit_strength = u.emit_strength; a.specularity = u.specularity;
+}
+
+// The trace stage of the next g frames (parameters at rest) as ONE launch of the tracer: g ring slots, frame numbers
+// frame_number+1 .. +g.  g > 1 only with the trace_kernel-based tracers (1, 4, 5).  slots[k] = ring slot of frame k.
+// path: optional g camera poses (position, direction), one per frame; null = the camera stays where it is.  cams / olds
+// (g entries each): the camera and the "old" camera of every frame, as temporal.comp and denoise.comp of that frame see them.
+int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam* olds, const float (*path_pos)[3], const float (*path_dir)[3],
+                 uint32_t gbuf_frames) {
+    const uint32_t first_frame_number = c->uniforms.frame_number + 1;
+    for (uint32_t k = 0; k < g; k++) {
+        if (path_pos) {
+            memcpy(c->cam_pos, path_pos[k], sizeof c->cam_pos);
+            memcpy(c->cam_dir, path_dir[k], sizeof c->cam_dir);
+        }
+        update_bindings(c);
+        cams[k] = c->cam;
+        olds[k] = c->old_cam;
+    }
+    // next frame slots (never the temporal history) and the trace stream of this launch
+    int s = c->slot;
+    for (uint32_t k = 0; k < g; k++) {
+        s = (s + 1) % int(c->ring.size());
+        if (c->has_history && s == c->hist_slot) s = (s + 1) % int(c->ring.size());
+        slots[k] = s;
+    }
+    const size_t lane = size_t(c->trace_launches % uint64_t(c->inflight));
+    hipStream_t ts = c->trace_streams[lane];
+    vxrt_ctx::TileSchedule& sched = c->schedules[lane];
+    for (uint32_t k = 0; k < g; k++) {
+        vxrt_ctx::Slot& sl = c->ring[size_t(slots[k])];
+        if (sl.last_use_recorded) HIP_TRY(hipStreamWaitEvent(ts, sl.last_use, 0));
+    }
+
+    TraceArgs a;
+    frame_constants(c, a);
+    for (uint32_t k = 0; k < g; k++) {
+        const vxrt_ctx::Slot& sl = c->ring[size_t(slots[k])];
+        a.out[k] = FrameOut{sl.sampled_color, sl.nd, sl.albedo};
+    }
+    a.out_color = a.out[0].color; a.out_nd = a.out[0].nd; a.out_albedo = a.out[0].albedo;
+    a.batch = int(g);
+    a.gbuf_frames = gbuf_frames;
+    a.ray_counter = c->d_rays;
+    a.tile_order = (c->use_tile_order && sched.valid) ? sched.order : nullptr;
+    a.tile_cost = c->use_tile_order ? sched.cost : nullptr;
+    a.frame_number = first_frame_number;
+    a.cam = cams[0];
+    for (uint32_t k = 0; k < g; k++) a.cams[k] = cams[k];
+    if (c->band.local_rows > 0) {
+        EventPair p;
+        if (timed) { p = take_pair(c, 0); HIP_TRY(hipEventRecord(p.a, ts)); }
+        a.tail = PathQueue{nullptr, nullptr, 0};
+        a.tail_zero = nullptr;
+        a.tail_from = 0;
+        const size_t scene_bytes = c->svo_count * sizeof(SvoRecord) + c->leaf_count * sizeof(int32_t);
+        // tracer 0 (auto) takes the all-in-one kernel (a) for scenes beyond the Infinity Cache (see auto_tracer) and (b) for ONE frame at
+        // a time on one stream — the latency case of a render loop that calls vxrt_render per frame: the head + tail pair waits twice
+        // for a longest wave (0.357 ms per 1080p bench frame), the single kernel once (0.267 ms); with frames in flight or several
+        // frames per launch the pair wins (0.123 ms per frame at 16 x 2)
+        const bool one_at_a_time = g == 1 && c->inflight == 1;
+        const int variant = (c->auto_tracer && (scene_bytes > (size_t(256) << 20) || one_at_a_time)) ? 0 : c->trace_variant;
+        if (variant == 0 || variant >= 4) {
+            if (variant >= 4) {
+                // count sets rotate as in launch_trace_wavefront: launch J reads set J%3, writes (J+1)%3, clears (J+2)%3
+                if (int rc = grow_tail_queues(c, lane)) return rc;
+                vxrt_ctx::StreamQueues& sq = c->queues[lane];
+                unsigned* sets[3] = {sq.counts3, sq.counts3 + 64 * 16, sq.counts3 + 2 * 64 * 16};
+                const unsigned J = sq.launches;
+                a.tail = PathQueue{sq.hitq[0], sets[(J + 1) % 3], c->shard_capacity};
+                a.tail_zero = sets[(J + 2) % 3];
+                a.tail_from = c->tail_from;
+                HIP_TRY(launch_trace(a, use_wide(c) && c->trace_variant == 4, ts));
+                sq.launches = J + 1;
+                if (!sq.counts_pending) {   // how much room this launch wanted (the set stays untouched until launch J + 2 clears it)
+                    HIP_TRY(hipMemcpyAsync(sq.host_counts, sets[(J + 1) % 3], 64 * 64, hipMemcpyDeviceToHost, ts));
+                    HIP_TRY(hipEventRecord(sq.counts_ready, ts));
+                    sq.counts_pending = true;
+                }
+#if VXRT_VARIANTS
+                if (c->trace_variant == 5) {
+                    HIP_TRY(launch_paths(a, a.tail, sets[J % 3], c->tail_from, c->path_blocks, ts));
+                    sq.launches = J + 2;
+                } else
+#endif
+                {
+                    // without a second queue (tail_split == 0) nothing is appended to queues[1]: its capacity 0 says so
+                    PathQueue queues[2] = {{sq.hitq[0], nullptr, c->shard_capacity}, {sq.hitq[1], nullptr, sq.hitq[1] ? c->shard_capacity : 0u}};
+                    HIP_TRY(launch_bounces(a, use_wide(c), queues, sets, &sq.launches, c->trace_blocks, sq.hitq[1] ? c->tail_split : 0u, c->tail_from, ts));
+                }
+            } else {
+                HIP_TRY(launch_trace(a, use_wide(c), ts));
+            }
+            if (timed) HIP_TRY(hipEventRecord(p.b, ts));
+            // Re-sort the tiles for this stream's coming frames from the costs just measured: after its first
+            // frame, then every 8th (costs keep accumulating as a running maximum in between; ~7 us per sort).
+            if (c->use_tile_order && (!sched.valid || sched.age >= 8)) {
+                const unsigned tiles = trace_tile_count(c->band.width, c->band.local_rows);
+                HIP_TRY(launch_tile_order(sched.cost, sched.order, sched.last_cost, sched.scratch, tiles, ts));
+                sched.valid = true;
+                sched.age = 0;
+            }
+            sched.age++;
+        }
+#if VXRT_VARIANTS
+        else {
+            vxrt_ctx::StreamQueues& sq = c->queues[lane];
+            PathQueue queues[2] = {{sq.hitq[0], nullptr, c->shard_capacity}, {sq.hitq[1], nullptr, c->shard_capacity}};
+            unsigned* sets[3] = {sq.counts3, sq.counts3 + 64 * 16, sq.counts3 + 2 * 64 * 16};
+            if (c->trace_variant == 2)
+                HIP_TRY(launch_trace_wavefront(a, queues, sets, &sq.launches, c->trace_blocks, c->trace_split, ts));
+            else
+                HIP_TRY(launch_trace_rayqueue(a, queues[0], sets, &sq.launches, sq.rq, c->shade_blocks, c->trace_blocks, c->rays_per_wave, ts));
+            if (timed) HIP_TRY(hipEventRecord(p.b, ts));
+        }
+#endif
+        if (timed) c->pending.push_back(p);
+    }
+    for (uint32_t k = 0; k < g; k++) {
+        vxrt_ctx::Slot& sl = c->ring[size_t(slots[k])];
+        HIP_TRY(hipEventRecord(sl.trace_done, ts));
+        HIP_TRY(hipEventRecord(sl.last_use, ts));  // until a later stage reads the slot, the trace is its last use
+        sl.last_use_recorded = true;
+    }
+    c->slot = slots[g - 1];
+    c->last_schedule = int(lane);
+    c->trace_launches += 1;
+    c->traced += g;
+    c->frames += g;
+    c->pixels += uint64_t(g) * uint64_t(c->band.local_rows) * c->band.width;
+    if (timed) { c->timed_frames += g; c->timed_launches += 1; }
+    c->accum_is_sampled = true;
+    c->halo_valid = false;
+    return VXRT_OK;
+}
+
+
+}  // namespace vxrt

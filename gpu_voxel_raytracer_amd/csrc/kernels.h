@@ -4,6 +4,14 @@
 
 #include <cstdint>
 
+// The default library holds the two schedules that won on MI355X — tracer 1 (all-in-one kernel) and tracer 4 (head + compacted tail) —
+// over the 8-byte scene records.  -DVXRT_VARIANTS=1 also builds what was measured slower and is kept for comparison:
+// tracers 2 (wavefront), 3 (ray queues), 5 (per-lane path refill) and the wide scene records (two tree levels per 16-byte record).
+// Every variant gives bit-identical images (scripts/test_variants.sh runs the parity tests over that build).
+#ifndef VXRT_VARIANTS
+#define VXRT_VARIANTS 0
+#endif
+
 namespace vxrt {
 
 // Compact sparse voxel octree, the device scene format ("SVO record"): the same tree as the
@@ -101,6 +109,19 @@ struct TraceArgs {
                            // displayed frame, vxrt_render_spp, whose first hits are identical: only the frame that is kept writes them)
 };
 
+// The rows of the neighbouring ranks that this rank can see (multi-rank: api_halo.hip, halo.hip).  Two messages are kept, side 0 =
+// the `rows` rows ABOVE each local band (sent by the previous rank), side 1 = the `rows` rows BELOW it (sent by the next rank); a
+// message is three planes over (slot = local band, row k, x):  A = (r, g, b, depth)  B = (nx, ny, nz, bits(material id))  C = blending
+// factor of the accumulated colour — 36 bytes per pixel: what denoise.comp:51-57's window reads of a neighbour's pixel (colour,
+// normal, depth, material) plus what temporal.comp:85-113's reprojection reads of it (colour + blending factor, depth).
+// Row k of side 0 is frame row band_y0 - rows + k, row k of side 1 is frame row band_end + k.
+struct HaloView {
+    const float4* base;   // null: no halo
+    int rows, slots;      // rows per band edge; bands a message has room for
+    size_t plane;         // float4 per A / B plane = slots * rows * width
+    size_t message;       // float4 per message (>= 2 * plane + plane / 4, rounded up)
+};
+
 struct TemporalArgs {
     const float4* sampled_color;
     const float4* new_nd;
@@ -112,10 +133,9 @@ struct TemporalArgs {
     float inv[12];  // affine inverse of the old camera matrix (temporal.comp:75-82), rows + translation
     float sample_blending, maximum_blending, blending_distance_cutoff;
     int has_history;
-    // multi-rank: the denoise halo imported for the previous frame holds the neighbours' rows of exactly this history
-    // (accumulated colour and normal/depth, `halo_radius` rows beyond each band edge); null: such rows are a disocclusion
-    const float4* halo;
-    int halo_radius;
+    // multi-rank: the halo unpacked for the previous frame holds the neighbours' rows of exactly this history
+    // (accumulated colour and depth, halo.rows rows beyond each band edge); base null: such rows are a disocclusion
+    HaloView halo;
     // fused denoise for radius 0 (the reference's default): out = mix(c, albedo * c, albedo_factor) of the blended colour
     const float4* albedo;   // null: no fusion
     float4* denoised;
@@ -127,9 +147,12 @@ struct DenoiseArgs {
     const float4* nd;
     const float4* albedo;
     float4* output;
-    // rows just outside this context's bands, received from the neighbouring ranks (may be null):
-    // [band][side][r rows][width] of (colour, nd, albedo)
-    const float4* halo;
+    // rows just outside this context's bands, received from the neighbouring ranks (base may be null)
+    HaloView halo;
+    // which rows of 16x16 tiles to denoise: null = all of them (blockIdx.y is the tile row); else tile row = tile_rows[blockIdx.y]
+    // (api_halo.hip: the tiles whose window stays inside this rank's rows, and the tiles that need the halo)
+    const uint16_t* tile_rows;
+    uint32_t tile_row_count;
     BandMap band;
     Cam cam;
     uint32_t radius;
@@ -155,20 +178,24 @@ hipError_t launch_path_log(const TraceArgs& a, bool wide, int x, int y, float* l
 hipError_t launch_cast_probe(const TraceArgs& a, bool wide, const float* origins, const float* dirs, float* out, unsigned n, hipStream_t s);
 unsigned trace_tile_count(int width, int local_rows);  // blocks per frame of trace_kernel = entries of a tile schedule
 void trace_tile_dims(int* w, int* h);                  // pixels per block  // monolithic: one pixel per lane, all bounces
+#if VXRT_VARIANTS
 // ray queues: primary_kernel, then shade / trace-rays launches per path segment with per-lane ray refill
 hipError_t launch_trace_rayqueue(const TraceArgs& a, const PathQueue& hits, unsigned* count_sets[3], unsigned* launch_counter,
                                  const RayQueue& q, int shade_blocks, int trace_blocks, unsigned min_rays_per_wave, hipStream_t s);
+#endif
 // longest-tile-first schedule for the next launch: order[] = tiles sorted by descending cost; cost[] is cleared
 // scratch: 256 * 128 uint32
 hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t* last_cost, uint32_t* scratch, unsigned tiles, hipStream_t s);
+#if VXRT_VARIANTS
 // wavefront: primary_kernel + max_bounces x bounce_kernel; queues[2] ping-pong, count_sets[3] rotate
 hipError_t launch_trace_wavefront(const TraceArgs& a, const PathQueue queues[2], unsigned* count_sets[3], unsigned* launch_counter,
                                   int blocks, unsigned split_mask, hipStream_t s);
+// tracer 5: path_kernel (trace_paths.hip) follows the paths queued in `in` to their end, refilling each lane with a new path
+hipError_t launch_paths(const TraceArgs& a, const PathQueue& in, unsigned* zero, int first_bounce, int blocks, hipStream_t s);
+#endif
 // bounce_kernel launches for path segments from.. of the paths queued in queues[0] (tracer 2 and the tail of tracer 4)
 hipError_t launch_bounces(const TraceArgs& a, bool wide, const PathQueue queues[2], unsigned* count_sets[3], unsigned* launch_counter, int blocks,
                           unsigned split_mask, int from, hipStream_t s);
-// tracer 5: path_kernel (trace_paths.hip) follows the paths queued in `in` to their end, refilling each lane with a new path
-hipError_t launch_paths(const TraceArgs& a, const PathQueue& in, unsigned* zero, int first_bounce, int blocks, hipStream_t s);
 // "N samples per pixel" (SURVEY.md 8d): sum[p] (+)= frames[0][p] + ... + frames[count-1][p], added in that order;
 // first: sum starts from frames[0]; last: out[p] = sum[p] / float(total) is written as well.  One streaming pass.
 struct SppArgs {
@@ -179,6 +206,20 @@ struct SppArgs {
     int count, first, last, total;
 };
 hipError_t launch_spp_accumulate(const SppArgs& a, hipStream_t s);
+// multi-rank halo (halo.hip): ONE pack launch fills both outgoing messages from this rank's band-edge rows, ONE unpack launch copies
+// both incoming messages into the context's halo store
+struct HaloPackArgs {
+    const float4* color;    // accumulated colour (rgb + blending factor)
+    const float4* nd;       // normal / depth
+    const float4* albedo;   // .w = bits(leaf word): material id = bits >> 24
+    float4* to_prev;        // message for rank - 1: this rank's top rows = the rows below that rank's bands
+    float4* to_next;        // message for rank + 1: this rank's bottom rows = the rows above that rank's bands
+    BandMap band;
+    int rows, slots, local_bands;
+    size_t plane;
+};
+hipError_t launch_halo_pack(const HaloPackArgs& a, hipStream_t s);
+hipError_t launch_halo_unpack(float4* store, const float4* from_prev, const float4* from_next, size_t message_f4, hipStream_t s);
 hipError_t launch_temporal(const TemporalArgs& a, hipStream_t s);
 hipError_t launch_denoise(const DenoiseArgs& a, hipStream_t s);
 hipError_t launch_noise_fill(float* dst, uint32_t seed, size_t n, hipStream_t s);

@@ -11,6 +11,7 @@
 //                    of three 16-byte global loads and two logs; the per-offset distance term comes
 //                    from a small LDS table; taps whose weight is exactly zero are skipped.
 //                    radius 0 (the default) is a separate streaming kernel.
+#include "halo_view.h"
 #include "kernels.h"
 #include "vx_vec.h"
 
@@ -24,36 +25,31 @@ __device__ __forceinline__ f3 pixel_dir(const Cam& c, int x, int y) {
     return norm3((float(x) * ld3(c.r) - float(y) * ld3(c.u)) + ld3(c.f));
 }
 
-// frame row -> local row of this context, or -1 when another rank owns it
-__device__ __forceinline__ int local_row(const BandMap& b, int y) {
-    int band = y / b.band_rows;
-    if (band % b.nranks != b.rank) return -1;
-    return (band / b.nranks) * b.band_rows + (y - band * b.band_rows);
-}
-__device__ __forceinline__ int frame_row(const BandMap& b, int lrow) {
-    int lband = lrow / b.band_rows;
-    return (lband * b.nranks + b.rank) * b.band_rows + (lrow - lband * b.band_rows);
-}
-
-// One image of the temporal history as this rank can see it: its own rows, plus — when the denoise halo of the previous
-// frame is still there — `r` rows beyond each of its band edges (layout of DenoiseArgs::halo: [(local band, side)][row][image][x],
-// images 0 = accumulated colour, 1 = normal/depth).
+// One image of the temporal history as this rank can see it: its own rows, plus — when the halo unpacked after the previous
+// frame's temporal stage is still there — halo.rows rows beyond each of its band edges (kernels.h: HaloView).
+//   kColour: the accumulated colour (rgb + blending factor)      kDepth: normal/depth, of which temporal.comp:94-104 reads .w only
+enum HistoryKind { kColour = 0, kDepth = 1 };
 struct HistoryRows {
     const float4* img;
-    const float4* halo;
-    int image, r;
+    HaloView halo;
+    HistoryKind kind;
 };
-// frame row y of the history, or null when this rank cannot see it
-__device__ __forceinline__ const float4* history_row(const BandMap& b, const HistoryRows& hs, int y) {
+struct HistoryRow {
+    const float4* own;   // a row of this rank's image, or null: the halo row
+    HaloRow far;
+};
+// frame row y of the history; false when this rank cannot see it
+__device__ __forceinline__ bool history_row(const BandMap& b, const HistoryRows& hs, int y, HistoryRow& out) {
     const int l = local_row(b, y);
-    if (l >= 0) return hs.img + size_t(l) * b.width;
-    if (hs.halo == nullptr) return nullptr;
-    const int band = y / b.band_rows, off = y - band * b.band_rows;
-    if (band >= 1 && (band - 1) % b.nranks == b.rank && off < hs.r)               // just below one of this rank's bands
-        return hs.halo + (size_t((((band - 1) / b.nranks) * 2 + 1) * hs.r + off) * 3 + hs.image) * b.width;
-    if ((band + 1) % b.nranks == b.rank && off >= b.band_rows - hs.r)             // just above one
-        return hs.halo + (size_t((((band + 1) / b.nranks) * 2 + 0) * hs.r + (off - (b.band_rows - hs.r))) * 3 + hs.image) * b.width;
-    return nullptr;
+    out.own = nullptr;
+    if (l >= 0) { out.own = hs.img + size_t(l) * b.width; return true; }
+    return halo_find(b, hs.halo, y, out.far);
+}
+__device__ __forceinline__ float4 history_texel(const HistoryRows& hs, const HistoryRow& r, int x) {
+    if (r.own != nullptr) return r.own[x];
+    const float4 a = r.far.a[x];
+    if (hs.kind == kColour) return make_float4(a.x, a.y, a.z, r.far.c[x]);
+    return make_float4(0.0f, 0.0f, 0.0f, a.w);   // the normal of an old texel is never read (temporal.comp:94-104)
 }
 
 // texture() through the reference's Linear / ClampToEdge sampler (src/context.rs:980-989): bilinear,
@@ -66,11 +62,12 @@ __device__ __forceinline__ bool sample_bilinear(const HistoryRows& hs, const Ban
     int xa = min(max(x0, 0), b.width - 1), xb = min(max(x0 + 1, 0), b.width - 1);
     int ya = min(max(y0, 0), b.height - 1), yb = min(max(y0 + 1, 0), b.height - 1);
     // a texel whose quantised weight is 0 is not read: only rows with a non-zero weight must be visible
-    const float4* ra = ay == 1.0f ? hs.img : history_row(b, hs, ya);
-    const float4* rb = ay == 0.0f ? hs.img : history_row(b, hs, yb);
-    if (ra == nullptr || rb == nullptr) return false;
-    float4 t00 = ra[xa], t10 = ra[xb];
-    float4 t01 = rb[xa], t11 = rb[xb];
+    HistoryRow ra, rb;
+    ra.own = rb.own = hs.img;
+    if (ay != 1.0f && !history_row(b, hs, ya, ra)) return false;
+    if (ay != 0.0f && !history_row(b, hs, yb, rb)) return false;
+    float4 t00 = history_texel(hs, ra, xa), t10 = history_texel(hs, ra, xb);
+    float4 t01 = history_texel(hs, rb, xa), t11 = history_texel(hs, rb, xb);
     const float* p00 = &t00.x; const float* p10 = &t10.x; const float* p01 = &t01.x; const float* p11 = &t11.x;
     float* o = &out.x;
     for (int k = 0; k < 4; k++) {
@@ -108,7 +105,7 @@ __global__ __launch_bounds__(256) void temporal_kernel(const TemporalArgs a) {
         float tv = (sy + -0.5f) * (-1.0f / float(a.band.height));
         if (0.0f <= tu && tu <= 1.0f && 0.0f <= tv && tv <= 1.0f) {
             float4 old_nd;
-            const HistoryRows nd_rows{a.old_nd, a.halo, 1, a.halo_radius}, color_rows{a.old_color, a.halo, 0, a.halo_radius};
+            const HistoryRows nd_rows{a.old_nd, a.halo, kDepth}, color_rows{a.old_color, a.halo, kColour};
             if (sample_bilinear(nd_rows, a.band, tu, tv, old_nd)) {
                 f3 old_dir = norm3((float(vx_f2i(sx + 0.5f)) * ld3(a.old_cam.r) + float(vx_f2i(sy - 0.5f)) * ld3(a.old_cam.u)) + ld3(a.old_cam.f));
                 f3 old_position = ld3(a.old_cam.o) + old_nd.w * old_dir;
@@ -170,7 +167,8 @@ __global__ __launch_bounds__(256) void denoise_kernel(const DenoiseArgs a) {
     float4* tileB = lds_raw + tw * tw;
     float* wdist = reinterpret_cast<float*>(lds_raw + 2 * tw * tw);  // (dx*dx + dy*dy) / sigma_distance_2 per window offset
     const int x0 = blockIdx.x * 16 - r;
-    const int lrow0 = blockIdx.y * 16;  // band_rows is a multiple of 16: a tile never straddles two bands
+    const int tile_row = a.tile_rows != nullptr ? int(a.tile_rows[blockIdx.y]) : int(blockIdx.y);
+    const int lrow0 = tile_row * 16;  // band_rows is a multiple of 16: a tile never straddles two bands
     const int y0 = frame_row(a.band, lrow0) - r;
     const int lband = lrow0 / a.band.band_rows;
     const int band_y0 = (lband * a.band.nranks + a.band.rank) * a.band.band_rows;  // first frame row of the band
@@ -186,24 +184,27 @@ __global__ __launch_bounds__(256) void denoise_kernel(const DenoiseArgs a) {
         float4 ta = make_float4(0.0f, 0.0f, 0.0f, 0.0f), tb = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(kTapOutside));
         if (gx >= 0 && gx < a.band.width && gy >= 0 && gy < a.band.height) {
             int l = local_row(a.band, gy);
-            float4 c, nd, al;
+            float4 c, nd;
+            int32_t mat = 0;
             bool have = true;
             if (l >= 0) {
                 size_t p = size_t(l) * a.band.width + gx;
-                c = a.colors[p]; nd = a.nd[p]; al = a.albedo[p];
-            } else if (a.halo != nullptr) {
-                // row of a neighbouring rank: halo[(lband*2 + side)*r + k][3][width]
-                // side 0 = the r rows above the band, side 1 = the r rows below it
-                int side = gy < band_y0 ? 0 : 1;
-                int k = side == 0 ? gy - (band_y0 - r) : gy - (band_y0 + a.band.band_rows);
-                const float4* row = a.halo + (size_t((lband * 2 + side) * r + k) * 3) * a.band.width;
-                c = row[gx]; nd = row[a.band.width + gx]; al = row[2 * a.band.width + gx];
+                c = a.colors[p]; nd = a.nd[p];
+                mat = (__float_as_int(a.albedo[p].w) >> 24) & 0xff;                             // denoise.comp:67
+            } else if (a.halo.base != nullptr) {
+                // a row of a neighbouring rank: side 0 = the rows above the band, side 1 = the rows below it
+                const int side = gy < band_y0 ? 0 : 1;
+                const int k = side == 0 ? gy - (band_y0 - a.halo.rows) : gy - (band_y0 + a.band.band_rows);
+                const HaloRow row = halo_row(a.halo, a.band.width, side, lband, k);
+                const float4 ha = row.a[gx], hb = row.b[gx];
+                c = make_float4(ha.x, ha.y, ha.z, 0.0f);
+                nd = make_float4(hb.x, hb.y, hb.z, ha.w);
+                mat = __float_as_int(hb.w);
             } else {
                 have = false;
             }
             if (have) {
                 ta = make_float4(c.x, c.y, c.z, vx_log(vx_abs(nd.w)));                         // denoise.comp:66
-                int32_t mat = (__float_as_int(al.w) >> 24) & 0xff;                              // denoise.comp:67
                 if (!finite3(c)) mat |= kTapNonFinite;
                 tb = make_float4(nd.x, nd.y, nd.z, __int_as_float(mat));
             }
@@ -341,7 +342,8 @@ hipError_t launch_denoise(const DenoiseArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(denoise_passthrough_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, a);
         return hipGetLastError();
     }
-    dim3 grid((a.band.width + 15) / 16, (a.band.local_rows + 15) / 16);
+    dim3 grid((a.band.width + 15) / 16, a.tile_rows != nullptr ? a.tile_row_count : unsigned(a.band.local_rows + 15) / 16u);
+    if (grid.y == 0u) return hipSuccess;
     int tw = 16 + 2 * int(a.radius), taps = 2 * int(a.radius) + 1;
     size_t lds = size_t(tw) * tw * 32 + size_t(taps * taps + 3) / 4 * 16;
     if (a.mode == 1)

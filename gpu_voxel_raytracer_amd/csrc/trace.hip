@@ -364,19 +364,25 @@ __global__ __launch_bounds__(kTB) void path_log_kernel(const TraceArgs a, int x,
 
 hipError_t launch_cast_probe(const TraceArgs& a, bool wide, const float* origins, const float* dirs, float* out, unsigned n, hipStream_t s) {
     const size_t lds = caster_lds_bytes(a, wide, kTB);
-    if (wide)
+#if VXRT_VARIANTS
+    if (wide) {
         hipLaunchKernelGGL(cast_probe_kernel<true>, dim3((n + kTB - 1) / kTB), dim3(kTB), lds, s, a, origins, dirs, out, n);
-    else
-        hipLaunchKernelGGL(cast_probe_kernel<false>, dim3((n + kTB - 1) / kTB), dim3(kTB), lds, s, a, origins, dirs, out, n);
+        return hipGetLastError();
+    }
+#endif
+    hipLaunchKernelGGL(cast_probe_kernel<false>, dim3((n + kTB - 1) / kTB), dim3(kTB), lds, s, a, origins, dirs, out, n);
     return hipGetLastError();
 }
 
 hipError_t launch_path_log(const TraceArgs& a, bool wide, int x, int y, float* log, hipStream_t s) {
     const size_t lds = caster_lds_bytes(a, wide, kTB);
-    if (wide)
+#if VXRT_VARIANTS
+    if (wide) {
         hipLaunchKernelGGL(path_log_kernel<true>, dim3(1), dim3(kTB), lds, s, a, x, y, log);
-    else
-        hipLaunchKernelGGL(path_log_kernel<false>, dim3(1), dim3(kTB), lds, s, a, x, y, log);
+        return hipGetLastError();
+    }
+#endif
+    hipLaunchKernelGGL(path_log_kernel<false>, dim3(1), dim3(kTB), lds, s, a, x, y, log);
     return hipGetLastError();
 }
 
@@ -390,10 +396,13 @@ void trace_tile_dims(int* w, int* h) { *w = kTileW; *h = kTileH; }
 hipError_t launch_trace(const TraceArgs& a, bool wide, hipStream_t s) {
     dim3 grid(trace_tile_count(a.band.width, a.band.local_rows) * unsigned(a.batch));
     const size_t lds = caster_lds_bytes(a, wide, kTB);
-    if (wide)
+#if VXRT_VARIANTS
+    if (wide) {
         hipLaunchKernelGGL(trace_kernel<true>, grid, dim3(kTB), lds, s, a);
-    else
-        hipLaunchKernelGGL(trace_kernel<false>, grid, dim3(kTB), lds, s, a);
+        return hipGetLastError();
+    }
+#endif
+    hipLaunchKernelGGL(trace_kernel<false>, grid, dim3(kTB), lds, s, a);
     return hipGetLastError();
 }
 

@@ -508,7 +508,9 @@ __device__ __forceinline__ bool cast_ray(const SceneView& sc, f3 o, f3 d, float 
 }
 
 __device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+#if VXRT_VARIANTS
 #include "walk_wide.h"
+#endif
 
 __device__ __forceinline__ f3 node_rgb(int32_t node) {
     return mk3(float((node >> 16) & 0xff), float((node >> 8) & 0xff), float(node & 0xff));
@@ -727,12 +729,14 @@ template <> struct Caster<false> {
     __device__ __forceinline__ Caster(const TraceArgs& a, uint4* lds, int tid) : sc(make_scene(a)), stack(reinterpret_cast<uint2*>(lds) + tid) {}
     __device__ __forceinline__ bool cast(f3 o, f3 d, RayHit& hit) const { return cast_ray(sc, o, d, kAlmostInfinity, stack, hit); }
 };
+#if VXRT_VARIANTS
 template <> struct Caster<true> {
     SceneW sc;
     uint4* stack;
     __device__ __forceinline__ Caster(const TraceArgs& a, uint4* lds, int tid) : sc(make_scene_w(a)), stack(lds + tid) {}
     __device__ __forceinline__ bool cast(f3 o, f3 d, RayHit& hit) const { return cast_ray_w(sc, o, d, kAlmostInfinity, stack, hit); }
 };
+#endif
 // dynamic shared memory a block of `threads` threads needs for its frames
 inline size_t caster_lds_bytes(const TraceArgs& a, bool wide, int threads) {
     if (!wide) return size_t(a.stack_levels) * size_t(threads) * sizeof(uint2);

@@ -161,9 +161,11 @@ hipError_t launch_bounces(const TraceArgs& a, bool wide, const PathQueue queues[
         in.counts = count_sets[J % 3];
         PathQueue out = queues[(stage & 1) ^ 1];
         out.counts = count_sets[(J + 1) % 3];
+#if VXRT_VARIANTS
         if (wide)
             hipLaunchKernelGGL(bounce_kernel<true>, dim3(blocks), dim3(kTailBlock), lds, s, a, in, out, count_sets[(J + 2) % 3], first, last);
         else
+#endif
             hipLaunchKernelGGL(bounce_kernel<false>, dim3(blocks), dim3(kTailBlock), lds, s, a, in, out, count_sets[(J + 2) % 3], first, last);
         J++;
         stage++;

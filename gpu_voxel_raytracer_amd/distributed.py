@@ -1,26 +1,39 @@
 """Multi-GPU orchestration of the vxrt frame loop: one process per GPU, torch.distributed (backend "nccl"
-= RCCL over xGMI on ROCm, "gloo" for CPU rehearsals) for the only exchange the path has — the denoise halo.
+= RCCL over xGMI on ROCm, "gloo" for CPU rehearsals) for the only exchange the path has — the halo.
 
 Decomposition: the frame's rows are dealt to the ranks in interleaved bands of `band_rows`
-rows (band b -> rank b % nranks); scene and noise table are replicated; trace and temporal need no
-communication (temporal history is same-pixel for a static camera; a reprojection that leaves the rank's
-rows is treated as a disocclusion).  denoise.comp's (2r+1)^2 window reaches r rows into the neighbouring
-bands, which live on rank-1 and rank+1 (mod nranks): each rank sends two messages and receives two,
-point-to-point, each on its own xGMI link.  No all-reduce anywhere.
+rows (band b -> rank b % nranks); scene and noise table are replicated; the trace stage needs no
+communication.  denoise.comp's (2r+1)^2 window (shaders/denoise.comp:51-57) reaches r rows into the
+neighbouring bands, and temporal.comp's reprojection (shaders/temporal.comp:85-113) reads the previous
+frame's history at a texel that may lie in them; both live on rank-1 and rank+1 (mod nranks).  After a
+frame's temporal stage each rank therefore sends two messages and receives two, point-to-point, each on its
+own xGMI link — `rows` = max(r, VXRT_OPT_HALO_ROWS) rows per band edge, 36 bytes per pixel (include/vxrt.h
+"halo").  No all-reduce anywhere.  The exchange is overlapped with the denoise of the tiles that need no
+halo:
 
-`ctx` is anything with halo_bytes() / halo_export(ptr, ptr) / halo_import(ptr, ptr) / render_stage(flags)
-— host.Context on a GPU; the CPU tests substitute an oracle-backed stand-in to rehearse the routing.
+    render(TRACE | TEMPORAL) -> halo.start() -> render_stage(DENOISE_INTERIOR) -> halo.finish() -> render_stage(DENOISE_EDGE)
+
+`ctx` is anything with halo_bytes() / halo_pack(ptr, ptr) / halo_unpack(ptr, ptr) / stream_wait_context(stream) /
+context_wait_stream(stream) / render_stage(flags) — host.Context on a GPU; the CPU tests substitute an
+oracle-backed stand-in to rehearse the routing and the message layout.
 """
 import numpy as np
 
-TRACE, TEMPORAL, DENOISE = 1, 2, 4
+TRACE, TEMPORAL, DENOISE, DENOISE_INTERIOR, DENOISE_EDGE = 1, 2, 4, 16, 32
+HALO_BYTES_PER_PIXEL = 36
+
+
+def band_rows_for(radius, minimum=16):
+    """Band height for the frame loop with a denoise window of `radius`: >= 8 radius, so that the halo is at most a quarter of
+    the rows a rank owns, a multiple of 16 (the denoise tiles); 16 without a window."""
+    return max(minimum, (8 * radius + 15) // 16 * 16)
 
 
 class BandLayout:
-    """Row ownership and halo message layout; mirrors BandMap / vxrt_halo_* in csrc/vxrt_api.hip."""
+    """Row ownership and halo message layout; mirrors BandMap and csrc/api_halo.hip / csrc/halo_view.h."""
 
     def __init__(self, width, height, nranks, band_rows=16, radius=None):
-        # the library's rule (vxrt_create / check_render in csrc/vxrt_api.hip): bands are multiples of the tracer's 8-row tiles;
+        # the library's rule (vxrt_create / check_render): bands are multiples of the tracer's 8-row tiles;
         # the denoise stage with a window (radius > 0) works on 16x16 tiles that must not straddle bands
         if band_rows <= 0 or band_rows % 8:
             raise ValueError("band_rows must be a multiple of 8")
@@ -42,60 +55,158 @@ class BandLayout:
     def max_bands(self):
         return (self.bands + self.nranks - 1) // self.nranks
 
-    def halo_floats(self, radius):
-        """float32 count of one halo message: max_bands x radius rows x 3 images x width x rgba."""
-        return self.max_bands() * radius * 3 * self.width * 4
+    def halo_rows(self, radius, min_rows=1):
+        """Rows per band edge an exchange carries (vxrt_halo_info.rows)."""
+        return 0 if self.nranks < 2 else min(self.band_rows, max(radius, min_rows))
+
+    def plane(self, rows):
+        """float4 per A / B plane of a message."""
+        return self.max_bands() * rows * self.width
+
+    def message_floats(self, rows):
+        """float32 count of one halo message: planes A and B (a float4 per pixel) and C (a float per pixel), rounded up
+        to whole 256-byte lines (vxrt_halo_info.message_bytes / 4)."""
+        plane = self.plane(rows)
+        f4 = 2 * plane + (plane + 3) // 4
+        return (f4 + 15) // 16 * 16 * 4
+
+    def message_views(self, buf, rows):
+        """numpy views into a message (a float32 array of message_floats(rows)): A[slot, row, x, 4] = (r, g, b, depth),
+        B[slot, row, x, 4] = (normal, bits(material id)), C[slot, row, x] = blending factor."""
+        plane, shape = self.plane(rows), (self.max_bands(), rows, self.width)
+        a = buf[:plane * 4].reshape(shape + (4,))
+        b = buf[plane * 4: plane * 8].reshape(shape + (4,))
+        c = buf[plane * 8: plane * 9].reshape(shape)
+        return a, b, c
+
+    def halo_pixels_per_rank(self, rank, rows):
+        """Pixels this rank SENDS per exchange (both neighbours)."""
+        n = 0
+        for gb in self.local_bands(rank):
+            y0 = gb * self.band_rows
+            here = min(self.band_rows, self.height - y0)
+            if gb >= 1:
+                n += min(rows, here)
+            if here == self.band_rows and (gb + 1) * self.band_rows < self.height:
+                n += rows
+        return n * self.width
+
+    def tile_rows(self, rank):
+        """(interior, edge): the rank's rows of 16x16 denoise tiles (index = local row // 16) whose window stays inside the rank's own
+        rows, and those that read rows of a neighbour — a band's first tile row when a band lies above it, its last when one lies
+        below (csrc/api_halo.hip: build_tile_rows)."""
+        interior, edge, t = [], [], 0
+        if self.band_rows % 16:
+            return interior, edge
+        for gb in self.local_bands(rank):
+            y0 = gb * self.band_rows
+            end = min(y0 + self.band_rows, self.height)
+            for ty in range(y0, end, 16):
+                above = self.nranks > 1 and ty == y0 and y0 > 0
+                below = self.nranks > 1 and min(ty + 16, end) == end and end < self.height
+                (edge if above or below else interior).append(t + (ty - y0) // 16)
+            t += self.band_rows // 16
+        return interior, edge
 
     def neighbours(self, rank):
         return (rank - 1) % self.nranks, (rank + 1) % self.nranks
 
 
 class HaloExchange:
-    """The denoise-halo exchange of one rank: export this rank's band-edge rows, swap them with rank-1 / rank+1, import what
-    arrived.  Messages: to_prev (tag 0) and to_next (tag 1); with nranks == 2 both go to the same peer.  The four message
-    buffers live as long as this object (vxrt_halo_import copies out of them on the context's stream and returns after that
-    copy has finished, so they may be re-used by the next frame's exchange)."""
+    """The halo exchange of one rank, in two halves so that the caller can put work between them:
+
+        start()   one pack kernel fills to_prev / to_next (on the context's stream); the communication stream waits for it with
+                  an event; over RCCL the two sends and two receives are posted (asynchronous); nothing waits on the host.
+        finish()  the communication stream waits for the four transfers, the context's stream waits for it (event), one unpack
+                  kernel moves both received messages into the context's halo store.
+
+    Messages: to_prev (tag 0) and to_next (tag 1); with nranks == 2 both go to the same peer.  The four message buffers live
+    as long as this object; a frame's receives are ordered after the previous frame's unpack through the same events.
+    comm_device "cpu" (a gloo rehearsal of several ranks on one GPU) stages the messages through pinned host memory; its
+    finish() is where the host blocks (copy out, gloo send/recv, copy in)."""
 
     def __init__(self, ctx, dist, rank, nranks, device, torch, comm_device=None):
         """device: where the context's halo buffers live (the rank's GPU; "cpu" for the oracle-backed stand-in of the CPU tests).
-        comm_device: where the messages travel — the same device over RCCL (default); "cpu" stages them through host memory
-        for a gloo rehearsal of several ranks on one GPU."""
+        comm_device: where the messages travel — the same device over RCCL (default); "cpu" stages them through host memory."""
         self.ctx, self.dist, self.rank, self.nranks, self.device, self.torch = ctx, dist, rank, nranks, device, torch
         self.comm_device = device if comm_device is None else comm_device
-        self.nfloats, self.bufs, self.staged = 0, None, None
+        self.on_gpu = str(device) != "cpu"
+        self.nfloats, self.bufs, self.staged, self.works, self.copied = 0, None, None, None, None
+        self.stream = torch.cuda.Stream(device) if self.on_gpu else None
+        self.exchanges = 0
+
+    def _handle(self):
+        return self.stream.cuda_stream if self.stream is not None else 0
 
     def _buffers(self):
         n = self.ctx.halo_bytes() // 4
         if self.bufs is None or n != self.nfloats:
+            torch = self.torch
+            if self.on_gpu and self.bufs is not None:
+                torch.cuda.synchronize()       # a launch may still be reading the old buffers (the layout changes rarely)
             self.nfloats = n
-            self.bufs = [self.torch.empty(max(n, 1), dtype=self.torch.float32, device=self.device) for _ in range(4)]
+            self.bufs = [torch.zeros(max(n, 1), dtype=torch.float32, device=self.device) for _ in range(4)]
             self.staged = None
             if str(self.comm_device) != str(self.device):
-                self.staged = [self.torch.empty(max(n, 1), dtype=self.torch.float32, device=self.comm_device) for _ in range(4)]
+                self.staged = [torch.zeros(max(n, 1), dtype=torch.float32, device=self.comm_device, pin_memory=self.on_gpu) for _ in range(4)]
         return self.bufs
 
-    def exchange(self):
+    def _ops(self, send_prev, send_next, recv_prev, recv_next):
+        dist, rank, nranks = self.dist, self.rank, self.nranks
+        prev, nxt = (rank - 1) % nranks, (rank + 1) % nranks
+        return [dist.P2POp(dist.isend, send_prev, prev, tag=0), dist.P2POp(dist.isend, send_next, nxt, tag=1),
+                dist.P2POp(dist.irecv, recv_next, nxt, tag=0),    # what the next rank addressed to ITS prev (me)
+                dist.P2POp(dist.irecv, recv_prev, prev, tag=1)]   # what the previous rank addressed to ITS next (me)
+
+    def start(self):
         to_prev, to_next, from_prev, from_next = self._buffers()
+        self.works, self.copied = None, None
         if self.nranks < 2 or self.nfloats == 0:
             return
-        dist, rank, nranks = self.dist, self.rank, self.nranks
-        self.ctx.halo_export(to_prev.data_ptr(), to_next.data_ptr())      # synchronous: the rows are in the buffers on return
-        prev, nxt = (rank - 1) % nranks, (rank + 1) % nranks
-        s_prev, s_next, r_prev, r_next = (to_prev, to_next, from_prev, from_next) if self.staged is None else self.staged
-        if self.staged is not None:
-            s_prev.copy_(to_prev)
-            s_next.copy_(to_next)
-        ops = [dist.P2POp(dist.isend, s_prev, prev, tag=0), dist.P2POp(dist.isend, s_next, nxt, tag=1),
-               dist.P2POp(dist.irecv, r_next, nxt, tag=0),    # what the next rank addressed to ITS prev (me)
-               dist.P2POp(dist.irecv, r_prev, prev, tag=1)]   # what the previous rank addressed to ITS next (me)
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-        if self.staged is not None:
-            from_prev.copy_(r_prev)
-            from_next.copy_(r_next)
-        if str(self.device) != "cpu":
-            self.torch.cuda.synchronize()
-        self.ctx.halo_import(from_prev.data_ptr(), from_next.data_ptr())
+        torch = self.torch
+        self.ctx.halo_pack(to_prev.data_ptr(), to_next.data_ptr())
+        self.ctx.stream_wait_context(self._handle())     # also orders this frame's receives after the last frame's unpack
+        if self.staged is None:
+            if self.on_gpu:
+                with torch.cuda.stream(self.stream):
+                    self.works = self.dist.batch_isend_irecv(self._ops(to_prev, to_next, from_prev, from_next))
+            else:
+                self.works = self.dist.batch_isend_irecv(self._ops(to_prev, to_next, from_prev, from_next))
+        else:   # copies to pinned host memory, asynchronous; finish() waits for them
+            with torch.cuda.stream(self.stream):
+                self.staged[0].copy_(to_prev, non_blocking=True)
+                self.staged[1].copy_(to_next, non_blocking=True)
+                self.copied = torch.cuda.Event()
+                self.copied.record(self.stream)
+
+    def finish(self):
+        to_prev, to_next, from_prev, from_next = self.bufs
+        if self.nranks < 2 or self.nfloats == 0:
+            return
+        torch = self.torch
+        if self.staged is None:
+            if self.on_gpu:
+                with torch.cuda.stream(self.stream):
+                    for w in self.works:
+                        w.wait()                 # RCCL: the communication stream waits, not the host
+            else:
+                for w in self.works:
+                    w.wait()
+        else:
+            s_prev, s_next, r_prev, r_next = self.staged
+            self.copied.synchronize()
+            for w in self.dist.batch_isend_irecv(self._ops(s_prev, s_next, r_prev, r_next)):
+                w.wait()
+            with torch.cuda.stream(self.stream):
+                from_prev.copy_(r_prev, non_blocking=True)
+                from_next.copy_(r_next, non_blocking=True)
+        self.ctx.context_wait_stream(self._handle())
+        self.ctx.halo_unpack(from_prev.data_ptr(), from_next.data_ptr())
+        self.exchanges += 1
+
+    def exchange(self):
+        self.start()
+        self.finish()
 
 
 def exchange_halo(ctx, dist, rank, nranks, device, torch):
@@ -103,13 +214,33 @@ def exchange_halo(ctx, dist, rank, nranks, device, torch):
     HaloExchange(ctx, dist, rank, nranks, device, torch).exchange()
 
 
-def render_frame(ctx, dist, rank, nranks, device, torch, radius, halo=None):
+def finish_frame(ctx, nranks, radius, halo, overlap=True, extra_flags=0):
+    """What follows a frame's TRACE | TEMPORAL on a rank: the halo exchange and the denoise stage, overlapped.
+    radius 0: the denoise stage has no window (and may have been fused into the temporal pass already); the exchange still runs —
+    the next frame's temporal stage reads the neighbours' history rows.  extra_flags: e.g. TIMED."""
+    if nranks < 2:
+        ctx.render_stage(DENOISE | extra_flags)
+        return
+    if radius == 0:
+        ctx.render_stage(DENOISE | extra_flags)
+        halo.exchange()
+    elif overlap:
+        halo.start()
+        ctx.render_stage(DENOISE_INTERIOR | extra_flags)
+        halo.finish()
+        ctx.render_stage(DENOISE_EDGE | extra_flags)
+    else:
+        halo.exchange()
+        ctx.render_stage(DENOISE | extra_flags)
+
+
+def render_frame(ctx, dist, rank, nranks, device, torch, radius, halo=None, overlap=True):
     """One frame of Context::render (src/context.rs:2004-2075) on a rank: trace -> temporal -> [halo] -> denoise.
     halo: a HaloExchange to re-use across frames (one is made for the call otherwise)."""
     ctx.render(TRACE | TEMPORAL)
-    if nranks > 1 and radius > 0:
-        (halo or HaloExchange(ctx, dist, rank, nranks, device, torch)).exchange()
-    ctx.render_stage(DENOISE)
+    if nranks > 1 and halo is None:
+        halo = HaloExchange(ctx, dist, rank, nranks, device, torch)
+    finish_frame(ctx, nranks, radius, halo, overlap)
 
 
 def gather_image(local_rows_img, layout, rank, dist, torch, device):

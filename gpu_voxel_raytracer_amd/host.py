@@ -43,6 +43,8 @@ E_VOX_MATERIAL, E_VOX_NOMATL, E_VOX_NOMODEL, E_IO, E_SCENE, E_NOSCENE, E_NOISE =
 SAMPLED_COLOR, NORMAL_DEPTH, ALBEDO_NODE, ACCUM_COLOR, DENOISED = range(5)
 # render flags
 TRACE, TEMPORAL, DENOISE, ALL, TIMED = 1, 2, 4, 7, 8
+DENOISE_INTERIOR, DENOISE_EDGE = 16, 32   # the denoise stage in two launches around a halo exchange (vxrt.h)
+FEATURE_VARIANTS = 1                      # vxrt_build_features: tracers 2 / 3 / 5 and the wide scene records are in the library
 
 NOISE_LEN = 512 * 128 * 128
 DEFAULT_NOISE_SEED = 0x5EED0001
@@ -102,10 +104,17 @@ class Stats(C.Structure):
                 ("timed_launches", C.c_uint64), ("scene_bytes", C.c_uint64), ("noise_bytes", C.c_uint64), ("local_rows", C.c_uint32),
                 ("octree_depth", C.c_uint32), ("octree_nodes", C.c_uint64), ("wide_nodes", C.c_uint64), ("scene_format", C.c_uint32),
                 ("reserved0", C.c_uint32), ("queue_bytes", C.c_uint64),
-                ("queue_overflow_paths", C.c_uint64)]
+                ("queue_overflow_paths", C.c_uint64), ("halo_pack_ms", C.c_double), ("halo_unpack_ms", C.c_double),
+                ("halo_exchanges", C.c_uint64)]
 
 
-OPT_DENOISE_MODE, OPT_TAIL_CAPACITY, OPT_SCENE_FORMAT = 1, 2, 3
+OPT_DENOISE_MODE, OPT_TAIL_CAPACITY, OPT_SCENE_FORMAT, OPT_HALO_ROWS = 1, 2, 3, 4
+
+
+class HaloInfo(C.Structure):
+    """vxrt_halo_info (include/vxrt.h)."""
+    _fields_ = [("rows", C.c_uint32), ("slots", C.c_uint32), ("bytes_per_pixel", C.c_uint32), ("interior_tile_rows", C.c_uint32),
+                ("edge_tile_rows", C.c_uint32), ("reserved", C.c_uint32), ("message_bytes", C.c_uint64)]
 
 
 class Camera:
@@ -139,9 +148,19 @@ def lib():
         L.vxrt_last_error.restype = C.c_char_p
         L.vxrt_status_string.restype = C.c_char_p
         L.vxrt_abi_version.restype = C.c_uint32
+        L.vxrt_build_features.restype = C.c_uint32
         L.vxrt_status_string.argtypes = [C.c_int]
         _LIB = L
     return _LIB
+
+
+def build_features():
+    """vxrt_build_features: FEATURE_* bits of the loaded library."""
+    return int(lib().vxrt_build_features())
+
+
+def has_variants():
+    return bool(build_features() & FEATURE_VARIANTS)
 
 
 def _p(a):
@@ -472,15 +491,44 @@ class Context:
     def reset_stats(self):
         _check(lib().vxrt_reset_stats(self._h), "vxrt_reset_stats")
 
-    # -- multi-GPU denoise halo ------------------------------------------------------------------------
+    # -- multi-GPU halo (include/vxrt.h "halo") --------------------------------------------------------
+    def _push_denoise(self):
+        # the halo's row count follows the denoise radius: the library must know the radius the caller has set
+        _check(lib().vxrt_set_denoise(self._h, C.byref(self.denoise_uniforms)), "vxrt_set_denoise")
+
+    def halo_info(self):
+        self._push_denoise()
+        info = HaloInfo()
+        _check(lib().vxrt_halo_info_get(self._h, C.byref(info)), "vxrt_halo_info_get")
+        return info
+
     def halo_bytes(self):
+        self._push_denoise()
         n = C.c_size_t(0)
         _check(lib().vxrt_halo_bytes(self._h, C.byref(n)), "vxrt_halo_bytes")
         return n.value
 
+    def halo_pack(self, dev_to_prev, dev_to_next):
+        """One pack launch on the context's stream; returns at once (order the communication with stream_wait_context)."""
+        _check(lib().vxrt_halo_pack(self._h, C.c_void_p(dev_to_prev), C.c_void_p(dev_to_next)), "vxrt_halo_pack")
+
+    def halo_unpack(self, dev_from_prev, dev_from_next):
+        """One unpack launch on the context's stream; returns at once."""
+        _check(lib().vxrt_halo_unpack(self._h, C.c_void_p(dev_from_prev), C.c_void_p(dev_from_next)), "vxrt_halo_unpack")
+
+    def stream_wait_context(self, stream):
+        """`stream` (a raw hipStream_t, e.g. torch.cuda.Stream.cuda_stream; 0 = the default stream) waits for what the context has enqueued."""
+        _check(lib().vxrt_stream_wait_context(self._h, C.c_void_p(stream)), "vxrt_stream_wait_context")
+
+    def context_wait_stream(self, stream):
+        """The context's stream waits for what `stream` has enqueued so far."""
+        _check(lib().vxrt_context_wait_stream(self._h, C.c_void_p(stream)), "vxrt_context_wait_stream")
+
     def halo_export(self, dev_to_prev, dev_to_next):
+        """Synchronous halo_pack."""
         _check(lib().vxrt_halo_export(self._h, C.c_void_p(dev_to_prev), C.c_void_p(dev_to_next)), "vxrt_halo_export")
 
     def halo_import(self, dev_from_prev, dev_from_next):
+        """Synchronous halo_unpack."""
         _check(lib().vxrt_halo_import(self._h, C.c_void_p(dev_from_prev), C.c_void_p(dev_from_next)),
                "vxrt_halo_import")

@@ -130,7 +130,13 @@ enum {                        /* vxrt_render flags: which of the three dispatche
     VXRT_TEMPORAL = 2,
     VXRT_DENOISE = 4,
     VXRT_ALL = 7,
-    VXRT_TIMED = 8            /* bracket every kernel with HIP events (read back through vxrt_get_stats) */
+    VXRT_TIMED = 8,           /* bracket every kernel with HIP events (read back through vxrt_get_stats) */
+    /* The denoise stage in two launches around a halo exchange (multi-GPU, see "halo" below): the 16x16 tiles whose
+     * (2r+1)^2 window (denoise.comp:51-57) stays inside this context's rows, and the tiles that read rows of a neighbour.
+     * INTERIOR needs no halo (it runs while the messages travel), EDGE needs vxrt_halo_unpack first; together they write
+     * exactly what VXRT_DENOISE writes.  On a single-GPU context every tile is interior. */
+    VXRT_DENOISE_INTERIOR = 16,
+    VXRT_DENOISE_EDGE = 32
 };
 
 typedef struct vxrt_stats {
@@ -153,6 +159,9 @@ typedef struct vxrt_stats {
     uint64_t queue_bytes;     /* device bytes of the tracer's path queues (sized by need for tracers 4 / 5)             */
     uint64_t queue_overflow_paths; /* paths that found their queue shard full and were followed by the head kernel
                                  instead (same image; the queues grow before the stream's next launch)               */
+    double halo_pack_ms;      /* summed kernel time of the halo pack / unpack launches (always timed) ...               */
+    double halo_unpack_ms;
+    uint64_t halo_exchanges;  /* ... and how many unpacks that was                                                      */
 } vxrt_stats;
 
 /* Run-time options (none of them changes what a frame means; defaults are the reference's behaviour).
@@ -165,8 +174,14 @@ typedef struct vxrt_stats {
  *   VXRT_OPT_SCENE_FORMAT  which scene records tracers 1 and 4 walk: 0 (default) the 8-byte records, one tree level each; 1 the wide
  *                          records, two levels per 16-byte record (half the dependent loads of a descent, ~35 % more instructions
  *                          per step: slower on MI355X for every scene measured, kept for comparison).  Same image either way.
- *                          Must be chosen before the scene is set (the wide records are built with the scene).              */
-typedef enum vxrt_option { VXRT_OPT_DENOISE_MODE = 1, VXRT_OPT_TAIL_CAPACITY = 2, VXRT_OPT_SCENE_FORMAT = 3 } vxrt_option;
+ *                          Must be chosen before the scene is set (the wide records are built with the scene).  Needs a
+ *                          library built with -DVXRT_VARIANTS=1 (vxrt_build_features); the default build refuses 1.
+ *   VXRT_OPT_HALO_ROWS     multi-GPU: the fewest rows beyond each band edge that a halo exchange carries (default 1).  The exchange
+ *                          carries max(denoise radius, this) rows; temporal.comp's reprojection (:85-113) sees that many rows of the
+ *                          neighbouring bands' history, so set it to the largest vertical image motion per frame, in rows, that
+ *                          should keep its history across a band edge (up to band_rows); beyond it a pixel is treated as
+ *                          disoccluded, the reference's rule for a reprojection that leaves the screen (temporal.comp:92).   */
+typedef enum vxrt_option { VXRT_OPT_DENOISE_MODE = 1, VXRT_OPT_TAIL_CAPACITY = 2, VXRT_OPT_SCENE_FORMAT = 3, VXRT_OPT_HALO_ROWS = 4 } vxrt_option;
 int vxrt_set_option(vxrt_ctx* ctx, vxrt_option option, uint32_t value);
 
 /* ---- context: replaces Context::new / create_bindings / resize (src/context.rs:595-660, 936-1016,
@@ -221,15 +236,50 @@ int vxrt_device_image(vxrt_ctx* ctx, vxrt_image which, void** device_ptr, size_t
 int vxrt_get_stats(vxrt_ctx* ctx, vxrt_stats* out);
 int vxrt_reset_stats(vxrt_ctx* ctx);
 
-/* ---- denoise halo for multi-GPU: the (2r+1)^2 window of denoise.comp:51-57 reaches
- *      r rows into the neighbouring bands, which live on other GPUs.  export packs, for every band
- *      edge of this context, the r boundary rows of (accumulated colour, normal/depth, albedo/node);
- *      import takes the rows that lie just outside this context's bands.  Buffers are DEVICE memory
- *      (the caller moves them with RCCL send/recv).  Layout: see DESIGN.md "halo". ------------------ */
-int vxrt_halo_bytes(vxrt_ctx* ctx, size_t* bytes_per_neighbour);
+/* ---- halo for multi-GPU.  A context renders interleaved bands of rows; the (2r+1)^2 window of
+ *      denoise.comp:51-57 and the reprojection of temporal.comp:85-113 read rows of the bands above and below each of its
+ *      own, which live on rank - 1 and rank + 1.  After a frame's temporal stage each rank sends TWO messages (to rank - 1:
+ *      the top `rows` rows of each of its bands; to rank + 1: the bottom `rows` rows) and receives two; rows = max(denoise
+ *      radius, VXRT_OPT_HALO_ROWS), at most band_rows.  A message holds, per pixel, 36 bytes in three planes over
+ *      (slot = the receiver's local band, row, x):  A float4 (r, g, b, depth) | B float4 (normal, material id) | C float
+ *      (blending factor of the accumulated colour)  — what denoise.comp reads of a neighbour's pixel plus what temporal.comp
+ *      reads of it.  Buffers are DEVICE memory of message_bytes each, owned by the caller (who moves them with RCCL
+ *      send/recv).  The frame loop, with the exchange overlapped (gpu_voxel_raytracer_amd/distributed.py):
+ *
+ *        vxrt_render(TRACE | TEMPORAL)
+ *        vxrt_halo_pack(to_prev, to_next)              one kernel on the context's stream
+ *        vxrt_stream_wait_context(comm_stream)         the communication stream waits for it (event, no host wait)
+ *        ... send to_prev / to_next, receive from_prev / from_next on comm_stream ...
+ *        vxrt_render(VXRT_DENOISE_INTERIOR)            runs while the messages travel
+ *        vxrt_context_wait_stream(comm_stream)         the context's stream waits for the receives (event)
+ *        vxrt_halo_unpack(from_prev, from_next)        one kernel: both messages -> the context's halo store
+ *        vxrt_render(VXRT_DENOISE_EDGE)
+ *
+ *      The unpacked rows also serve the NEXT frame's temporal stage as the neighbours' history.  from_prev is what the
+ *      previous rank sent as its to_next, from_next what the next rank sent as its to_prev. ------------------------------ */
+typedef struct vxrt_halo_info {
+    uint32_t rows;              /* rows per band edge that the next exchange carries (0: single-GPU context, nothing to exchange) */
+    uint32_t slots;             /* bands a message has room for: ceil(bands / nranks)                                    */
+    uint32_t bytes_per_pixel;   /* 36                                                                                    */
+    uint32_t interior_tile_rows, edge_tile_rows;   /* rows of 16x16 denoise tiles that need no halo / that read it      */
+    uint32_t reserved;
+    uint64_t message_bytes;     /* size of each of the four buffers (>= slots * rows * width * 36, whole 256-byte lines) */
+} vxrt_halo_info;
+int vxrt_halo_info_get(vxrt_ctx* ctx, vxrt_halo_info* out);
+int vxrt_halo_bytes(vxrt_ctx* ctx, size_t* bytes_per_neighbour);     /* = vxrt_halo_info.message_bytes */
+/* Asynchronous: one launch on the context's stream each, return at once.  The buffers must stay untouched until the launch
+ * has run: order the communication against it with the two calls below. */
+int vxrt_halo_pack(vxrt_ctx* ctx, void* dev_to_prev, void* dev_to_next);
+int vxrt_halo_unpack(vxrt_ctx* ctx, const void* dev_from_prev, const void* dev_from_next);
+/* `stream`: a hipStream_t of the context's device (NULL = the legacy default stream).  vxrt_stream_wait_context: work
+ * enqueued on `stream` after this call starts only when everything enqueued on the context so far has finished.
+ * vxrt_context_wait_stream: the context's stages enqueued after this call start only when everything enqueued on `stream`
+ * so far has finished.  Events only; the host does not wait.  (Also what a zero-copy consumer of vxrt_device_image needs.) */
+int vxrt_stream_wait_context(vxrt_ctx* ctx, void* stream);
+int vxrt_context_wait_stream(vxrt_ctx* ctx, void* stream);
+/* Synchronous forms: pack / unpack and wait for the launch (the buffers are borrowed for the call only). */
 int vxrt_halo_export(vxrt_ctx* ctx, void* dev_to_prev, void* dev_to_next);
 int vxrt_halo_import(vxrt_ctx* ctx, const void* dev_from_prev, const void* dev_from_next);
-/* Both calls return after their device copies have finished: the caller's buffers are borrowed for the call only. */
 
 /* ---- host-side scene preparation, callable without a GPU (src/vox.rs, src/context.rs:710-834,
  *      913-933, src/camera.rs).  Counts are returned through *n; nothing is written past cap. ------ */
@@ -309,6 +359,11 @@ int vxrt_debug_tile_costs(vxrt_ctx* ctx, uint32_t* out, size_t n);
 const char* vxrt_status_string(int status);
 const char* vxrt_last_error(void);               /* thread-local detail of the last failing call */
 uint32_t vxrt_abi_version(void);
+/* What this build of the library contains: VXRT_FEATURE_VARIANTS = it was compiled with -DVXRT_VARIANTS=1 and also holds the
+ * schedules and the scene format that measured slower on MI355X and are kept for comparison (tracers 2, 3, 5; the wide scene
+ * records).  The default build holds tracers 1 and 4 over the 8-byte records and refuses the others with VXRT_E_INVALID. */
+enum { VXRT_FEATURE_VARIANTS = 1 };
+uint32_t vxrt_build_features(void);
 
 #ifdef __cplusplus
 }

@@ -5,13 +5,9 @@ set -e
 tag=$1; shift
 cd "$(dirname "$0")/.."
 python - "$tag" "$@" <<'PY'
-import sys, shutil
+import sys
 from gpu_voxel_raytracer_amd import _build
 tag, flags = sys.argv[1], sys.argv[2:]
-keep = _build.LIB + ".keep"
-shutil.copy(_build.LIB, keep)
-_build.build(force=True, extra_flags=flags)
-shutil.move(_build.LIB, _build.LIB.replace("libvxrt.so", f"libvxrt_{tag}.so"))
-shutil.move(keep, _build.LIB)
+_build.build(extra_flags=flags, out=_build.LIB.replace("libvxrt.so", f"libvxrt_{tag}.so"))
 print("built", tag, flags)
 PY

@@ -43,6 +43,16 @@ def scenes():
     return s
 
 
+def require_variants(H, env=None, tracer=None, wide=None):
+    """Skip a case that needs a schedule or scene format the default library does not hold (tracers 2 / 3 / 5, the wide records):
+    they are compiled only with -DVXRT_VARIANTS=1 (scripts/test_variants.sh runs these cases over that build)."""
+    env = env or {}
+    needs = (str(env.get("VXRT_TRACE_VARIANT", "")) in ("2", "3", "5") or str(env.get("VXRT_WIDE", "")) == "1" or
+             str(tracer) in ("2", "3", "5") or str(wide) in ("1", "True", "wide"))
+    if needs and not H.has_variants():
+        pytest.skip("needs libvxrt built with -DVXRT_VARIANTS=1 (scripts/test_variants.sh)")
+
+
 def have_reference():
     return os.path.isdir(os.path.join(REFERENCE, "vox"))
 

@@ -16,9 +16,11 @@ def main():
     import torch
     import torch.distributed as dist
     from gpu_voxel_raytracer_amd import ACCUM_COLOR, ALL, DENOISED, SAMPLED_COLOR, Camera, Context, distributed, scenes
+    from gpu_voxel_raytracer_amd.host import OPT_HALO_ROWS
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    w, h, bounces, radius, band = 320, 200, 3, int(os.environ.get("VXRT_TEST_RADIUS", "3")), 16
+    w, h, bounces, radius = 320, 200, 3, int(os.environ.get("VXRT_TEST_RADIUS", "3"))
+    band, halo_rows = int(os.environ.get("VXRT_TEST_BAND", "16")), int(os.environ.get("VXRT_TEST_HALO_ROWS", "1"))
     pos, mrgb, size = scenes.load_scene("castle")
     p0, d0, fov = scenes.close_camera(size)
     layout = distributed.BandLayout(w, h, world, band, radius=radius)
@@ -32,6 +34,7 @@ def main():
         ctx = Context(w, h, device=0, max_bounces=bounces, rank=rank, nranks=world, band_rows=band)
         ctx.recreate_octree(pos, mrgb)
         ctx.denoise_uniforms.radius = radius
+        ctx.set_option(OPT_HALO_ROWS, halo_rows)
         halo = distributed.HaloExchange(ctx, dist, rank, world, torch.device("cuda", 0), torch, comm_device="cpu")
         for cp, cd in path:
             ctx.camera = Camera(cp, cd, fov)

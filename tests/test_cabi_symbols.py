@@ -20,7 +20,7 @@ def test_every_declared_symbol_is_exported(H):
     lib = H.lib()
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.vxrt_abi_version() == 3
+    assert lib.vxrt_abi_version() == 4
     assert lib.vxrt_status_string(-13) == b"unexpected end of file"
 
 

@@ -14,45 +14,67 @@ from conftest import ROOT
 
 
 class OracleBandContext:
-    """Stand-in with host.Context's halo/render interface; mirrors vxrt_halo_export/import (vxrt_api.hip)."""
+    """Stand-in with host.Context's halo / render interface; mirrors csrc/api_halo.hip + csrc/halo.hip (message layout:
+    distributed.BandLayout.message_views) with the oracle as the denoiser."""
 
-    def __init__(self, O, layout, rank, radius, full_accum, full_nd, full_alb, cam16):
+    def __init__(self, O, layout, rank, radius, full_accum, full_nd, full_alb, cam16, min_rows=1):
         self.O, self.layout, self.rank, self.r = O, layout, rank, radius
         self.rows = layout.rows(rank)
         self.imgs = [a[self.rows].copy() for a in (full_accum, full_nd, full_alb)]   # only OUR rows are known
         self.cam16 = cam16
+        self.hrows = layout.halo_rows(radius, min_rows)
         self.halo = None
+        self.denoised = np.zeros_like(self.imgs[0])
+        self.log = []
 
     def halo_bytes(self):
-        return self.layout.halo_floats(self.r) * 4
+        return self.layout.message_floats(self.hrows) * 4
 
     def _view(self, ptr):
-        n = self.layout.halo_floats(self.r)
-        return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_float)), (n,)).reshape(
-            self.layout.max_bands(), self.r, 3, self.layout.width, 4)
+        n = self.layout.message_floats(self.hrows)
+        return self.layout.message_views(np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_float)), (n,)), self.hrows)
 
-    def halo_export(self, to_prev, to_next):
-        L, r = self.layout, self.r
+    def stream_wait_context(self, stream):
+        self.log.append("stream_wait_context")
+
+    def context_wait_stream(self, stream):
+        self.log.append("context_wait_stream")
+
+    def halo_pack(self, to_prev, to_next):
+        self.log.append("pack")
+        L, H = self.layout, self.hrows
+        accum, nd, alb = self.imgs
+        mat = ((alb[..., 3].view(np.int32) >> 24) & 0xff).view(np.float32)        # denoise.comp:67
+
+        def put(views, slot, k, lrow):
+            A, B, C = views
+            A[slot, k, :, :3] = accum[lrow, :, :3]; A[slot, k, :, 3] = nd[lrow, :, 3]
+            B[slot, k, :, :3] = nd[lrow, :, :3]; B[slot, k, :, 3] = mat[lrow]
+            C[slot, k] = accum[lrow, :, 3]
         vp, vn = self._view(to_prev), self._view(to_next)
         for lb, gb in enumerate(L.local_bands(self.rank)):
             y0 = gb * L.band_rows
             nrows = min(L.band_rows, L.height - y0)
             if gb >= 1:
-                for k in range(min(r, nrows)):
-                    for im in range(3):
-                        vp[(gb - 1) // L.nranks, k, im] = self.imgs[im][lb * L.band_rows + k]
+                for k in range(min(H, nrows)):
+                    put(vp, (gb - 1) // L.nranks, k, lb * L.band_rows + k)
             if nrows == L.band_rows and (gb + 1) * L.band_rows < L.height:
-                for k in range(r):
-                    for im in range(3):
-                        vn[(gb + 1) // L.nranks, k, im] = self.imgs[im][lb * L.band_rows + L.band_rows - r + k]
+                for k in range(H):
+                    put(vn, (gb + 1) // L.nranks, k, lb * L.band_rows + L.band_rows - H + k)
 
-    def halo_import(self, from_prev, from_next):
-        self.halo = (self._view(from_prev).copy(), self._view(from_next).copy())
+    def halo_unpack(self, from_prev, from_next):
+        self.log.append("unpack")
+        self.halo = tuple(tuple(v.copy() for v in self._view(p)) for p in (from_prev, from_next))
 
     def render_stage(self, flags):
-        # rebuild, for each of our bands, the band + its halo rows, denoise that strip with the oracle
-        L, r, O = self.layout, self.r, self.O
-        out = np.zeros_like(self.imgs[0])
+        # rebuild, for each of our bands, the band + its halo rows, denoise that strip with the oracle; keep the rows of the
+        # tile rows the flags select (DENOISE: all; DENOISE_INTERIOR / DENOISE_EDGE: distributed.BandLayout.tile_rows)
+        from gpu_voxel_raytracer_amd import distributed as D
+        flags &= D.DENOISE | D.DENOISE_INTERIOR | D.DENOISE_EDGE
+        self.log.append({D.DENOISE: "denoise", D.DENOISE_INTERIOR: "interior", D.DENOISE_EDGE: "edge"}[flags])
+        L, r, H, O = self.layout, self.r, self.hrows, self.O
+        interior, edge = L.tile_rows(self.rank)
+        chosen = set(interior + edge) if flags == D.DENOISE else set(interior if flags == D.DENOISE_INTERIOR else edge)
         du = O.Denoise.default()
         du.radius = r
         for lb, gb in enumerate(L.local_bands(self.rank)):
@@ -62,16 +84,22 @@ class OracleBandContext:
             strip = [np.zeros((L.height, L.width, 4), np.float32) for _ in range(3)]   # full-frame canvas
             for im in range(3):
                 strip[im][y0:y0 + nrows] = self.imgs[im][lb * L.band_rows: lb * L.band_rows + nrows]
-                for y in range(top, y0):
-                    strip[im][y] = self.halo[0][lb, y - (y0 - r), im]
-                for y in range(y0 + nrows, bot):
-                    strip[im][y] = self.halo[1][lb, y - (y0 + L.band_rows), im]
+            if flags != D.DENOISE_INTERIOR:     # the interior launch runs BEFORE the unpack: it must not need the halo
+                for side, ys in ((0, range(top, y0)), (1, range(y0 + nrows, bot))):
+                    A, B, C = self.halo[side]
+                    for y in ys:
+                        k = y - (y0 - H) if side == 0 else y - (y0 + L.band_rows)
+                        strip[0][y, :, :3] = A[lb, k, :, :3]; strip[0][y, :, 3] = C[lb, k]
+                        strip[1][y, :, :3] = B[lb, k, :, :3]; strip[1][y, :, 3] = A[lb, k, :, 3]
+                        strip[2][y, :, 3] = (B[lb, k, :, 3].view(np.int32) << 24).view(np.float32)   # only the material id is read
             den = O.denoise(strip[0], strip[1], strip[2], self.cam16, du, nthreads=2)
-            out[lb * L.band_rows: lb * L.band_rows + nrows] = den[y0:y0 + nrows]
-        self.denoised = out
+            for t in range(nrows // 16 + (1 if nrows % 16 else 0)):
+                if lb * (L.band_rows // 16) + t in chosen:
+                    lo, hi = t * 16, min(t * 16 + 16, nrows)
+                    self.denoised[lb * L.band_rows + lo: lb * L.band_rows + hi] = den[y0 + lo:y0 + hi]
 
 
-def _worker(rank, world, port, w, h, radius, q):
+def _worker(rank, world, port, w, h, radius, band, overlap, q):
     import sys
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -91,18 +119,22 @@ def _worker(rank, world, port, w, h, radius, q):
         u.set_camera(cam[0], O.camera_axis_scaled(cam[0], cam[1], cam[2], w, h))
         u.frame_number = 1
         cam16 = u.camera16()
-        layout = D.BandLayout(w, h, world, 16)
+        layout = D.BandLayout(w, h, world, band)
         # each rank traces ONLY its rows (pixel coordinates are frame-absolute)
         mine = layout.rows(rank)
         color = np.zeros((h, w, 4), np.float32); nd = np.zeros_like(color); alb = np.zeros_like(color)
         for gb in layout.local_bands(rank):
-            y0, y1 = gb * 16, min(gb * 16 + 16, h)
+            y0, y1 = gb * band, min(gb * band + band, h)
             c, n_, a, _ = O.trace(octree, noise, u, w, h, 3, crop=(0, y0, w, y1), nthreads=2)
             color[y0:y1], nd[y0:y1], alb[y0:y1] = c, n_, a
         accum = O.temporal(color, nd, np.zeros_like(color), np.zeros_like(nd), cam16, cam16, O.Temporal.default(), False, nthreads=2)
         ctx = OracleBandContext(O, layout, rank, radius, accum, nd, alb, cam16)
-        D.exchange_halo(ctx, dist, rank, world, "cpu", torch)
-        ctx.render_stage(D.DENOISE)
+        halo = D.HaloExchange(ctx, dist, rank, world, "cpu", torch)
+        D.finish_frame(ctx, world, radius, halo, overlap=overlap)
+        want_log = (["pack", "stream_wait_context", "interior", "context_wait_stream", "unpack", "edge"] if overlap else
+                    ["pack", "stream_wait_context", "context_wait_stream", "unpack", "denoise"])
+        assert ctx.log == want_log, ctx.log
+        assert ctx.halo_bytes() == layout.message_floats(layout.halo_rows(radius)) * 4 >= layout.max_bands() * layout.halo_rows(radius) * w * 36
         full = D.gather_image(ctx.denoised, layout, rank, dist, torch, "cpu")
         if rank == 0:
             # single-process reference
@@ -120,13 +152,13 @@ def _worker(rank, world, port, w, h, radius, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("w,h,radius", [(96, 72, 3), (64, 50, 8)])
-def test_two_rank_gloo_halo_exchange(O, w, h, radius):
+@pytest.mark.parametrize("w,h,radius,band,overlap", [(96, 72, 3, 16, True), (64, 50, 8, 16, False), (48, 150, 4, 32, True)])
+def test_two_rank_gloo_halo_exchange(O, w, h, radius, band, overlap):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mpctx = mp.get_context("spawn")
     q = mpctx.Queue()
-    procs = [mpctx.Process(target=_worker, args=(r, 2, port, w, h, radius, q)) for r in range(2)]
+    procs = [mpctx.Process(target=_worker, args=(r, 2, port, w, h, radius, band, overlap, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = q.get(timeout=240)

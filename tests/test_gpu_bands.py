@@ -20,9 +20,13 @@ def hip():
     return lib
 
 
-@pytest.mark.parametrize("nranks,w,h,radius", [(2, 128, 80, 3), (3, 96, 100, 8), (4, 160, 72, 1), (8, 64, 200, 8), (5, 80, 40, 2)])
-def test_bands_and_halo_equal_single_context(H, scenes, noise, nranks, w, h, radius):
-    from gpu_voxel_raytracer_amd import ALL, DENOISE, TEMPORAL, TRACE, Camera, Context
+@pytest.mark.parametrize("nranks,w,h,radius,band,split", [(2, 128, 80, 3, 16, False), (3, 96, 100, 8, 16, True), (4, 160, 72, 1, 16, False),
+                                                          (8, 64, 200, 8, 16, False), (5, 80, 40, 2, 16, True), (2, 100, 300, 8, 64, True),
+                                                          (3, 64, 250, 4, 32, True), (2, 72, 130, 8, 48, False)])
+def test_bands_and_halo_equal_single_context(H, scenes, noise, nranks, w, h, radius, band, split):
+    """split: the denoise stage in two launches around the exchange (DENOISE_INTERIOR before the unpack, DENOISE_EDGE after)."""
+    from gpu_voxel_raytracer_amd import ALL, DENOISE, DENOISE_EDGE, DENOISE_INTERIOR, TEMPORAL, TRACE, Camera, Context
+    from gpu_voxel_raytracer_amd.distributed import BandLayout
     pos, mrgb, size = scenes.load_scene("castle")
     cam = Camera(*scenes.close_camera(size))
     rt = hip()
@@ -34,12 +38,19 @@ def test_bands_and_halo_equal_single_context(H, scenes, noise, nranks, w, h, rad
 
     with Context(w, h, max_bounces=3, noise=noise) as single:
         setup(single)
-        ctxs = [Context(w, h, max_bounces=3, noise=noise, rank=r, nranks=nranks, band_rows=16) for r in range(nranks)]
+        ctxs = [Context(w, h, max_bounces=3, noise=noise, rank=r, nranks=nranks, band_rows=band) for r in range(nranks)]
         try:
             for c in ctxs:
                 setup(c)
             rows = [c.local_rows() for c in ctxs]
             assert sorted(np.concatenate(rows).tolist()) == list(range(h))          # a partition of the frame
+            layout = BandLayout(w, h, nranks, band)
+            for r, c in enumerate(ctxs):      # the message layout and the tile split as distributed.py states them
+                info = c.halo_info()
+                interior, edge = layout.tile_rows(r)
+                assert (info.rows, info.slots, info.bytes_per_pixel) == (layout.halo_rows(radius), layout.max_bands(), 36)
+                assert info.message_bytes == layout.message_floats(info.rows) * 4 == c.halo_bytes()
+                assert (info.interior_tile_rows, info.edge_tile_rows) == (len(interior), len(edge))
             for frame in range(3):
                 single.render(ALL)
                 for c in ctxs:
@@ -54,11 +65,13 @@ def test_bands_and_halo_equal_single_context(H, scenes, noise, nranks, w, h, rad
                     rt.hipDeviceSynchronize()   # hipMemset is not ordered against the context's non-blocking stream
                     c.halo_export(p.value, n.value)
                     bufs[r] = (p, n)
+                    if split:
+                        c.render_stage(DENOISE_INTERIOR)           # needs nothing from the neighbours
                 for r, c in enumerate(ctxs):
                     from_prev = bufs[(r - 1) % nranks][1]      # what the previous rank addressed to its next
                     from_next = bufs[(r + 1) % nranks][0]      # what the next rank addressed to its prev
                     c.halo_import(from_prev.value, from_next.value)
-                    c.render_stage(DENOISE)
+                    c.render_stage(DENOISE_EDGE if split else DENOISE)
                 for c in ctxs:
                     c.sync()
                 for p, n in bufs.values():
@@ -78,13 +91,21 @@ def test_bands_and_halo_equal_single_context(H, scenes, noise, nranks, w, h, rad
 
 
 def test_multirank_denoise_without_halo_is_refused(H, scenes, noise):
-    from gpu_voxel_raytracer_amd import ALL, Camera, Context, VxrtError
+    from gpu_voxel_raytracer_amd import ALL, DENOISE, DENOISE_EDGE, DENOISE_INTERIOR, TEMPORAL, TRACE, Camera, Context, VxrtError
     pos, mrgb, size = scenes.load_scene("8x8x8")
     with Context(64, 64, rank=1, nranks=2, noise=noise) as ctx:
         ctx.recreate_octree(pos, mrgb)
         ctx.denoise_uniforms.radius = 2
         with pytest.raises(VxrtError):
             ctx.render(ALL)
+        ctx.render(TRACE | TEMPORAL)
+        ctx.render_stage(DENOISE_INTERIOR)                # the tiles that need no neighbour may run before the exchange
+        with pytest.raises(VxrtError, match="no halo"):
+            ctx.render_stage(DENOISE_EDGE)
+        with pytest.raises(VxrtError, match="no halo"):
+            ctx.render_stage(DENOISE)
+        with pytest.raises(VxrtError, match="does not combine"):
+            ctx.render_stage(DENOISE | DENOISE_EDGE)
         ctx.denoise_uniforms.radius = 0
         ctx.render(ALL)                                   # radius 0 needs no neighbours
     with pytest.raises(VxrtError):
@@ -130,3 +151,59 @@ def test_eight_row_bands_without_denoise_window(H, scenes, noise, nranks, w, h):
         finally:
             for c in ctxs:
                 c.close()
+
+
+@pytest.mark.parametrize("radius,halo_rows,band", [(0, 1, 16), (0, 4, 8), (2, 1, 16), (1, 16, 32)])
+def test_history_rows_cross_band_edges_without_a_denoise_window(H, scenes, noise, radius, halo_rows, band):
+    """The halo carries max(radius, VXRT_OPT_HALO_ROWS) rows, at least 1 by default, also with radius 0 (the reference's default): the
+    temporal stage of the next frame finds the neighbours' history there.  A camera at rest (whose reprojection still touches the next
+    row for the ~1 % of pixels where the divide rounds off the texel centre) and a slow drift (image motion below halo_rows rows per
+    frame) give the single-context frames bit for bit, accumulated colour included; without any history rows they would not."""
+    from gpu_voxel_raytracer_amd import ALL, DENOISE, TEMPORAL, TRACE, Camera, Context
+    from gpu_voxel_raytracer_amd.host import OPT_HALO_ROWS
+    w, h, nranks = 192, 208, 2
+    pos, mrgb, size = scenes.load_scene("castle")
+    p0, d0, fov = scenes.close_camera(size)
+    rt = hip()
+    step = np.float32(0.0004 * halo_rows) * np.array([0.3, 1.0, 0.0], np.float32)
+    for name, path in (("rest", [(p0, d0)] * 3), ("drift", [(p0 + np.float32(k) * step, d0) for k in range(4)])):
+        with Context(w, h, max_bounces=2, noise=noise) as single:
+            ctxs = [Context(w, h, max_bounces=2, noise=noise, rank=r, nranks=nranks, band_rows=band) for r in range(nranks)]
+            try:
+                for c in [single] + ctxs:
+                    c.recreate_octree(pos, mrgb)
+                    c.denoise_uniforms.radius = radius
+                for c in ctxs:
+                    c.set_option(OPT_HALO_ROWS, halo_rows)
+                rows = [c.local_rows() for c in ctxs]
+                for cp, cd in path:
+                    for c in [single] + ctxs:
+                        c.camera = Camera(cp, cd, fov)
+                    single.render(ALL)
+                    nbytes = None
+                    bufs = {}
+                    for r, c in enumerate(ctxs):
+                        c.render(TRACE | TEMPORAL | (DENOISE if radius == 0 else 0))
+                        nbytes = c.halo_bytes()
+                        assert c.halo_info().rows == max(radius, halo_rows)
+                        p, n = C.c_void_p(), C.c_void_p()
+                        assert rt.hipMalloc(C.byref(p), nbytes) == 0 and rt.hipMalloc(C.byref(n), nbytes) == 0
+                        c.halo_export(p.value, n.value)
+                        bufs[r] = (p, n)
+                    for r, c in enumerate(ctxs):
+                        c.halo_import(bufs[(r - 1) % nranks][1].value, bufs[(r + 1) % nranks][0].value)
+                        if radius > 0:
+                            c.render_stage(DENOISE)
+                    for c in ctxs:
+                        c.sync()
+                    for p, n in bufs.values():
+                        rt.hipFree(p); rt.hipFree(n)
+                    for img in (0, 3, 4):
+                        want = single.read(img)
+                        got = np.zeros_like(want)
+                        for c, rr in zip(ctxs, rows):
+                            got[rr] = c.read(img)
+                        assert_bits_equal(got, want, f"{name}: image {img}, radius {radius}, halo rows {halo_rows}")
+            finally:
+                for c in ctxs:
+                    c.close()

@@ -45,7 +45,7 @@ def test_config5_one_rank_of_the_8k_frame_vs_oracle(O, H, noise):
     u = oracle_uniforms(O, cam)
     results = {}
     # 0: what the library picks for a scene of this size; 1: all-in-one kernel; 4: head + compacted tail; "wide": the wide scene records
-    for tracer in (0, 1, 4, "wide"):
+    for tracer in (0, 1, 4) + (("wide",) if H.has_variants() else ()):
         with make_context(noise, 4 if tracer == "wide" else tracer, wide=tracer == "wide") as ctx:
             st = ctx.stats()
             assert (st.scene_format, st.wide_nodes > 30_000_000) == ((1, True) if tracer == "wide" else (0, False))
@@ -65,7 +65,7 @@ def test_config5_one_rank_of_the_8k_frame_vs_oracle(O, H, noise):
             results[tracer] = (one, rays_one, [ctx.read(i) for i in (SAMPLED_COLOR, NORMAL_DEPTH, ALBEDO_NODE, ACCUM_COLOR)], ctx.stats().rays, rows)
 
     one, rays_one, shown, rays_shown, rows = results[0]
-    for tracer in (1, 4, "wide"):
+    for tracer in [t for t in (1, 4, "wide") if t in results]:
         for a, b, label in zip(results[0][0] + results[0][2], results[tracer][0] + results[tracer][2],
                                ("colour", "nd", "albedo", "mean colour", "nd16", "albedo16", "accum")):
             assert_bits_equal(a, b, f"config 5: tracer {tracer} vs default, {label}")

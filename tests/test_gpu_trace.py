@@ -4,7 +4,7 @@ are integers/flags, and every float follows include/vxrt_detmath.h on both sides
 import numpy as np
 import pytest
 
-from conftest import assert_bits_equal
+from conftest import assert_bits_equal, require_variants
 
 pytestmark = pytest.mark.gpu
 
@@ -172,6 +172,7 @@ def test_full_size_bench_config_crops(O, H, scenes, noise):
 def test_every_trace_variant_is_bit_exact(O, H, scenes, noise, monkeypatch, env):
     """The scheduling variants of the tracer (read from the environment when a context is created) change
     which lane / launch executes a path segment, never a result."""
+    require_variants(H, env)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     for name, w, h, b, cam in (("castle", 200, 120, 5, "close"), ("room", 136, 104, 3, "close"), ("menger", 256, 144, 4, "bench")):
@@ -223,6 +224,7 @@ def _render_voxels(O, noise, pos, mrgb, cam, w, h, bounces, frames=(1,)):
 
 @pytest.mark.parametrize("wide", ["0", "1"])     # the 8-byte scene records / the wide ones (odd and even numbers of tree levels)
 def test_empty_scene_and_single_voxel(O, H, noise, monkeypatch, wide):
+    require_variants(H, wide=wide)
     monkeypatch.setenv("VXRT_WIDE", wide)
     """Edge cases of the scene format: no voxels at all (root node of eight empty slots, depth 0) and one voxel."""
     f32 = np.float32
@@ -240,6 +242,7 @@ def test_empty_scene_and_single_voxel(O, H, noise, monkeypatch, wide):
 
 @pytest.mark.parametrize("wide", ["0", "1"])     # the 8-byte scene records / the wide ones (odd and even numbers of tree levels)
 def test_deep_octree_negative_coordinates_and_depth_limit(O, H, noise, monkeypatch, wide):
+    require_variants(H, wide=wide)
     monkeypatch.setenv("VXRT_WIDE", wide)
     """Random voxels on both sides of the origin (all eight root octants used), a depth-10 tree, and the deepest
     tree i16 coordinates allow (depth 15)."""
@@ -279,6 +282,7 @@ def test_zero_times_infinity_rays_through_the_gpu(O, H, scenes, noise, monkeypat
     """An axis-aligned camera on integer coordinates sends its centre rays exactly along +z through node mid-planes:
     (center - origin) * (1/0) = 0 * inf = NaN in the shader (voxels.comp:140,191).  The kernel reproduces the
     oracle's NaNs and everything around them."""
+    require_variants(H, wide=wide)
     monkeypatch.setenv("VXRT_WIDE", wide)
     pos, mrgb, size = scenes.load_scene("8x8x8")
     f32 = np.float32
@@ -313,6 +317,7 @@ def test_iteration_cap(O, H, noise, monkeypatch, env):
     Probe rays (both walks: regular rays -> walkf_step, a zero direction component -> walk_step) and a rendered frame in
     which hundreds of primary rays are capped and their paths go on from the capped "hit" — for every tracer variant."""
     from gpu_voxel_raytracer_amd import Camera, Context
+    require_variants(H, env)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     pos, mrgb = cap_scene()
@@ -345,6 +350,10 @@ def test_tracer_field_of_the_config(O, H, scenes, noise):
     cam = scenes.close_camera(size)
     imgs = []
     for tracer, bounces in ((0, 8), (1, 8), (2, 8), (3, 8), (4, 8), (5, 8)):
+        if tracer in (2, 3, 5) and not H.has_variants():     # not in the default library: refused, loudly
+            with pytest.raises(VxrtError, match="VXRT_VARIANTS"):
+                Context(128, 80, max_bounces=bounces, noise=noise, tracer=tracer)
+            continue
         with Context(128, 80, max_bounces=bounces, noise=noise, tracer=tracer) as ctx:
             ctx.recreate_octree(pos, mrgb)
             ctx.camera = Camera(*cam)
