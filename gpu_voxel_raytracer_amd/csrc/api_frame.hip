@@ -119,7 +119,7 @@ int post_stages(vxrt_ctx* c, uint32_t flags, bool timed) {
         a.tile_row_count = 0;
         const bool both = (parts & VXRT_DENOISE) || parts == (VXRT_DENOISE_INTERIOR | VXRT_DENOISE_EDGE);
         bool launch = c->band.local_rows > 0;
-        if (!both && c->denoise.radius > 0) {
+        if (!both && c->denoise.radius > 0 && launch) {
             if (c->d_tile_rows == nullptr) { set_error("no denoise tile lists for this band layout"); return VXRT_E_INVALID; }
             const bool interior = parts == VXRT_DENOISE_INTERIOR;
             a.tile_rows = c->d_tile_rows + (interior ? 0u : c->tile_rows_interior);
