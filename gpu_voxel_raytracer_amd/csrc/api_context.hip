@@ -416,7 +416,7 @@ int vxrt_set_option(vxrt_ctx* c, vxrt_option option, uint32_t value) try {
     HIP_TRY(hipSetDevice(c->cfg.device));
     switch (option) {
         case VXRT_OPT_DENOISE_MODE:
-            if (value > 1) { set_error("denoise mode must be 0 (exact) or 1 (tolerant)"); return VXRT_E_INVALID; }
+            if (value > 3) { set_error("denoise mode must be 0 (exact) or 1 (tolerant), + 2 for the generic kernel"); return VXRT_E_INVALID; }
             c->denoise_mode = int(value);
             return VXRT_OK;
         case VXRT_OPT_SCENE_FORMAT:

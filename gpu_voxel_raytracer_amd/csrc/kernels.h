@@ -157,7 +157,8 @@ struct DenoiseArgs {
     Cam cam;
     uint32_t radius;
     float sigma_distance_2, sigma_range_2, albedo_factor;
-    int mode;   // 0 exact (bit-identical to the oracle), 1 tolerant (vxrt_set_option VXRT_OPT_DENOISE_MODE)
+    int mode;   // bit 0: 0 exact (bit-identical to the oracle), 1 tolerant (vxrt_set_option VXRT_OPT_DENOISE_MODE); bit 1: the generic kernel
+    float wdist[17 * 17];   // filled by launch_denoise: factor_distance of denoise.comp:79 per window offset (dy + r) * (2 r + 1) + (dx + r)
 };
 
 // Queue of live paths between two launches of the wavefront tracer (trace.hip): 64-byte records in 64 shards.

@@ -28,7 +28,7 @@ with Context(W, H, max_bounces=B) as ctx:
               f"denoise (exact, in the frame) {st.denoise_ms / N:.4f} ms", flush=True)
         if radius == 0:
             continue
-        for mode, label in ((0, "exact"), (1, "tolerant")):
+        for mode, label in ((0, "exact"), (1, "tolerant"), (2, "exact, generic kernel"), (3, "tolerant, generic kernel")):
             ctx.set_option(OPT_DENOISE_MODE, mode)
             ctx.update_bindings()
             ctx.render_stage(DENOISE)

@@ -28,7 +28,7 @@ def main():
     # camera, moves by 0.3 rows per frame); one fast pan (reprojections leave the rank's rows + halo: the frame after the jump)
     paths = {"rest": [(p0, d0)] * 3,
              "slow": [(p0 + np.float32(0.001 * k) * np.array([1, 0.5, 0], np.float32), d0) for k in range(4)],
-             "fast": [(p0, d0), (p0, d0 + np.float32(0.12) * np.array([0, -1, 0], np.float32))]}
+             "fast": [(p0, d0), (p0, d0 + np.float32(0.12 * float(np.linalg.norm(d0))) * np.array([0, -1, 0], np.float32))]}   # ~0.12 rad: 17 rows
     out = {}
     for name, path in paths.items():
         ctx = Context(w, h, device=0, max_bounces=bounces, rank=rank, nranks=world, band_rows=band)

@@ -1,0 +1,119 @@
+"""GPU: denoise.comp (shaders/denoise.comp:24-93) on SYNTHETIC G-buffers written straight into the context's images, so that the
+inputs the traced scenes rarely produce are all there: colours and depths that are 0 / inf / NaN, normals that are not axis unit
+vectors, every material id, window edges of the frame.  The fast kernel (two outputs per lane, one code compare instead of the normal
+and material terms — csrc/post.hip: denoise_pair_kernel) and the generic kernel (the full formula per tap) must both equal the
+oracle bit for bit in exact mode; the tolerant mode stays within BASELINE's RMSE bar."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def hip():
+    lib = C.CDLL("libamdhip64.so")
+    lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    return lib
+
+
+def synthetic_gbuffer(w, h, seed, exotic, radius=1):
+    """colour (rgb, blending), normal/depth, albedo/node: float32[h, w, 4] each."""
+    rng = np.random.default_rng(seed)
+    f32 = np.float32
+    color = rng.random((h, w, 4)).astype(f32) * f32(3.0)
+    # surfaces: blocks of equal normal / material / similar depth, so that most taps carry weight
+    by, bx = np.mgrid[0:h, 0:w]
+    patch = (by // 9) * 7 + (bx // 11)
+    axes = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [0, 0, 0]], f32)
+    nd = np.zeros((h, w, 4), f32)
+    nd[..., :3] = axes[patch % 7]
+    nd[..., 3] = (f32(4.0) + (patch % 5).astype(f32) + rng.random((h, w)).astype(f32) * f32(0.05))
+    node = (np.uint32(0x80000000) | ((patch % 3).astype(np.uint32) << np.uint32(24)) | rng.integers(0, 1 << 24, (h, w)).astype(np.uint32))
+    sky = rng.random((h, w)) < 0.15                                     # misses: normal 2^30, depth -1, node 0xffffff
+    nd[sky, :3] = f32(2.0 ** 30)
+    nd[sky, 3] = f32(-1.0)
+    node[sky] = np.uint32(0xffffff)
+    alb = rng.random((h, w, 4)).astype(f32)
+    alb[..., 3] = node.view(f32)
+    if exotic:
+        thin = 9.0 / (2 * radius + 1) ** 2                              # a non-finite pixel poisons its whole window: keep most of the frame finite
+        pick = lambda p: rng.random((h, w)) < p * thin                  # noqa: E731
+        color[pick(0.004), 0] = np.inf
+        color[pick(0.004), 1] = np.nan
+        color[pick(0.003), 2] = -np.inf
+        nd[pick(0.004), 3] = 0.0                                        # log 0 = -inf
+        nd[pick(0.004), 3] = np.nan
+        nd[pick(0.003), 3] = np.inf
+        odd = pick(0.01)
+        nd[odd, :3] = np.array([0.6, 0.8, 0.0], f32)                    # not an axis vector
+        nd[pick(0.003), 0] = np.nan
+        nd[pick(0.003), 1] = f32(-0.0)
+    return color, nd, alb
+
+
+def run_denoise(H, scenes, noise, color, nd, alb, radius, mode, sigma_range=1.5, sigma_distance=2.0, albedo_factor=1.0):
+    from gpu_voxel_raytracer_amd import DENOISE, DENOISED, NORMAL_DEPTH, SAMPLED_COLOR, ALBEDO_NODE, TRACE, Camera, Context
+    h, w = color.shape[:2]
+    pos, mrgb, size = scenes.load_scene("8x8x8")
+    cam = scenes.bench_camera(size)
+    rt = hip()
+    with Context(w, h, max_bounces=1, noise=noise) as ctx:
+        ctx.recreate_octree(pos, mrgb)
+        ctx.camera = Camera(*cam)
+        ctx.render(TRACE)                     # a frame slot exists and is current
+        ctx.sync()
+        for which, img in ((SAMPLED_COLOR, color), (NORMAL_DEPTH, nd), (ALBEDO_NODE, alb)):
+            ptr, nbytes = ctx.device_image(which)
+            assert nbytes == img.nbytes
+            assert rt.hipMemcpy(C.c_void_p(ptr), img.ctypes.data_as(C.c_void_p), nbytes, 1) == 0
+        ctx.denoise_uniforms.radius = radius
+        ctx.denoise_uniforms.sigma_range = sigma_range
+        ctx.denoise_uniforms.sigma_distance = sigma_distance
+        ctx.denoise_uniforms.albedo_factor = albedo_factor
+        ctx.set_option(H.OPT_DENOISE_MODE, mode)
+        ctx.update_bindings()
+        ctx.render_stage(DENOISE)
+        return ctx.read(DENOISED), cam
+
+
+def oracle_denoise(O, color, nd, alb, cam, radius, sigma_range=1.5, sigma_distance=2.0, albedo_factor=1.0):
+    h, w = color.shape[:2]
+    u = O.Uniforms.default()
+    u.set_camera(cam[0], O.camera_axis_scaled(cam[0], cam[1], cam[2], w, h))
+    du = O.Denoise.default()
+    du.radius, du.sigma_range, du.sigma_distance, du.albedo_factor = radius, sigma_range, sigma_distance, albedo_factor
+    return O.denoise(color, nd, alb, u.camera16(), du)
+
+
+@pytest.mark.parametrize("w,h,radius,exotic", [(70, 50, 1, True), (97, 33, 2, True), (64, 64, 5, True), (131, 70, 8, True), (40, 23, 8, False),
+                                             (33, 17, 3, True)])
+def test_exact_denoise_equals_the_oracle_on_synthetic_gbuffers(O, H, scenes, noise, w, h, radius, exotic):
+    color, nd, alb = synthetic_gbuffer(w, h, seed=w * 1000 + h + radius, exotic=exotic, radius=radius)
+    fast, cam = run_denoise(H, scenes, noise, color, nd, alb, radius, mode=0)
+    generic, _ = run_denoise(H, scenes, noise, color, nd, alb, radius, mode=2)
+    want = oracle_denoise(O, color, nd, alb, cam, radius)
+    assert np.isfinite(want[..., :3]).mean() > 0.4 and (not exotic or np.isnan(want[..., :3]).any())
+    assert_bits_equal(generic, want, f"generic kernel, radius {radius}")
+    assert_bits_equal(fast, want, f"fast kernel, radius {radius}")
+
+
+@pytest.mark.parametrize("sigma_range,sigma_distance,albedo_factor", [(0.1, 0.5, 0.0), (5.0, 3.0, 0.5), (7.0, 2.0, 1.0), (8.0, 2.0, 1.0), (40.0, 1.0, 0.3)])
+def test_denoise_parameter_range(O, H, scenes, noise, sigma_range, sigma_distance, albedo_factor):
+    """sigma_range up to 7 (the GUI offers 0.1 .. 5, src/context.rs:1798): the fast kernel's premise holds (1e4 / (2 sigma^2) > 100); beyond it
+    a tap of another material can carry weight and launch_denoise takes the generic kernel — bit-exact either way."""
+    color, nd, alb = synthetic_gbuffer(90, 60, seed=int(sigma_range * 10), exotic=True, radius=4)
+    got, cam = run_denoise(H, scenes, noise, color, nd, alb, 4, 0, sigma_range, sigma_distance, albedo_factor)
+    want = oracle_denoise(O, color, nd, alb, cam, 4, sigma_range, sigma_distance, albedo_factor)
+    assert_bits_equal(got, want, f"sigma_range {sigma_range}")
+
+
+@pytest.mark.parametrize("radius,mode", [(2, 1), (8, 1), (8, 3)])
+def test_tolerant_denoise_on_synthetic_gbuffers(O, H, scenes, noise, radius, mode):
+    color, nd, alb = synthetic_gbuffer(128, 96, seed=radius, exotic=False)
+    got, cam = run_denoise(H, scenes, noise, color, nd, alb, radius, mode)
+    want = oracle_denoise(O, color, nd, alb, cam, radius)
+    err = got[..., :3].astype(np.float64) - want[..., :3]
+    assert np.sqrt(np.mean(err ** 2)) <= 1e-5 and np.abs(err).max() <= 1e-4         # BASELINE's bar is RMSE <= 1e-3

@@ -429,8 +429,11 @@ def test_tolerant_denoise_mode_at_4k_radius_8(O, H, scenes, noise):
         ctx.set_option(H.OPT_DENOISE_MODE, 0)
         ctx.render_stage(DENOISE)
         assert_bits_equal(ctx.read(DENOISED), exact, "mode 0 after mode 1")
+        ctx.set_option(H.OPT_DENOISE_MODE, 2)    # + 2: the generic kernel (the full formula for every tap) — same image
+        ctx.render_stage(DENOISE)
+        assert_bits_equal(ctx.read(DENOISED), exact, "generic kernel vs fast kernel, exact mode")
         with pytest.raises(H.VxrtError):
-            ctx.set_option(H.OPT_DENOISE_MODE, 2)
+            ctx.set_option(H.OPT_DENOISE_MODE, 4)
     u = O.Uniforms.default()
     u.set_camera(cam[0], O.camera_axis_scaled(cam[0], cam[1], cam[2], w, h))
     du = O.Denoise.default()
