@@ -286,6 +286,7 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) try {
     auto fail = [&](int code) { vxrt_destroy(c); return code; };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipStreamCreate"));
     if (hipEventCreateWithFlags(&c->halo_event, hipEventDisableTiming) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipEventCreate"));
+    if (const char* v = getenv("VXRT_SKY_CULL")) c->sky_cull = atoi(v) != 0;   // A/B and tests
     if (const char* v = getenv("VXRT_HALO_ROWS")) c->halo_min_rows = uint32_t(atoi(v) < 0 ? 0 : atoi(v));
     c->inflight = cfg->frames_in_flight == 0 ? 1 : int(cfg->frames_in_flight);
     if (const char* v = getenv("VXRT_INFLIGHT")) c->inflight = atoi(v);
@@ -434,6 +435,10 @@ int vxrt_set_option(vxrt_ctx* c, vxrt_option option, uint32_t value) try {
             if (c->trace_variant < 4) return VXRT_OK;   // the other tracers' queues are sized for the worst case
             c->tail_capacity_override = int(value > 0x7fffffffu ? 0x7fffffffu : value);
             return resize_tail_queues(c, value == 0 ? (c->shard_capacity_max / 8u < 4096u ? 4096u : c->shard_capacity_max / 8u) : value);
+        case VXRT_OPT_SKY_CULL:
+            if (value > 1) { set_error("sky cull must be 0 or 1"); return VXRT_E_INVALID; }
+            c->sky_cull = int(value);
+            return VXRT_OK;
         case VXRT_OPT_HALO_ROWS:
             if (value > 4096) { set_error("halo rows must be 0..4096"); return VXRT_E_INVALID; }
             c->halo_min_rows = value;
@@ -514,6 +519,9 @@ int vxrt_get_stats(vxrt_ctx* c, vxrt_stats* out) try {
     out->halo_pack_ms = c->ms[3];
     out->halo_unpack_ms = c->ms[4];
     out->halo_exchanges = c->halo_exchanges;
+    out->cull_box_valid = c->box_valid ? 1u : 0u;
+    memcpy(out->cull_box_min, c->box_min, sizeof c->box_min);
+    memcpy(out->cull_box_max, c->box_max, sizeof c->box_max);
     out->timed_frames = c->timed_frames;
     out->timed_launches = c->timed_launches;
     out->scene_bytes = c->svo_count * sizeof(SvoRecord) + c->leaf_count * sizeof(int32_t);

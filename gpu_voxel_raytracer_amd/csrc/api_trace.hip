@@ -79,6 +79,7 @@ void frame_constants(const vxrt_ctx* c, TraceArgs& a) {
     a.band = c->band;
     a.max_bounces = int(c->cfg.max_bounces);
     a.launch_index = 0;
+    a.cull = 0;
     a.stack_levels = c->depth < 1 ? 1 : int(c->depth);
     // voxels.comp:296 and the other per-frame constants, evaluated once with the same operations
     f3 sun_dir = mk3(vx_cos(u.sun_yaw) * vx_cos(u.sun_pitch), -vx_sin(u.sun_pitch), vx_sin(u.sun_yaw) * vx_cos(u.sun_pitch));
@@ -137,6 +138,25 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
     a.out_color = a.out[0].color; a.out_nd = a.out[0].nd; a.out_albedo = a.out[0].albedo;
     a.batch = int(g);
     a.gbuf_frames = gbuf_frames;
+    // Sky cull: the scene's box grown by a margin m that dwarfs every rounding error of the walk and of the test itself.  The walk
+    // visits a cell only if the ray passes within ~2^-21 (|origin| + root_size) of it (its plane times are fl(fl(p - o) * inv): two
+    // roundings of quantities no larger than that); m = 0.01 + 2^-16 (max |origin| + 2 root_size) is at least 32 times as much.
+    a.cull = 0;
+    if (c->sky_cull && c->box_valid) {
+        float far = 0.0f;
+        bool sane = true;
+        for (uint32_t k = 0; k < g; k++)
+            for (int i = 0; i < 3; i++) {
+                const float v = fabsf(cams[k].o[i]);
+                sane = sane && v < 1e6f && std::isfinite(cams[k].r[i]) && std::isfinite(cams[k].u[i]) && std::isfinite(cams[k].f[i]);   // NaN fails v < 1e6
+                far = v > far ? v : far;
+            }
+        if (sane) {
+            const float m = 0.01f + ldexpf(far + 2.0f * c->root_size, -16);
+            for (int i = 0; i < 3; i++) { a.cull_min[i] = c->box_min[i] - m; a.cull_max[i] = c->box_max[i] + m; }
+            a.cull = 1;
+        }
+    }
     a.ray_counter = c->d_rays;
     a.tile_order = (c->use_tile_order && sched.valid) ? sched.order : nullptr;
     a.tile_cost = c->use_tile_order ? sched.cost : nullptr;

@@ -76,6 +76,10 @@ struct vxrt_ctx {
     size_t svo_count = 0, leaf_count = 0;
     float root_center[3] = {0, 0, 0};
     float root_size = 1.0f;
+    // the sky cull's box (api_scene.hip: scene_box): every occupied cell of tree level min(depth, 7), world units, not yet grown
+    bool box_valid = false;
+    float box_min[3] = {0, 0, 0}, box_max[3] = {0, 0, 0};
+    int sky_cull = 1;   // VXRT_OPT_SKY_CULL
     uint32_t depth = 0;
     float* d_noise = nullptr;
 
@@ -196,6 +200,9 @@ bool valid_ctx(const vxrt_ctx* c);
 float4* image_ptr(vxrt_ctx* c, vxrt_image which);
 // ---- api_scene.hip
 bool use_wide(const vxrt_ctx* c);
+// the smallest box of cells of tree level min(depth, 7) that holds every voxel; recs: the first records of the tree, breadth first,
+// at least those of levels 0 .. min(depth, 7) - 1.  false: no voxel at all
+bool scene_box(const SvoRecord* recs, size_t count, uint32_t depth, const float root_center[3], float root_size, float box_min[3], float box_max[3]);
 // ---- api_trace.hip
 int resize_tail_queues(vxrt_ctx* c, unsigned want);
 int grow_tail_queues(vxrt_ctx* c, size_t lane);

@@ -107,6 +107,12 @@ struct TraceArgs {
     int tail_from;
     uint32_t gbuf_frames;  // bit k: frame k of the launch writes its normal/depth and albedo/node images (all set, except for the samples of one
                            // displayed frame, vxrt_render_spp, whose first hits are identical: only the frame that is kept writes them)
+    // Sky cull (trace.hip: primary_miss_is_certain; DESIGN.md "sky cull"): a box that holds every occupied cell of the tree at level
+    // min(depth, 7), grown by a margin far above the walk's rounding.  A regular primary ray that misses it provably makes the walk
+    // return "miss" (no leaf is near it and fewer than 1536 of the 2048 trips are possible), so its pixel takes the miss outputs of
+    // voxels.comp:373-388 / :292-294 without walking.  cull = 0: off (no box, odd camera, VXRT_OPT_SKY_CULL 0).
+    int cull;
+    float cull_min[3], cull_max[3];
 };
 
 // The rows of the neighbouring ranks that this rank can see (multi-rank: api_halo.hip, halo.hip).  Two messages are kept, side 0 =

@@ -47,6 +47,41 @@ namespace {
 #ifndef VXRT_TRACE_WAVES
 #define VXRT_TRACE_WAVES 5   // waves per SIMD the register allocation aims for (96 VGPRs)
 #endif
+// Sky cull.  True only when the primary ray (o, d) PROVABLY makes cast_bounded_ray return false, decided without walking:
+//  * the ray is regular (every component of 1 / d finite and non-zero) and, by a slab test in plain binary32, misses the box
+//    TraceArgs::cull_min/max — the smallest box of cells of tree level L = min(depth, 7) that holds every voxel, grown by a margin
+//    m >= 32 x the largest rounding error of the walk's plane times (api_trace.hip).  Comparisons with NaN are false: no cull.
+//  * then the walk can visit (descend into) no node of level >= L — every such node that exists lies inside the box, and the walk
+//    only enters cells the ray passes within rounding distance of — hence no leaf: it cannot return a hit from a leaf;
+//  * and it cannot return the iteration cap's "hit" (voxels.comp:166-169) either: each trip of the loop handles one (node, octant)
+//    pair, a node's octants are left along each axis at most once (a sibling step needs (directional & transition) == 0), so a
+//    node costs at most 4 trips; the nodes visited at level l form a path that is monotone along each axis of a 2^l grid, at most
+//    3 * 2^l - 2 cells; summed over the levels 0 .. L - 1 <= 6 that can be visited: at most 367 nodes, 1468 trips < 2048.
+// So the walk ends in a miss (or the root test fails first), and voxels.comp:373-388 / :292-294 with bounce == 0 give the pixel's
+// outputs from d alone.  tests/test_gpu_trace.py::test_sky_cull* compare culled and walked frames value for value.
+__device__ __forceinline__ bool primary_miss_is_certain(const TraceArgs& a, f3 o, f3 d) {
+    if (!a.cull) return false;
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    if (!ray_is_regular(inv)) return false;
+    const f3 t0 = (ld3(a.cull_min) - o) * inv, t1 = (ld3(a.cull_max) - o) * inv;
+    const float t_in = vx_max3(__builtin_fminf(t0.x, t1.x), __builtin_fminf(t0.y, t1.y), __builtin_fminf(t0.z, t1.z));
+    const float t_out = vx_min3(__builtin_fmaxf(t0.x, t1.x), __builtin_fmaxf(t0.y, t1.y), __builtin_fmaxf(t0.z, t1.z));
+    return t_in > t_out || t_out < 0.0f;
+}
+
+// voxels.comp:373-388 for a primary ray that misses (bounce == 0), :292-294 and :391-396: the three outputs of such a pixel
+__device__ __forceinline__ void store_primary_miss(const TraceArgs& a, const FrameOut& fo, size_t pix, f3 d, bool gbuf) {
+    const f3 sun_color = ld3(a.sun_color), sky = ld3(a.sky_color);
+    const float sun_power = sun_power_of(a, d);
+    const f3 sample = splat3(0.0f) + (sky + sun_color * sun_power) * splat3(1.0f);
+    const f3 out = sample / float(1u);
+    if (gbuf) {
+        store_out(fo.nd + pix, make_float4(kAlmostInfinity, kAlmostInfinity, kAlmostInfinity, -1.0f));
+        store_out(fo.albedo + pix, make_float4(1.0f, 1.0f, 1.0f, __int_as_float(0xffffff)));
+    }
+    store_out(fo.color + pix, make_float4(out.x, out.y, out.z, 1.0f));
+}
+
 constexpr int kTB = VXRT_TRACE_BLOCK;
 constexpr int kTileW = kTB == 64 ? 8 : 16, kTileH = kTB == 256 ? 16 : 8;
 
@@ -76,7 +111,18 @@ __global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const Trac
     uint32_t rays = 0;
     const unsigned tail_shard = (blockIdx.x * unsigned(kTB / 64) + unsigned(wave)) % kShards;
     if (a.tail.recs != nullptr) zero_counts(a.tail_zero, tid);
-    if (active) {
+    bool walk = active;
+    if (active) {   // the sky cull: a pixel whose primary ray certainly misses needs no walk
+        const Cam& cam = a.cams[fb];
+        const f3 o = ld3(cam.o);
+        const f3 d = norm3((float(x) * ld3(cam.r) - float(y) * ld3(cam.u)) + ld3(cam.f));  // voxels.comp:299-303
+        if (primary_miss_is_certain(a, o, d)) {
+            store_primary_miss(a, fo, size_t(lrow) * a.band.width + x, d, gbuf);
+            rays = 1;
+            walk = false;
+        }
+    }
+    if (walk) {
         bool handed_over = false;  // this lane's path continues in bounce_kernel (TraceArgs::tail)
         const Caster<kWide> caster(a, lds_stack, tid);
         const size_t pix = size_t(lrow) * a.band.width + x;

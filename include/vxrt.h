@@ -162,13 +162,19 @@ typedef struct vxrt_stats {
     double halo_pack_ms;      /* summed kernel time of the halo pack / unpack launches (always timed) ...               */
     double halo_unpack_ms;
     uint64_t halo_exchanges;  /* ... and how many unpacks that was                                                      */
+    uint32_t cull_box_valid;  /* the sky cull's box (VXRT_OPT_SKY_CULL): every occupied cell of tree level min(depth, 7),       */
+    float cull_box_min[3];    /* world units, before the per-frame margin is added                                              */
+    float cull_box_max[3];
+    uint32_t reserved1;
 } vxrt_stats;
 
 /* Run-time options (none of them changes what a frame means; defaults are the reference's behaviour).
  *   VXRT_OPT_DENOISE_MODE  0 (default): denoise.comp evaluated exactly as the oracle restates it (bit-identical).
  *                          1: tolerant — the per-tap weight exp(-(..)/sigma_range_2 - (..)/sigma_distance_2) (denoise.comp:64-80)
  *                             with a reciprocal multiply and the hardware's exp2; within BASELINE's RMSE <= 1e-3 of mode 0
- *                             (tests/test_gpu_pipeline.py), about twice as fast for radius >= 4.
+ *                             (tests/test_gpu_pipeline.py, test_gpu_denoise.py), 1.7 - 2.6 x as fast.
+ *                          + 2: the generic kernel (the full formula for every tap) instead of the fast one — a cross-check; the
+ *                             library takes it by itself when sigma_range > 7 (the GUI of the reference offers 0.1 .. 5).
  *   VXRT_OPT_TAIL_CAPACITY records per shard of the compacted tail's path queue (test hook: a small value forces the
  *                          queue-full path); 0 = back to automatic sizing.
  *   VXRT_OPT_SCENE_FORMAT  which scene records tracers 1 and 4 walk: 0 (default) the 8-byte records, one tree level each; 1 the wide
@@ -180,8 +186,12 @@ typedef struct vxrt_stats {
  *                          carries max(denoise radius, this) rows; temporal.comp's reprojection (:85-113) sees that many rows of the
  *                          neighbouring bands' history, so set it to the largest vertical image motion per frame, in rows, that
  *                          should keep its history across a band edge (up to band_rows); beyond it a pixel is treated as
- *                          disoccluded, the reference's rule for a reprojection that leaves the screen (temporal.comp:92).   */
-typedef enum vxrt_option { VXRT_OPT_DENOISE_MODE = 1, VXRT_OPT_TAIL_CAPACITY = 2, VXRT_OPT_SCENE_FORMAT = 3, VXRT_OPT_HALO_ROWS = 4 } vxrt_option;
+ *                          disoccluded, the reference's rule for a reprojection that leaves the screen (temporal.comp:92).
+ *   VXRT_OPT_SKY_CULL      1 (default): a pixel whose primary ray provably misses the scene — it misses, with a margin, the box of the
+ *                          tree's occupied cells at level min(depth, 7) — gets voxels.comp's miss outputs without walking the octree
+ *                          (same values: csrc/trace.hip, primary_miss_is_certain states the proof).  0: every primary ray walks.     */
+typedef enum vxrt_option { VXRT_OPT_DENOISE_MODE = 1, VXRT_OPT_TAIL_CAPACITY = 2, VXRT_OPT_SCENE_FORMAT = 3, VXRT_OPT_HALO_ROWS = 4,
+                           VXRT_OPT_SKY_CULL = 5 } vxrt_option;
 int vxrt_set_option(vxrt_ctx* ctx, vxrt_option option, uint32_t value);
 
 /* ---- context: replaces Context::new / create_bindings / resize (src/context.rs:595-660, 936-1016,

@@ -41,7 +41,7 @@ def test_ranks_in_processes_stitch_to_the_single_context_frame(nproc, radius):
     f = d["fast"]
     assert f["rays_equal"] and f["sampled_differing_pixels"] == 0
     assert f["accum_differs_only_where_treated_as_disocclusion"], f
-    assert 0 < f["accum_differing_pixels"] < 0.5 * f["geometry_pixels"]
+    assert 0 < f["accum_differing_pixels"] < f["geometry_pixels"]      # a 17-row jump against 3 / 8 / 1 halo rows: most of the history is out of reach
 
 
 def test_history_halo_sized_for_the_motion_keeps_the_fast_pan_exact():

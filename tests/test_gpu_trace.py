@@ -417,3 +417,52 @@ def test_tail_queue_full_and_growth(O, H, scenes, noise):
     # an 8K single context with 32 frames per launch x 3 in flight can be created (worst-case queues would need 204 GB)
     with Context(7680, 4320, max_bounces=4, frames_per_launch=32, frames_in_flight=3) as ctx:
         assert ctx.stats().queue_bytes < 40 << 30
+
+
+@pytest.mark.parametrize("name,view", [("menger", "bench"), ("menger", "close"), ("castle", "bench"), ("monu10", "start"), ("room", "close"), ("3x3x3", "bench")])
+def test_sky_cull_changes_no_value(O, H, scenes, noise, name, view):
+    """VXRT_OPT_SKY_CULL: a pixel whose primary ray provably misses takes voxels.comp's miss outputs without walking (csrc/trace.hip:
+    primary_miss_is_certain).  Frames with the cull on and off are equal value for value, ray counts included, from outside, from
+    close up and from inside the root cube; the box it tests against holds every voxel and is tight to one leaf-parent cell."""
+    from gpu_voxel_raytracer_amd import TRACE, Camera, Context
+    pos, mrgb, size = scenes.load_scene(name)
+    cam = {"bench": scenes.bench_camera, "close": scenes.close_camera}[view](size) if view != "start" else scenes.reference_start_camera()
+    w, h, bounces = 320, 200, 3
+    imgs = {}
+    for cull in (1, 0):
+        with Context(w, h, max_bounces=bounces, noise=noise, frames_per_launch=3) as ctx:
+            ctx.recreate_octree(pos, mrgb)
+            ctx.set_option(H.OPT_SKY_CULL, cull)
+            ctx.camera = Camera(*cam)
+            ctx.render_frames(TRACE, 3)
+            st = ctx.stats()
+            imgs[cull] = ([ctx.read(i) for i in range(3)], st.rays)
+            if cull:
+                lo, hi = np.array(st.cull_box_min), np.array(st.cull_box_max)
+                vmin, vmax = pos.min(0) * 0.5, (pos.max(0) + 1) * 0.5          # a voxel p occupies [p / 2, p / 2 + 0.5)
+                assert st.cull_box_valid and (lo <= vmin).all() and (hi >= vmax).all() and (vmin - lo < 1.0).all() and (hi - vmax < 1.0).all()
+    for a, b, label in zip(imgs[1][0], imgs[0][0], ("colour", "nd", "albedo")):
+        assert_bits_equal(a, b, f"{label}: sky cull on vs off, {name} {view}")
+    assert imgs[1][1] == imgs[0][1]
+    u = O.Uniforms.default()
+    u.set_camera(cam[0], O.camera_axis_scaled(cam[0], cam[1], cam[2], w, h))
+    u.frame_number = 3
+    ref = O.trace(O.create_octree(pos, mrgb), noise, u, w, h, bounces, crop=(0, 0, w, h))
+    for a, b, label in zip(imgs[1][0], ref[:3], ("colour", "nd", "albedo")):
+        assert_bits_equal(a, b, f"{label}: sky cull vs oracle, {name} {view}")
+
+
+def test_sky_cull_beside_the_iteration_cap_scene(O, H, noise):
+    """The 4 096-voxel row (a depth-12 tree whose rays CAN reach the 2 048-trip cap): the cull's box is made of level-7 cells there,
+    rays inside it walk (and are capped as in the oracle), rays outside it are culled — among them rays that run the whole length of
+    the row a few cells away from it, the worst case for the trip bound in the proof.  Every pixel equals the oracle's."""
+    pos, mrgb = cap_scene()
+    f32 = np.float32
+    for cam in ((np.array([-40, 33, 33], f32), np.array([1, 0.001, 0.001], f32), 0.9),      # along the row, skimming past the box's corner
+                (np.array([-40, 30, 20], f32), np.array([1, -0.012, -0.008], f32), 0.9),
+                (np.array([-1, 20.0, 0.25], f32), np.array([1, -0.009, 0], f32), 0.4),
+                (np.array([-1, 0.6, 0.25], f32), np.array([1, 0, 0], f32), 0.05)):
+        for (g, rays, ref) in _render_voxels(O, noise, pos, mrgb, cam, 160, 96, 2, frames=(1, 2)):
+            for a, b, label in zip(g, ref[:3], ("colour", "nd", "albedo")):
+                assert_bits_equal(a, b, f"{label} beside the row")
+            assert rays == ref[3]
