@@ -47,7 +47,7 @@ WIDTH, HEIGHT, BOUNCES, SCENE = 1920, 1080, 4, "menger"
 # structure beats against the 128-row period).  (A denoise radius > 0 needs 16-row bands; the default benchmark is the trace stage.)
 BAND_ROWS = 8
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_DIRS = ("r02", "r01")   # newest first: where the rocprofv3 summaries of the default command are kept
+PROFILE_DIRS = ("r03", "r02", "r01")   # newest first: where the rocprofv3 summaries of the default command are kept
 
 
 def algorithmic_bytes(pixels, bounces, scene_bytes):
@@ -125,6 +125,54 @@ def cpu_baseline_cpu_rs(target_seconds=float(os.environ.get("VXRT_BENCH_CPU_RS_S
             "mrays_per_s": round(rays_per_frame / (ms * 1e-3) / 1e6, 2),
             "sample": f"vox/3x3x3.vox 256x256, src/cpu.rs shading at time 0, median of {len(times)} frames, {threads} threads "
                       f"(the fastest of 8..{cores} on this host)"}
+
+
+def measure_latency(Context, Camera, TRACE, pos, mrgb, cam, device, bounces, frames=60):
+    """One vxrt_render(TRACE) per frame, each waited for before the next is submitted: what a render loop that calls the library
+    once per displayed frame sees (the library then takes its all-in-one kernel).  Median over `frames` frames, ms."""
+    ctx = Context(WIDTH, HEIGHT, device=device, max_bounces=bounces, frames_in_flight=1, frames_per_launch=1)
+    ctx.recreate_octree(pos, mrgb)
+    ctx.camera = Camera(*cam)
+    for _ in range(10):
+        ctx.render(TRACE)
+    ctx.sync()
+    times = []
+    for _ in range(frames):
+        t0 = time.perf_counter()
+        ctx.render(TRACE)
+        ctx.sync()
+        times.append(time.perf_counter() - t0)
+    ctx.close()
+    return statistics.median(times) * 1e3
+
+
+def measure_view(Context, Camera, TRACE, pos, mrgb, cam, device, bounces, inflight, batch, width=WIDTH, height=HEIGHT, frames=480, blocks=7,
+                 setup=None):
+    """Throughput of the trace stage for another view / scene with the headline's schedule: median of `blocks` blocks of `frames` frames."""
+    ctx = Context(width, height, device=device, max_bounces=bounces, frames_in_flight=inflight, frames_per_launch=batch)
+    if setup is not None:
+        setup(ctx)
+    else:
+        ctx.recreate_octree(pos, mrgb)
+    ctx.camera = Camera(*cam)
+    ctx.render_frames(TRACE, max(2 * batch * inflight, 32))
+    ctx.sync()
+    res = []
+    for _ in range(blocks):
+        ctx.reset_stats()
+        ctx.sync()
+        t0 = time.perf_counter()
+        ctx.render_frames(TRACE, frames)
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        res.append((dt, ctx.stats().rays))
+    st = ctx.stats()
+    ctx.close()
+    res.sort()
+    dt, rays = res[len(res) // 2]
+    return {"value": round(rays / dt / 1e6, 2), "unit": "Mrays/s", "ms_per_frame": round(dt / frames * 1e3, 4),
+            "rays_per_pixel": round(rays / frames / (width * height), 4), "frames_per_block": frames, "blocks": blocks,
+            "scene_bytes": int(st.scene_bytes)}
 
 
 def pick_schedule(world, steps, inflight=0, batch=0):
@@ -269,16 +317,20 @@ def trace_bench(args):
                        "gbs_one_launch_alone": round(alg * frames_per_launch / (launch_ms * 1e-3) / 1e9, 2) if launch_ms > 0 else None},
         }
         if prof is not None and default_cfg:
-            try:
-                t = prof["traffic"]
+            drv = prof.get("driver_schedule") or {}
+            t, same = prof.get("traffic"), False
+            try:   # the recorded pass whose schedule is nearest to this run's (frames per launch)
+                t = min([t for t in (prof.get("traffic"), drv.get("traffic")) if t], key=lambda t: abs(float(t["frames_per_launch"]) - frames_per_launch))
+                same = t is drv.get("traffic")
                 roof["traffic"] = float(t["hbm_bytes_per_launch_corrected"]) / float(t["frames_per_launch"])
-                roof["traffic_source"] = (f"RECORDED in {prof_path} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, read "
-                                          "side doubled per MI355X_MICROARCH.md), per step; not measured by this run")
+                roof["traffic_source"] = (f"RECORDED in {prof_path} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, read side doubled per "
+                                          f"MI355X_MICROARCH.md) with the schedule `{t.get('command_args', '--steps 96 --warmup 32 --blocks 2')}` "
+                                          f"({t['frames_per_launch']} frames per launch), scaled per step; not measured by this run")
             except (KeyError, ValueError, TypeError, ZeroDivisionError):
                 pass
             try:
-                sq = prof["sq"]
-                per_frame = sum(k["valu_wave_instr_per_launch"] for k in sq.values()) / float(prof["traffic"]["frames_per_launch"])
+                sq = drv["sq"] if (same and drv.get("sq")) else prof["sq"]
+                per_frame = sum(k["valu_wave_instr_per_launch"] for k in sq.values()) / float(t["frames_per_launch"])
                 # 1024 SIMDs; a wave64 VALU instruction occupies its SIMD's issue port for 2 cycles at ~2.4 GHz
                 roof["valu"] = {"source": f"RECORDED in {prof_path} (rocprofv3 --pmc SQ_* pass), not measured by this run",
                                 "valu_wave_instr_per_step": round(per_frame),
@@ -302,9 +354,28 @@ def trace_bench(args):
                        "block_ms": {"min": round(min(times) * 1e3, 4), "median": round(elapsed * 1e3, 4), "max": round(max(times) * 1e3, 4)},
                        "timed_region_s_total": round(sum(times), 3),
                        "note": "ms_per_step is reciprocal THROUGHPUT (frames of a camera at rest, several per launch, launches "
-                               "overlapping); the latency of one vxrt_render(TRACE) call, one frame at a time, is 0.27 ms (DESIGN.md §7)"},
+                               "overlapping); latency_ms_one_frame_at_a_time is one vxrt_render(TRACE) per frame, each waited for"},
             "roofline": roof,
         }
+        if world == 1 and not args.no_extras:
+            # secondary figures, measured in this run after the headline block (none of them is `value`)
+            out["timing"]["latency_ms_one_frame_at_a_time"] = round(measure_latency(Context, Camera, TRACE, pos, mrgb, cam, device, args.bounces), 4)
+            extra = {}
+            if args.view == "bench":
+                extra["close_view"] = dict(measure_view(Context, Camera, TRACE, pos, mrgb, scenes.close_camera(size), device, args.bounces,
+                                                        args.inflight, args.batch),
+                                           workload=f"vox/{SCENE}.vox {WIDTH}x{HEIGHT}, {args.bounces} bounces, camera 'close' (geometry fills the frame)")
+            if default_cfg and not args.no_config5:
+                try:
+                    c5cam = scenes.config5_cameras()["outside"]
+                    extra["config5_outside_view"] = dict(
+                        measure_view(Context, Camera, TRACE, None, None, c5cam, device, 8, 1, 1, width=3840, height=2160, frames=24, blocks=5,
+                                     setup=lambda ctx: ctx.set_menger(*scenes.CONFIG5)),
+                        workload="BASELINE configs[4]'s scene (procedural Menger level 7 clipped to 2048^3, 5.6 GB: HBM-resident) at 3840x2160, "
+                                 "8 bounces, one frame per launch, view from outside; one GPU's share is a band set of the 7680x4320 frame")
+                except Exception as e:  # noqa: BLE001 — an extra must never cost the headline line
+                    extra["config5_outside_view"] = {"error": repr(e)}
+            out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pos, mrgb, cam)
             out["cpu_baseline_cpu_rs"] = cpu_baseline_cpu_rs()
@@ -428,6 +499,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=-1)
     ap.add_argument("--blocks", type=int, default=0, help="timed blocks of --steps frames (default: >= 50 and >= 1 s of GPU time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (latency, close view, config 5's scene)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the extra that builds the 5.6 GB procedural scene")
     ap.add_argument("--pipeline", action="store_true", help="time the whole frame loop with the denoise halo exchange (BASELINE configs[3])")
     ap.add_argument("--radius", type=int, default=8, help="--pipeline: denoise radius")
     ap.add_argument("--band-rows", type=int, default=0, help="--pipeline: rows per band (default: >= 8 radius, a multiple of 16)")

@@ -1,6 +1,7 @@
 // api_scene.hip — scene upload of libvxrt: voxel list -> reference-layout octree (scene_host.cpp) -> breadth-first device records
 // (kernels.h: SvoRecord, WideRec) -> HBM.  Replaces Context::recreate_octree (src/context.rs:799-810); the procedural scene of
 // BASELINE config 5 is built on the device (scene_device.hip).
+#include <cmath>
 #include <fstream>
 #include <iterator>
 
@@ -93,6 +94,40 @@ int widen_svo(const std::vector<SvoRecord>& recs, uint32_t depth, std::vector<Wi
     return VXRT_OK;
 }
 
+// The sky cull's box (kernels.h: TraceArgs::cull): the smallest box of level-L cells, L = min(depth, 7), that holds every occupied
+// cell of that level — node levels run 0 (the root, edge root_size) .. depth (the leaf parents, edge 1).  The tree's records are
+// breadth first with a node's children contiguous, so levels 0 .. L - 1 are a prefix of `recs`.
+bool scene_box(const SvoRecord* recs, size_t count, uint32_t depth, const float root_center[3], float root_size, float box_min[3], float box_max[3]) {
+    if (count == 0 || (recs[0].masks & 0xffffu) == 0u) return false;
+    const uint32_t L = depth < 7u ? depth : 7u;
+    struct Cell { uint32_t index, x, y, z; };
+    std::vector<Cell> level{{0u, 0u, 0u, 0u}}, next;
+    for (uint32_t l = 0; l < L; l++) {
+        next.clear();
+        for (const Cell& n : level) {
+            if (n.index >= count) return false;               // the prefix handed in is too short: no box, no cull
+            const uint32_t cm = recs[n.index].masks & 0xffu;
+            uint32_t k = 0;
+            for (uint32_t s = 0; s < 8; s++)
+                if (cm >> s & 1u) next.push_back(Cell{recs[n.index].base + k++, n.x * 2 + ((s >> 2) & 1u), n.y * 2 + ((s >> 1) & 1u), n.z * 2 + (s & 1u)});
+        }
+        level.swap(next);
+        if (level.empty()) return false;
+    }
+    uint32_t lo[3] = {~0u, ~0u, ~0u}, hi[3] = {0, 0, 0};
+    for (const Cell& n : level) {
+        const uint32_t p[3] = {n.x, n.y, n.z};
+        for (int a = 0; a < 3; a++) { lo[a] = p[a] < lo[a] ? p[a] : lo[a]; hi[a] = p[a] > hi[a] ? p[a] : hi[a]; }
+    }
+    const float cell = ldexpf(root_size, -int(L));             // exact: powers of two
+    for (int a = 0; a < 3; a++) {
+        const float root_min = root_center[a] - 0.5f * root_size;
+        box_min[a] = root_min + float(lo[a]) * cell;
+        box_max[a] = root_min + float(hi[a] + 1u) * cell;
+    }
+    return true;
+}
+
 int upload_svo(vxrt_ctx* c, std::vector<SvoRecord>& recs, std::vector<int32_t>& leaves, uint32_t depth) {
     if (leaves.empty()) leaves.push_back(0);
     HIP_TRY(hipSetDevice(c->cfg.device));
@@ -126,6 +161,7 @@ int upload_svo(vxrt_ctx* c, std::vector<SvoRecord>& recs, std::vector<int32_t>& 
     c->root_size = float(1u << depth);                                   // src/context.rs:779
     c->depth = depth;
     c->has_scene = true;
+    c->box_valid = scene_box(recs.data(), recs.size(), depth, c->root_center, c->root_size, c->box_min, c->box_max);
     return VXRT_OK;
 }
 
@@ -204,6 +240,20 @@ int vxrt_set_menger(vxrt_ctx* c, uint32_t level, uint32_t clip, const uint8_t mr
         c->root_size = float(1u << depth);
         c->depth = depth;
         c->has_scene = true;
+        // the sky cull's box from the top of the tree: levels 0 .. 6 are a prefix of the records (find where level 7 starts, copy that much)
+        c->box_valid = false;
+        size_t prefix = 1;
+        SvoRecord first = root;
+        for (uint32_t l = 0; l < (depth < 7u ? depth : 7u) && (first.masks & 0xffu) != 0u; l++) {
+            prefix = first.base;
+            if (prefix >= nsvo) break;
+            HIP_TRY(hipMemcpy(&first, svo + prefix, sizeof first, hipMemcpyDeviceToHost));
+        }
+        if (prefix <= nsvo && prefix <= (size_t(1) << 22)) {
+            std::vector<SvoRecord> top(prefix);
+            HIP_TRY(hipMemcpy(top.data(), svo, prefix * sizeof(SvoRecord), hipMemcpyDeviceToHost));
+            c->box_valid = scene_box(top.data(), top.size(), depth, c->root_center, c->root_size, c->box_min, c->box_max);
+        }
         return VXRT_OK;
     }
     std::vector<SvoRecord> recs;

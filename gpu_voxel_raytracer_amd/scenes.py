@@ -46,3 +46,14 @@ def close_camera(size_xyz):
 def reference_start_camera():
     """The reference's start-up camera (src/context.rs:618-622)."""
     return np.array([0.0, 0.0, -2.0], np.float32), np.array([0.0, 0.0, 1.0], np.float32), FOV_70
+
+
+# BASELINE configs[4] (SURVEY.md §8d config 5): the procedural level-7 Menger sponge clipped to 2048^3 — level, clip, colour
+# (material, r, g, b), emissive period — and its two views (Context.set_menger(*CONFIG5)).
+CONFIG5 = (7, 2048, (0, 150, 170, 120), 8192)
+
+
+def config5_cameras():
+    ext = np.float32(1024)   # world extent of 2048 voxels
+    return {"outside": (np.array([-0.9, 0.6, -1.2], np.float32) * ext + ext / 2, np.array([0.9, -0.6, 1.2], np.float32), 1.2217305),
+            "tunnel": (np.array([0.5, 0.5, 0.02], np.float32) * ext, np.array([0.05, 0.03, 1.0], np.float32), 1.2217305)}

@@ -8,8 +8,10 @@ Parity status of the scene itself: BASELINE.json's config, not a reference fixtu
 import numpy as np
 import pytest
 
-MRGB = (0, 150, 170, 120)
-FULL = (7, 2048, MRGB, 8192)          # level, clip, colour, emissive period (scripts/exp_baseline_configs.py)
+from gpu_voxel_raytracer_amd.scenes import CONFIG5 as FULL       # level, clip, colour, emissive period
+from gpu_voxel_raytracer_amd.scenes import config5_cameras
+
+MRGB = FULL[2]
 
 
 def voxel_list(O, level, clip, mrgb, period):
@@ -21,9 +23,7 @@ def voxel_list(O, level, clip, mrgb, period):
 
 
 def full_size_cameras():
-    ext = np.float32(1024)   # world extent of 2048 voxels
-    return {"outside": (np.array([-0.9, 0.6, -1.2], np.float32) * ext + ext / 2, np.array([0.9, -0.6, 1.2], np.float32), 1.2217305),
-            "tunnel": (np.array([0.5, 0.5, 0.02], np.float32) * ext, np.array([0.05, 0.03, 1.0], np.float32), 1.2217305)}
+    return config5_cameras()
 
 
 def primary_rays(O, cam, w, h, n, rng):
