@@ -24,7 +24,7 @@ def launches(sub, counter=None):
         rows = list(csv.DictReader(open(f)))
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
         for r in rows:
-            m = re.search(r"(temporal_kernel|denoise_kernel<\w+>|denoise_kernel|denoise_passthrough_kernel)", r["Kernel_Name"])
+            m = re.search(r"(temporal_kernel|denoise_pair_kernel|denoise_generic_kernel|denoise_passthrough_kernel)", r["Kernel_Name"])
             if not m:
                 continue
             if counter:
@@ -39,16 +39,21 @@ def split(seq, n):
     """scripts/post_stage_run.py's launch order -> {label: [values]} (warm-up launches dropped)"""
     groups = collections.defaultdict(list)
     temporal = [v for k, v in seq if k == "temporal_kernel"]
-    den = [(k, v) for k, v in seq if k.startswith("denoise_kernel")]
+    den = [(k, v) for k, v in seq if k in ("denoise_pair_kernel", "denoise_generic_kernel")]
     # temporal: 3 radii x (2 warm-up + n)
     for i, r in enumerate((0, 2, 8)):
         groups[f"temporal_kernel (r={r}{', denoise fused' if r == 0 else ''})"] = temporal[i * (2 + n) + 2:(i + 1) * (2 + n)]
-    # denoise_kernel: per radius in (2, 8): 2 warm-up + n in-frame (exact), then 1 + n exact, 1 + n tolerant
-    per = 2 + n + 2 * (1 + n)
+    # denoise: per radius in (2, 8): 2 warm-up + n in-frame (exact, fast kernel), then 1 + n each of: exact, tolerant (denoise_pair_kernel: two
+    # outputs per lane), exact generic, tolerant generic (denoise_generic_kernel: round 2's kernel, one output per lane, full formula)
+    per = 2 + n + 4 * (1 + n)
     for i, r in enumerate((2, 8)):
         blk = den[i * per:(i + 1) * per]
-        groups[f"denoise_kernel r={r} exact"] = [v for _, v in blk[2 + n + 1:2 + n + 1 + n]]
-        groups[f"denoise_kernel r={r} tolerant"] = [v for _, v in blk[2 + n + 1 + n + 1:]]
+        for j, label in enumerate(("exact", "tolerant", "exact, generic kernel", "tolerant, generic kernel")):
+            first = 2 + n + j * (1 + n) + 1
+            part = blk[first:first + n]
+            want = "denoise_generic_kernel" if "generic" in label else "denoise_pair_kernel"
+            assert all(k == want for k, _ in part), (label, [k for k, _ in part])
+            groups[f"denoise r={r} {label}"] = [v for _, v in part]
     return groups
 
 
@@ -56,6 +61,7 @@ out = {"workload": f"vox/monu10.vox {W}x{H}, 8 bounces, temporal + denoise (BASE
 dur = split(launches("stats"), N_STATS)
 fetch = split(launches("fetch", "FETCH_SIZE"), N_PMC)
 write = split(launches("write", "WRITE_SIZE"), N_PMC)
+sq = {c: split(launches("sq", c), N_PMC) for c in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAVES")}
 for label, d in dur.items():
     if not d:
         continue
@@ -68,9 +74,16 @@ for label, d in dur.items():
         k.update({"fetch_size_kb": fk, "write_size_kb": wk, "hbm_bytes_raw": (fk + wk) * 1024, "hbm_bytes_read_doubled": (2 * fk + wk) * 1024,
                   "hbm_gbs_raw": round((fk + wk) * 1024 / (ms * 1e-3) / 1e9, 1), "hbm_gbs_read_doubled": round((2 * fk + wk) * 1024 / (ms * 1e-3) / 1e9, 1),
                   "frac_of_8TBs_read_doubled": round((2 * fk + wk) * 1024 / (ms * 1e-3) / 8e12, 4)})
-    if label.startswith("denoise_kernel"):
+    if label.startswith("denoise r="):
         r = int(re.search(r"r=(\d+)", label)[1])
-        k["taps_per_s"] = round((2 * r + 1) ** 2 * px / (ms * 1e-3), -9)
+        taps = (2 * r + 1) ** 2 * px
+        k["taps_per_s"] = round(taps / (ms * 1e-3), -9)
+        for c, g in sq.items():
+            if g.get(label):
+                k[c.lower() + "_per_launch"] = sum(g[label]) / len(g[label])
+        if "sq_insts_valu_per_launch" in k:
+            k["valu_lane_instr_per_tap"] = round(k["sq_insts_valu_per_launch"] * 64 / taps, 2)
+            k["lds_wave_instr_per_1000_taps"] = round(k.get("sq_insts_lds_per_launch", 0) * 1000 / taps, 3)
     out["kernels"][label] = k
 out["note"] = ("temporal with radius 0 also does the denoise stage's work (mix with the albedo) in the same pass: 64 B read (sampled colour, new "
                "normal/depth, old colour, old normal/depth) + 16 B albedo read + 2 x 16 B written = 112 B/px algorithmic; sky pixels skip the "
