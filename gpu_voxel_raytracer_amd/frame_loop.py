@@ -63,8 +63,10 @@ def load_into(ctx, scene, whole_scene=False):
 
 
 def run(scene="menger", width=1280, height=720, frames=16, bounces=3, radius=0, moving=False, out=None, device=0,
-        frames_in_flight=1, dump_every=0, noise="white", spp=1, whole_scene=False):
-    """Renders `frames` frames; returns the last denoised frame (float32 [h, w, 4]) and the context statistics."""
+        frames_in_flight=1, dump_every=0, noise="white", spp=1, whole_scene=False, float_dump=False):
+    """Renders `frames` frames; returns the last denoised frame (float32 [h, w, 4]) and the context statistics.
+    float_dump: also write the frame losslessly as <out>.npy (float32 [h, w, 4], linear radiance as denoise.comp stores it) — the
+    lossless counterpart of the 8-bit sRGB PNG (SURVEY.md 8f n1 asks for PNG / EXR; no EXR writer is available here)."""
     from . import host
     with Context(width, height, device=device, max_bounces=bounces, frames_in_flight=frames_in_flight,
                  frames_per_launch=min(max(spp, 1), 32) if spp > 1 else min(max(frames, 1), 16)) as ctx:
@@ -95,6 +97,8 @@ def run(scene="menger", width=1280, height=720, frames=16, bounces=3, radius=0, 
         st = ctx.stats()
     if out:
         save_png(img, out + ".png")
+        if float_dump:
+            np.save(out + ".npy", np.ascontiguousarray(img, np.float32))
     return img, st
 
 
@@ -117,10 +121,11 @@ def main():
     ap.add_argument("--noise", default="white", help="white (seeded stand-in), blue (void-and-cluster, made on the GPU) or an archive")
     ap.add_argument("--spp", type=int, default=1, help="samples per pixel per displayed frame (vxrt_render_spp)")
     ap.add_argument("--whole-scene", action="store_true", help="place every model of a .vox file's scene graph")
+    ap.add_argument("--float-dump", action="store_true", help="also write <out>.npy: the frame as float32 [h, w, 4], lossless")
     ap.add_argument("--out", default="gpurun_out/frame")
     args = ap.parse_args()
     img, st = run(args.scene, args.width, args.height, args.frames, args.bounces, args.radius, args.moving, args.out,
-                  dump_every=args.dump_every, noise=args.noise, spp=args.spp, whole_scene=args.whole_scene)
+                  dump_every=args.dump_every, noise=args.noise, spp=args.spp, whole_scene=args.whole_scene, float_dump=args.float_dump)
     print(f"{args.scene}: {st.frames} frames, {st.rays} rays, image {img.shape[1]}x{img.shape[0]} -> {args.out}.png, "
           f"mean radiance {float(np.nanmean(img[..., :3])):.4f}")
 

@@ -196,7 +196,25 @@ class Context {
         check(vxrt_set_denoise(ctx_, &denoise_uniforms), "vxrt_set_denoise");
         check(vxrt_render_spp(ctx_, flags, spp), "vxrt_render_spp");
     }
-    // run-time options (vxrt.h: VXRT_OPT_DENOISE_MODE, VXRT_OPT_TAIL_CAPACITY, VXRT_OPT_SCENE_FORMAT)
+    // vxrt_render without re-pushing the parameter blocks: the stages of a frame around a halo exchange
+    void render_stage(uint32_t flags) { check(vxrt_render(ctx_, flags), "vxrt_render"); }
+    // Multi-GPU halo (vxrt.h "halo"): one frame of a rank = render(VXRT_TRACE | VXRT_TEMPORAL); halo_pack; [send / receive on comm_stream];
+    // render_stage(VXRT_DENOISE_INTERIOR); halo_unpack; render_stage(VXRT_DENOISE_EDGE) — ordered by events, the host never waits.
+    vxrt_halo_info halo_info() {
+        check(vxrt_set_denoise(ctx_, &denoise_uniforms), "vxrt_set_denoise");   // the halo's row count follows the radius
+        vxrt_halo_info info{};
+        check(vxrt_halo_info_get(ctx_, &info), "vxrt_halo_info_get");
+        return info;
+    }
+    void halo_pack(void* dev_to_prev, void* dev_to_next, void* comm_stream) {
+        check(vxrt_halo_pack(ctx_, dev_to_prev, dev_to_next), "vxrt_halo_pack");
+        check(vxrt_stream_wait_context(ctx_, comm_stream), "vxrt_stream_wait_context");
+    }
+    void halo_unpack(const void* dev_from_prev, const void* dev_from_next, void* comm_stream) {
+        check(vxrt_context_wait_stream(ctx_, comm_stream), "vxrt_context_wait_stream");
+        check(vxrt_halo_unpack(ctx_, dev_from_prev, dev_from_next), "vxrt_halo_unpack");
+    }
+    // run-time options (vxrt.h: VXRT_OPT_DENOISE_MODE, VXRT_OPT_TAIL_CAPACITY, VXRT_OPT_SCENE_FORMAT, VXRT_OPT_HALO_ROWS, VXRT_OPT_SKY_CULL)
     void set_option(vxrt_option option, uint32_t value) { check(vxrt_set_option(ctx_, option, value), "vxrt_set_option"); }
     void sync() { check(vxrt_sync(ctx_), "vxrt_sync"); }
     std::vector<float> read(vxrt_image which) {

@@ -236,9 +236,10 @@ def test_headless_frame_loop(H, scenes, tmp_path):
     """the headless driver renders a camera path and writes what the reference would display."""
     from gpu_voxel_raytracer_amd import frame_loop
     out = str(tmp_path / "castle")
-    img, st = frame_loop.run("castle", 160, 96, frames=6, bounces=3, radius=1, moving=True, out=out, dump_every=3)
+    img, st = frame_loop.run("castle", 160, 96, frames=6, bounces=3, radius=1, moving=True, out=out, dump_every=3, float_dump=True)
     assert img.shape == (96, 160, 4) and np.isfinite(img).all() and st.frames == 6
     assert os.path.exists(out + ".png") and os.path.exists(out + "_0003.png") and os.path.exists(out + "_0006.png")
+    assert np.array_equal(np.load(out + ".npy"), img)          # the lossless dump
     # converged static view is less noisy than a single frame
     one, _ = frame_loop.run("castle", 160, 96, frames=1, bounces=3)
     many, _ = frame_loop.run("castle", 160, 96, frames=24, bounces=3)
