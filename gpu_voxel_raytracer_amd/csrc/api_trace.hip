@@ -7,28 +7,40 @@
 
 namespace vxrt {
 
-// new capacity (records per shard) for the path queues of every stream; waits for the GPU first
+// new capacity (records per shard) for the path queues of every stream; waits for the GPU first.  All new buffers are allocated before
+// any old one is released: if an allocation fails the context keeps its queues, its capacity and its accounting as they were.
 int resize_tail_queues(vxrt_ctx* c, unsigned want) {
     want = want > c->shard_capacity_max ? c->shard_capacity_max : (want + 63u) / 64u * 64u;
     if (want == c->shard_capacity) return VXRT_OK;
     if (int rc = sync_all(c)) return rc;
-    const size_t hit_bytes = (size_t(want) * 64 + 1) * 64;
+    const size_t new_bytes = (size_t(want) * 64 + 1) * 64, old_bytes = (size_t(c->shard_capacity) * 64 + 1) * 64;
+    std::vector<float4*> fresh;
+    for (vxrt_ctx::StreamQueues& q : c->queues)
+        for (float4* p : q.hitq)
+            if (p) {
+                float4* n = nullptr;
+                const hipError_t e = hipMalloc(reinterpret_cast<void**>(&n), new_bytes);
+                if (e != hipSuccess) {
+                    for (float4* f : fresh) (void)hipFree(f);
+                    return hip_fail(e, "hipMalloc (tail queues)");
+                }
+                fresh.push_back(n);
+            }
+    size_t k = 0;
     for (vxrt_ctx::StreamQueues& q : c->queues)
         for (float4*& p : q.hitq)
             if (p) {
                 (void)hipFree(p);
-                p = nullptr;
-                c->queue_bytes -= (size_t(c->shard_capacity) * 64 + 1) * 64;
-                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p), hit_bytes));
-                c->queue_bytes += hit_bytes;
+                p = fresh[k++];
+                c->queue_bytes += new_bytes - old_bytes;
             }
     c->shard_capacity = want;
     return VXRT_OK;
 }
 
-// Tail queues sized by need: look at what the stream's last launch wanted (its shard counters, copied back after the launch) and,
-// if that did not fit, make the stream's queues larger before its next launch.  Paths that did not fit were followed by the head
-// kernel itself, so no frame was wrong — only slower.
+// Tail queues sized by need: look at what the stream's last launch wanted (its shard counters, copied back after the launch, with the
+// capacity that launch ran with) and, if that did not fit, make the queues larger before the stream's next launch.  Paths that did not
+// fit were followed by the head kernel itself, so no frame was wrong — only slower.
 int grow_tail_queues(vxrt_ctx* c, size_t lane) {
     vxrt_ctx::StreamQueues& sq = c->queues[lane];
     if (!sq.counts_pending || hipEventQuery(sq.counts_ready) != hipSuccess) return VXRT_OK;
@@ -37,7 +49,7 @@ int grow_tail_queues(vxrt_ctx* c, size_t lane) {
     for (unsigned s = 0; s < 64; s++) {
         const unsigned n = sq.host_counts[s * 16];
         peak = n > peak ? n : peak;
-        if (n > c->shard_capacity) c->queue_overflow_paths += n - c->shard_capacity;
+        if (n > sq.counts_capacity) c->queue_overflow_paths += n - sq.counts_capacity;   // against the capacity THAT launch had
     }
     if (peak <= c->shard_capacity || c->tail_capacity_override > 0 || c->shard_capacity >= c->shard_capacity_max) return VXRT_OK;
     // every stream's queues share one capacity (PathQueue::shard_capacity travels with the launch): grow them all, at rest
@@ -164,6 +176,8 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
     a.cam = cams[0];
     for (uint32_t k = 0; k < g; k++) a.cams[k] = cams[k];
     if (c->band.local_rows > 0) {
+        // the tail queues grow (host wait + reallocation) BEFORE the launch's timed region starts
+        if (c->trace_variant >= 4 && !c->queues.empty()) { if (int rc = grow_tail_queues(c, lane)) return rc; }
         EventPair p;
         if (timed) { p = take_pair(c, 0); HIP_TRY(hipEventRecord(p.a, ts)); }
         a.tail = PathQueue{nullptr, nullptr, 0};
@@ -179,7 +193,6 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
         if (variant == 0 || variant >= 4) {
             if (variant >= 4) {
                 // count sets rotate as in launch_trace_wavefront: launch J reads set J%3, writes (J+1)%3, clears (J+2)%3
-                if (int rc = grow_tail_queues(c, lane)) return rc;
                 vxrt_ctx::StreamQueues& sq = c->queues[lane];
                 unsigned* sets[3] = {sq.counts3, sq.counts3 + 64 * 16, sq.counts3 + 2 * 64 * 16};
                 const unsigned J = sq.launches;
@@ -192,6 +205,7 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
                     HIP_TRY(hipMemcpyAsync(sq.host_counts, sets[(J + 1) % 3], 64 * 64, hipMemcpyDeviceToHost, ts));
                     HIP_TRY(hipEventRecord(sq.counts_ready, ts));
                     sq.counts_pending = true;
+                    sq.counts_capacity = c->shard_capacity;
                 }
 #if VXRT_VARIANTS
                 if (c->trace_variant == 5) {

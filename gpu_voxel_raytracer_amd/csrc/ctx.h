@@ -145,6 +145,7 @@ struct vxrt_ctx {
         unsigned* host_counts = nullptr;        // pinned, one set: 64 counters, 16 uints apart
         hipEvent_t counts_ready = nullptr;
         bool counts_pending = false;
+        unsigned counts_capacity = 0;           // the shard capacity of the launch whose counters host_counts holds
     };
     std::vector<StreamQueues> queues;
     unsigned shard_capacity = 0;        // records per shard of the path queues

@@ -682,7 +682,9 @@ __device__ __forceinline__ Shaded shade_hit(const TraceArgs& a, int bounce, f3 h
 // wide and the power is EXACTLY zero for every direction further from the sun: vx_pow = vx_exp(y * vx_log(x)), and vx_exp
 // returns +0 for every argument below -87.3.  TraceArgs::sun_zero_below is a bound (made on the host with a safety margin three
 // orders of magnitude above vx_log's error) below which that is certain, so most sky pixels skip the ~90 instructions of log and
-// exp; the result is the same bit pattern either way (tests/test_gpu_detmath.py::test_sun_power_shortcut).
+// exp; the result is the same bit pattern either way (the bound: tests/test_detmath_cpu.py::test_sun_power_is_exactly_zero_below_the_kernels_bound;
+// on the device, other sun sizes with the sun in view: tests/test_gpu_trace.py::test_sun_power_shortcut_with_other_sun_sizes; the
+// build without the shortcut, -DVXRT_SUN_SHORTCUT=0, goes through the parity tests in scripts/test_variants.sh).
 __device__ __forceinline__ float sun_power_of(const TraceArgs& a, f3 d) {
     const float x = vx_max(0.0f, dot3(d, ld3(a.neg_sun_dir_n)));
 #ifndef VXRT_SUN_SHORTCUT

@@ -466,3 +466,37 @@ def test_sky_cull_beside_the_iteration_cap_scene(O, H, noise):
             for a, b, label in zip(g, ref[:3], ("colour", "nd", "albedo")):
                 assert_bits_equal(a, b, f"{label} beside the row")
             assert rays == ref[3]
+
+
+@pytest.mark.parametrize("sun_size", [0.02, 0.05, 0.2, 0.8, 3.0])
+def test_sun_power_shortcut_with_other_sun_sizes(O, H, scenes, noise, sun_size):
+    """sun_power_of (csrc/trace_common.h): pow(x, 1 / sun_size^2) of voxels.comp:378-381 is skipped where a host-made bound proves
+    it exactly +0.  The default sun_size (0.05: exponent 400) is what every other test runs; here the exponent is 2500, 25, 1.56 and
+    0.11 (no shortcut: the bound exists only for exponents > 1), with the camera turned towards the sun so that the disc, its rim and
+    the exactly-zero region are all in the frame — sky pixels (culled and walked ones) equal the oracle's bit for bit."""
+    from gpu_voxel_raytracer_amd import TRACE, Camera, Context
+    pos, mrgb, size = scenes.load_scene("castle")
+    w, h = 256, 160
+    u = O.Uniforms.default()
+    u.sun_size = sun_size
+    sun = np.array([np.cos(u.sun_yaw) * np.cos(u.sun_pitch), -np.sin(u.sun_pitch), np.sin(u.sun_yaw) * np.cos(u.sun_pitch)], np.float32)
+    cam_pos = scenes.bench_camera(size)[0]
+    cam = (cam_pos, (-sun + np.array([0.15, -0.1, 0.05], np.float32)).astype(np.float32), 1.3)     # looking at the sun, a little off-centre
+    u.set_camera(cam[0], O.camera_axis_scaled(cam[0], cam[1], cam[2], w, h))
+    u.frame_number = 1
+    ref = O.trace(O.create_octree(pos, mrgb), noise, u, w, h, 2, crop=(0, 0, w, h))
+    sky = ref[1][..., 3] < 0
+    lum = ref[0][..., 0][sky]
+    assert sky.mean() > 0.5 and lum.max() > lum.min()                      # the sun's disc shows in the sky
+    if sun_size <= 0.2:
+        assert (lum == lum.min()).mean() > 0.1                             # ... and so does the region where its power is exactly 0
+    for cull in (1, 0):
+        with Context(w, h, max_bounces=2, noise=noise) as ctx:
+            ctx.recreate_octree(pos, mrgb)
+            ctx.set_option(H.OPT_SKY_CULL, cull)
+            ctx.camera = Camera(*cam)
+            ctx.uniforms.sun_size = sun_size
+            ctx.render(TRACE)
+            for i, label in enumerate(("colour", "nd", "albedo")):
+                assert_bits_equal(ctx.read(i), ref[i], f"{label}, sun_size {sun_size}, cull {cull}")
+            assert ctx.stats().rays == ref[3]
