@@ -372,7 +372,8 @@ __device__ __forceinline__ void pair_tap(const DenoiseArgs& a, PairCentre& ct, f
             const float factor_range = (dot3(cd, cd) + 1e4f * (bd * bd)) / a.sigma_range_2;
             const float arg = -factor_range - wd;
             if (!(arg < -87.3f)) {      // below: exp is exactly +0 and the (finite) colour times it adds nothing
-                const float f = vx_exp(arg);
+                // plain pixels: factor_range and the distance term are finite and >= 0, so arg is a number in [-87.3, 0]
+                const float f = vx_exp_in_range(arg);
                 ct.norm += f;
                 ct.sum = ct.sum + wc * f;
             }

@@ -114,10 +114,15 @@ VX_HD float vx_tan(float x) { return vx_sin(x) / vx_cos(x); }
 /* ---- exp ------------------------------------------------------------------------------------
  * exp(x) = 2^k * e^r, k = round(x/ln2), |r| <= ln2/2, degree-7 Taylor–Horner.  Results below
  * the normal range are flushed to +0 (x < -87.3), above to +inf (x > 88.7); NaN -> NaN. */
+VX_HD float vx_exp_in_range(float x);
 VX_HD float vx_exp(float x) {
     if (!(x == x)) return x;
     if (x > 88.72f) return vx_u2f(0x7f800000u);
     if (x < -87.3f) return 0.0f;
+    return vx_exp_in_range(x);
+}
+/* vx_exp for an argument the caller knows to lie in [-87.3, 88.72] (not NaN): the same operations without the three range tests */
+VX_HD float vx_exp_in_range(float x) {
     float kf = vx_floor(x * 1.44269504088896341f + 0.5f);
     float r = x - kf * 6.93145752e-01f;   /* ln2 hi, 0x3f317200 */
     r = r - kf * 1.42860677e-06f;         /* ln2 lo */

@@ -488,7 +488,7 @@ def test_sun_power_shortcut_with_other_sun_sizes(O, H, scenes, noise, sun_size):
     sky = ref[1][..., 3] < 0
     lum = ref[0][..., 0][sky]
     assert sky.mean() > 0.5 and lum.max() > lum.min()                      # the sun's disc shows in the sky
-    if sun_size <= 0.2:
+    if sun_size <= 0.05:
         assert (lum == lum.min()).mean() > 0.1                             # ... and so does the region where its power is exactly 0
     for cull in (1, 0):
         with Context(w, h, max_bounces=2, noise=noise) as ctx:

@@ -145,7 +145,7 @@ def test_bench_schedule_choice():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     assert bench.pick_schedule(1, 1000) == (2, 16) and bench.pick_schedule(2, 1000) == (3, 16)
-    assert bench.pick_schedule(4, 1000) == (3, 32) and bench.pick_schedule(8, 1000) == (3, 32)   # never more than 3 trace streams
+    assert bench.pick_schedule(4, 1000) == (3, 16) and bench.pick_schedule(8, 1000) == (3, 16)   # never more than 3 trace streams
     assert bench.pick_schedule(1, 20) == (3, 7)                     # the driver's --steps 20: three launches of 7, 7 and 6 frames
     for world in (1, 2, 4, 8):
         for steps in (1, 2, 5, 20, 63, 64, 100):
