@@ -4,12 +4,16 @@ One "displayed frame" = `spp` trace frames averaged (vxrt_render_spp) + temporal
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from gpu_voxel_raytracer_amd import ALL, TRACE, TEMPORAL, Camera, Context, scenes
+import ctypes as C
+from gpu_voxel_raytracer_amd import ALL, DENOISE_EDGE, DENOISE_INTERIOR, TRACE, TEMPORAL, Camera, Context, distributed, scenes
 
 
-def run(label, w, h, bounces, spp, flags, radius, scene=None, menger=None, rank=0, nranks=1, cam=None, shown=12, batch=None, inflight=2):
+def run(label, w, h, bounces, spp, flags, radius, scene=None, menger=None, rank=0, nranks=1, cam=None, shown=12, batch=None, inflight=2, band=16,
+        halo_loop=False):
+    """halo_loop: a rank's whole frame of the multi-rank loop — trace + temporal, halo pack, denoise of the interior tiles, halo unpack,
+    denoise of the edge tiles — with the rank's own messages handed back to it (the work of a rank without the transfer time)."""
     batch = batch or min(spp, 16)
-    with Context(w, h, max_bounces=bounces, rank=rank, nranks=nranks, frames_per_launch=batch, frames_in_flight=inflight) as ctx:
+    with Context(w, h, max_bounces=bounces, rank=rank, nranks=nranks, frames_per_launch=batch, frames_in_flight=inflight, band_rows=band) as ctx:
         if menger:
             ctx.set_menger(*menger)
         else:
@@ -19,6 +23,20 @@ def run(label, w, h, bounces, spp, flags, radius, scene=None, menger=None, rank=
         ctx.camera = Camera(*cam)
         ctx.denoise_uniforms.radius = radius
         render = (lambda: ctx.render_spp(flags, spp)) if spp > 1 else (lambda: ctx.render_frames(flags, 16))
+        if halo_loop:
+            rt = C.CDLL("libamdhip64.so")
+            rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+            bufs = [C.c_void_p() for _ in range(2)]
+            nbytes = ctx.halo_bytes()
+            for b in bufs:
+                assert rt.hipMalloc(C.byref(b), nbytes) == 0
+
+            def render():
+                ctx.render_spp(TRACE | TEMPORAL, spp)
+                ctx.halo_pack(bufs[0].value, bufs[1].value)
+                ctx.render_stage(DENOISE_INTERIOR)
+                ctx.halo_unpack(bufs[0].value, bufs[1].value)
+                ctx.render_stage(DENOISE_EDGE)
         per_call = spp if spp > 1 else 16
         for _ in range(3):
             render()
@@ -38,8 +56,12 @@ run("config 2  menger 1920x1080, 1 spp, 4 bounces, trace only", 1920, 1080, 4, 1
 for r in (2, 8):
     run(f"config 3  monu10 3840x2160, 4 spp, 8 bounces, temporal + denoise r={r}", 3840, 2160, 8, 4, ALL, r, scene="monu10")
 for rank in (0, 5):
-    run(f"config 4  castle 3840x2160, 4 spp, 8 bounces, rank {rank} of 8 (trace + temporal; denoise needs the halo)", 3840, 2160, 8, 4,
+    run(f"config 4  castle 3840x2160, 4 spp, 8 bounces, rank {rank} of 8, 16-row bands (trace + temporal)", 3840, 2160, 8, 4,
         TRACE | TEMPORAL, 2, scene="castle", rank=rank, nranks=8)
+    run(f"config 4  castle 3840x2160, 4 spp, 8 bounces, rank {rank} of 8, 64-row bands (trace + temporal)", 3840, 2160, 8, 4,
+        TRACE | TEMPORAL, 2, scene="castle", rank=rank, nranks=8, band=distributed.band_rows_for(8))
+    run(f"config 4  castle 3840x2160, 4 spp, 8 bounces, rank {rank} of 8, 64-row bands, the rank's whole loop with denoise r=8 (no transfer time)",
+        3840, 2160, 8, 4, ALL, 8, scene="castle", rank=rank, nranks=8, band=distributed.band_rows_for(8), halo_loop=True)
 ext = np.float32(1024)
 outside = (np.array([-0.9, 0.6, -1.2], np.float32) * ext + ext / 2, np.array([0.9, -0.6, 1.2], np.float32), 1.2217305)
 for rank in (0, 5):
