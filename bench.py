@@ -394,7 +394,8 @@ def pipeline_bench(args):
 
         render_spp(TRACE | TEMPORAL, 4) -> halo pack -> [two sends + two receives] -> DENOISE_INTERIOR -> halo unpack -> DENOISE_EDGE
 
-    with band_rows >= 8 r (64 rows at r = 8: the halo is a quarter of a rank's rows) and everything ordered by events.  One step = one
+    with band_rows chosen by distributed.band_rows_for (48 or 64 rows at r = 8: the halo is a third or a quarter of a rank's rows, whichever
+    leaves the busiest rank fewer rows) and everything ordered by events.  One step = one
     displayed frame.  Reported apart: halo bytes per rank and frame, the pack / unpack kernel times (HIP events), and — from a second,
     synchronised pass in which nothing overlaps — the time of the exchange alone and the frame time without overlap."""
     world, rank, device, dist, torch, backend = init_dist()
@@ -402,7 +403,7 @@ def pipeline_bench(args):
     red_dev = "cuda" if backend == "nccl" else "cpu"
     from gpu_voxel_raytracer_amd import DENOISE, TEMPORAL, TIMED, TRACE, Camera, Context, distributed, scenes
     w, h, bounces, spp, radius = 3840, 2160, 8, 4, args.radius
-    band = args.band_rows or distributed.band_rows_for(radius)
+    band = args.band_rows or distributed.band_rows_for(radius, h, world)
     pos, mrgb, size = scenes.load_scene("castle")
     cam = scenes.close_camera(size)
     ctx = Context(w, h, device=device, max_bounces=bounces, rank=rank, nranks=world, band_rows=band, frames_in_flight=1,

@@ -55,13 +55,14 @@ def run(label, w, h, bounces, spp, flags, radius, scene=None, menger=None, rank=
 run("config 2  menger 1920x1080, 1 spp, 4 bounces, trace only", 1920, 1080, 4, 1, TRACE, 0, scene="menger", batch=16)
 for r in (2, 8):
     run(f"config 3  monu10 3840x2160, 4 spp, 8 bounces, temporal + denoise r={r}", 3840, 2160, 8, 4, ALL, r, scene="monu10")
-for rank in (0, 5):
+for rank in (0, 1, 5, 7):
     run(f"config 4  castle 3840x2160, 4 spp, 8 bounces, rank {rank} of 8, 16-row bands (trace + temporal)", 3840, 2160, 8, 4,
         TRACE | TEMPORAL, 2, scene="castle", rank=rank, nranks=8)
-    run(f"config 4  castle 3840x2160, 4 spp, 8 bounces, rank {rank} of 8, 64-row bands (trace + temporal)", 3840, 2160, 8, 4,
-        TRACE | TEMPORAL, 2, scene="castle", rank=rank, nranks=8, band=distributed.band_rows_for(8))
-    run(f"config 4  castle 3840x2160, 4 spp, 8 bounces, rank {rank} of 8, 64-row bands, the rank's whole loop with denoise r=8 (no transfer time)",
-        3840, 2160, 8, 4, ALL, 8, scene="castle", rank=rank, nranks=8, band=distributed.band_rows_for(8), halo_loop=True)
+    for band in (48, 64):
+        run(f"config 4  castle 3840x2160, 4 spp, 8 bounces, rank {rank} of 8, {band}-row bands (trace + temporal)", 3840, 2160, 8, 4,
+            TRACE | TEMPORAL, 2, scene="castle", rank=rank, nranks=8, band=band)
+        run(f"config 4  castle 3840x2160, 4 spp, 8 bounces, rank {rank} of 8, {band}-row bands, the rank's whole loop with denoise r=8 (no transfer time)",
+            3840, 2160, 8, 4, ALL, 8, scene="castle", rank=rank, nranks=8, band=band, halo_loop=True)
 ext = np.float32(1024)
 outside = (np.array([-0.9, 0.6, -1.2], np.float32) * ext + ext / 2, np.array([0.9, -0.6, 1.2], np.float32), 1.2217305)
 for rank in (0, 5):

@@ -190,3 +190,11 @@ def test_band_layout_row_rule_is_the_librarys():
         with pytest.raises(ValueError):
             D.BandLayout(1920, 1080, 8, bad[0], radius=bad[1])
     D.BandLayout(1920, 1080, 8, 32, radius=8)
+    # band height for the frame loop: >= 8 r without a frame size; with one, the candidate in [48, 8 r] that leaves the busiest rank fewest rows
+    assert D.band_rows_for(0) == 16 and D.band_rows_for(2) == 16 and D.band_rows_for(8) == 64 and D.band_rows_for(3) == 32
+    assert D.band_rows_for(8, 2160, 8) == 48 and D.band_rows_for(8, 2160, 2) == 64 and D.band_rows_for(8, 2160, 1) == 64
+    for radius, h, n in ((8, 2160, 8), (8, 2160, 4), (8, 1080, 8), (4, 2160, 3), (1, 720, 2)):
+        band = D.band_rows_for(radius, h, n)
+        assert band % 16 == 0 and 48 <= band <= max(64, 8 * radius)
+        most = max(len(D.BandLayout(w := 64, h, n, band).rows(r)) for r in range(n))
+        assert all(most <= max(len(D.BandLayout(w, h, n, other).rows(r)) for r in range(n)) for other in range(48, max(64, 8 * radius) + 1, 16))
