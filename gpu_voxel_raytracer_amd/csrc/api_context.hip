@@ -22,8 +22,7 @@ int local_band_count(const BandMap& b) {
 void free_images(vxrt_ctx* c) {
     for (vxrt_ctx::Slot& sl : c->ring) {
         for (float4** p : {&sl.sampled_color, &sl.albedo, &sl.nd}) { if (*p) (void)hipFree(*p); *p = nullptr; }
-        if (sl.trace_done) (void)hipEventDestroy(sl.trace_done);
-        if (sl.last_use) (void)hipEventDestroy(sl.last_use);
+        if (sl.own) (void)hipEventDestroy(sl.own);
     }
     c->ring.clear();
     free_halo(c);
@@ -61,8 +60,8 @@ int alloc_images(vxrt_ctx* c) {
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), bytes));
             HIP_TRY(hipMemsetAsync(*p, 0, bytes, c->stream));
         }
-        HIP_TRY(hipEventCreateWithFlags(&sl.trace_done, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&sl.last_use, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl.own, hipEventDisableTiming));
+        sl.trace_done = sl.last_use = nullptr;
         sl.last_use_recorded = false;
     }
     float4** imgs[] = {&c->accum[0], &c->accum[1], &c->denoised};
@@ -334,6 +333,10 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) try {
         for (hipStream_t& t : c->trace_streams)
             if (hipStreamCreateWithFlags(&t, hipStreamNonBlocking) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipStreamCreate"));
     }
+    c->launch_events.assign(size_t(c->inflight) * 2, nullptr);
+    c->launch_event_turn.assign(size_t(c->inflight), 0u);
+    for (hipEvent_t& e : c->launch_events)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipEventCreate"));
     set_band(c, cfg->width, cfg->height);
     if ((rc = alloc_images(c)) != VXRT_OK) return fail(rc);
     if (hipMalloc(reinterpret_cast<void**>(&c->d_noise), kNoiseCount * sizeof(float)) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipMalloc noise"));
@@ -366,6 +369,7 @@ int vxrt_destroy(vxrt_ctx* c) try {
     if (c->d_rays) (void)hipFree(c->d_rays);
     for (hipStream_t t : c->trace_streams) if (t && t != c->stream) (void)hipStreamDestroy(t);
     if (c->halo_event) (void)hipEventDestroy(c->halo_event);
+    for (hipEvent_t e : c->launch_events) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return VXRT_OK;

@@ -53,7 +53,7 @@ int post_stages(vxrt_ctx* c, uint32_t flags, bool timed) {
     const bool multi = c->band.nranks > 1;
     vxrt_ctx::Slot& cur = c->ring[size_t(c->slot)];
     const bool post = (flags & (VXRT_TEMPORAL | VXRT_DENOISE | VXRT_DENOISE_INTERIOR | VXRT_DENOISE_EDGE)) != 0;
-    if (post && c->traced > 0) HIP_TRY(hipStreamWaitEvent(c->stream, cur.trace_done, 0));
+    if (post && cur.trace_done != nullptr) HIP_TRY(hipStreamWaitEvent(c->stream, cur.trace_done, 0));
 
     bool fused_denoise = false;
     if (flags & VXRT_TEMPORAL) {
@@ -87,7 +87,8 @@ int post_stages(vxrt_ctx* c, uint32_t flags, bool timed) {
             if (timed) { HIP_TRY(hipEventRecord(p.b, c->stream)); c->pending.push_back(p); }
         }
         if (c->hist_slot >= 0 && c->hist_slot != c->slot) {  // the old history slot may be traced into again after this
-            HIP_TRY(hipEventRecord(hist.last_use, c->stream));
+            HIP_TRY(hipEventRecord(hist.own, c->stream));
+            hist.last_use = hist.own;
             hist.last_use_recorded = true;
         }
         c->accum_is_sampled = false;
@@ -134,7 +135,8 @@ int post_stages(vxrt_ctx* c, uint32_t flags, bool timed) {
         }
     }
     if (post) {
-        HIP_TRY(hipEventRecord(cur.last_use, c->stream));
+        HIP_TRY(hipEventRecord(cur.own, c->stream));
+        cur.last_use = cur.own;
         cur.last_use_recorded = true;
     }
     return VXRT_OK;
@@ -233,7 +235,8 @@ int vxrt_render_spp(vxrt_ctx* c, uint32_t flags, uint32_t spp) try {
             SppArgs a{};
             for (uint32_t k = 0; k < g; k++) {
                 vxrt_ctx::Slot& sl = c->ring[size_t(slots[k])];
-                HIP_TRY(hipStreamWaitEvent(c->stream, sl.trace_done, 0));
+                if (sl.trace_done != nullptr && (k == 0 || sl.trace_done != c->ring[size_t(slots[k - 1])].trace_done))
+                    HIP_TRY(hipStreamWaitEvent(c->stream, sl.trace_done, 0));
                 a.frames[k] = sl.sampled_color;
             }
             a.sum = c->spp_sum;
@@ -243,7 +246,8 @@ int vxrt_render_spp(vxrt_ctx* c, uint32_t flags, uint32_t spp) try {
             HIP_TRY(launch_spp_accumulate(a, c->stream));
             for (uint32_t k = 0; k < g; k++) {  // the slots may be traced into again only after this pass has read them
                 vxrt_ctx::Slot& sl = c->ring[size_t(slots[k])];
-                HIP_TRY(hipEventRecord(sl.last_use, c->stream));
+                if (k == 0) HIP_TRY(hipEventRecord(sl.own, c->stream));   // one event for the pass; the batch's slots share it
+                sl.last_use = c->ring[size_t(slots[0])].own;
                 sl.last_use_recorded = true;
             }
         }

@@ -107,7 +107,7 @@ int vxrt_halo_pack(vxrt_ctx* c, void* dev_to_prev, void* dev_to_next) try {
     if (!dev_to_prev || !dev_to_next) { set_error("null halo buffer"); return VXRT_E_INVALID; }
     HIP_TRY(hipSetDevice(c->cfg.device));
     vxrt_ctx::Slot& cur = c->ring[size_t(c->slot)];
-    if (c->traced > 0) HIP_TRY(hipStreamWaitEvent(c->stream, cur.trace_done, 0));
+    if (cur.trace_done != nullptr) HIP_TRY(hipStreamWaitEvent(c->stream, cur.trace_done, 0));
     const HaloView v = view_for(c, rows);
     HaloPackArgs a;
     a.color = c->accum_is_sampled ? cur.sampled_color : c->accum[c->last];
@@ -125,7 +125,8 @@ int vxrt_halo_pack(vxrt_ctx* c, void* dev_to_prev, void* dev_to_next) try {
     HIP_TRY(launch_halo_pack(a, c->stream));
     HIP_TRY(hipEventRecord(p.b, c->stream));
     c->pending.push_back(p);
-    HIP_TRY(hipEventRecord(cur.last_use, c->stream));   // the slot may be traced into again only after its rows were packed
+    HIP_TRY(hipEventRecord(cur.own, c->stream));   // the slot may be traced into again only after its rows were packed
+    cur.last_use = cur.own;
     cur.last_use_recorded = true;
     return VXRT_OK;
 } VXRT_CATCH

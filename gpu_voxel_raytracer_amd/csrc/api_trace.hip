@@ -136,9 +136,13 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
     const size_t lane = size_t(c->trace_launches % uint64_t(c->inflight));
     hipStream_t ts = c->trace_streams[lane];
     vxrt_ctx::TileSchedule& sched = c->schedules[lane];
-    for (uint32_t k = 0; k < g; k++) {
+    hipEvent_t waited = nullptr;
+    for (uint32_t k = 0; k < g; k++) {   // the slots of an earlier launch share its event: wait for each event once
         vxrt_ctx::Slot& sl = c->ring[size_t(slots[k])];
-        if (sl.last_use_recorded) HIP_TRY(hipStreamWaitEvent(ts, sl.last_use, 0));
+        if (sl.last_use_recorded && sl.last_use != waited) {
+            HIP_TRY(hipStreamWaitEvent(ts, sl.last_use, 0));
+            waited = sl.last_use;
+        }
     }
 
     TraceArgs a;
@@ -246,10 +250,12 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
 #endif
         if (timed) c->pending.push_back(p);
     }
+    hipEvent_t done = c->launch_events[lane * 2 + (c->launch_event_turn[lane]++ & 1u)];
+    HIP_TRY(hipEventRecord(done, ts));   // one event for the whole launch
     for (uint32_t k = 0; k < g; k++) {
         vxrt_ctx::Slot& sl = c->ring[size_t(slots[k])];
-        HIP_TRY(hipEventRecord(sl.trace_done, ts));
-        HIP_TRY(hipEventRecord(sl.last_use, ts));  // until a later stage reads the slot, the trace is its last use
+        sl.trace_done = done;
+        sl.last_use = done;              // until a later stage reads the slot, the trace is its last use
         sl.last_use_recorded = true;
     }
     c->slot = slots[g - 1];

@@ -91,13 +91,18 @@ struct vxrt_ctx {
         float4* sampled_color = nullptr;
         float4* albedo = nullptr;
         float4* nd = nullptr;
-        hipEvent_t trace_done = nullptr;  // recorded on the slot's trace stream
-        hipEvent_t last_use = nullptr;    // recorded after the last stage that touched the slot
+        // Events.  A trace launch covers up to 32 slots and is ONE event (launch_events, per trace stream): recording two events
+        // per slot cost ~8 us of host time per frame of a launch — more than a rank of 8 can afford (scripts/exp_host_submit.py).
+        hipEvent_t own = nullptr;         // owned: recorded on the main stream by the stages that read the slot (temporal, denoise, halo pack, spp)
+        hipEvent_t trace_done = nullptr;  // handle, not owned: the event of the launch that traced the slot
+        hipEvent_t last_use = nullptr;    // handle: what must have finished before the slot is traced into again (`own` or a launch's event)
         bool last_use_recorded = false;
     };
     std::vector<Slot> ring;
     int inflight = 1;
     std::vector<hipStream_t> trace_streams;   // inflight entries; entry 0 is `stream` when inflight == 1
+    std::vector<hipEvent_t> launch_events;    // two per trace stream, used alternately: "this launch has finished"
+    std::vector<unsigned> launch_event_turn;
     int slot = 0;        // slot of the most recently traced frame
     int hist_slot = -1;  // slot whose normal/depth pairs with accum[hist] as the temporal history
     float4* accum[2] = {nullptr, nullptr};
