@@ -117,3 +117,55 @@ def test_tolerant_denoise_on_synthetic_gbuffers(O, H, scenes, noise, radius, mod
     want = oracle_denoise(O, color, nd, alb, cam, radius)
     err = got[..., :3].astype(np.float64) - want[..., :3]
     assert np.sqrt(np.mean(err ** 2)) <= 1e-5 and np.abs(err).max() <= 1e-4         # BASELINE's bar is RMSE <= 1e-3
+
+
+@pytest.mark.parametrize("nranks,band,radius,split", [(2, 16, 3, False), (3, 32, 8, True), (2, 48, 8, True)])
+def test_exotic_pixels_across_band_edges(O, H, scenes, noise, nranks, band, radius, split):
+    """The same synthetic G-buffer dealt to N contexts in row bands: non-finite colours, zero / NaN depths and odd normals sit in the
+    HALO rows too, where the fast kernel's literal path fetches its operands from the halo store instead of the rank's own images.
+    Stitched output equals the oracle's, with the denoise stage whole and split around the exchange."""
+    from gpu_voxel_raytracer_amd import (DENOISE, DENOISE_EDGE, DENOISE_INTERIOR, DENOISED, NORMAL_DEPTH, SAMPLED_COLOR, ALBEDO_NODE, TRACE,
+                                         Camera, Context)
+    w, h = 96, 200
+    color, nd, alb = synthetic_gbuffer(w, h, seed=nranks * 100 + band + radius, exotic=True, radius=radius)
+    pos, mrgb, size = scenes.load_scene("8x8x8")
+    cam = scenes.bench_camera(size)
+    want = oracle_denoise(O, color, nd, alb, cam, radius)
+    rt = hip()
+    rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    ctxs = [Context(w, h, max_bounces=1, noise=noise, rank=r, nranks=nranks, band_rows=band) for r in range(nranks)]
+    try:
+        rows = []
+        for c in ctxs:
+            c.recreate_octree(pos, mrgb)
+            c.camera = Camera(*cam)
+            c.render(TRACE)
+            c.sync()
+            rr = c.local_rows()
+            rows.append(rr)
+            for which, img in ((SAMPLED_COLOR, color), (NORMAL_DEPTH, nd), (ALBEDO_NODE, alb)):
+                ptr, nbytes = c.device_image(which)
+                mine = np.ascontiguousarray(img[rr])
+                assert nbytes == mine.nbytes
+                assert rt.hipMemcpy(C.c_void_p(ptr), mine.ctypes.data_as(C.c_void_p), nbytes, 1) == 0
+            c.denoise_uniforms.radius = radius
+            c.update_bindings()
+        bufs = {}
+        for r, c in enumerate(ctxs):
+            p, n = C.c_void_p(), C.c_void_p()
+            nbytes = c.halo_bytes()
+            assert rt.hipMalloc(C.byref(p), nbytes) == 0 and rt.hipMalloc(C.byref(n), nbytes) == 0
+            c.halo_export(p.value, n.value)
+            bufs[r] = (p, n)
+            if split:
+                c.render_stage(DENOISE_INTERIOR)
+        got = np.zeros_like(want)
+        for r, c in enumerate(ctxs):
+            c.halo_import(bufs[(r - 1) % nranks][1].value, bufs[(r + 1) % nranks][0].value)
+            c.render_stage(DENOISE_EDGE if split else DENOISE)
+            got[rows[r]] = c.read(DENOISED)
+        assert np.isnan(want[..., :3]).any() and np.isfinite(want[..., :3]).mean() > 0.4
+        assert_bits_equal(got, want, f"{nranks} ranks, {band}-row bands, radius {radius}")
+    finally:
+        for c in ctxs:
+            c.close()
