@@ -7,8 +7,9 @@ Run in the build container (needs /root/reference):   python tests/golden/make_s
 tests/test_oracle_spirv_pin.py checks the oracle's restatement against the fixture (and, when the reference is mounted, that the
 fixture is what this script produces).
 
-The fixture holds facts ABOUT the binaries — a list of constants, instruction counts, and the association order of the listed
-expressions — not the shaders' text: control flow, declarations, bindings and everything not listed are not in it."""
+The fixture holds facts ABOUT the binaries — a list of constants, instruction counts, the association order of the listed
+expressions, the order in which four functions call others (the order of the rand() draws) and the order of the comparisons and returns of
+cast_bounded_ray's loop — not the shaders' text: declarations, bindings, the bodies of the branches and everything not listed are not in it."""
 import hashlib
 import json
 import os
@@ -57,6 +58,12 @@ EXPRESSIONS = {
 RETURNS = {"voxels": ["octant_center", "current_octant", "node_color", "node_emmitance", "rand"]}
 # (function prefix, after the store to, up to the store to): the conditional branches and the values chosen between the two
 DECISIONS = {"voxels": [("cast_bounded_ray", "plane", "transition")]}
+# functions whose sequence of calls (in instruction order = source order: glslang does not reorder) is kept: the order of the rand() draws
+CALLS = {"voxels": ["main", "cast_bounded_ray", "cast_ray", "random_hemisphere"]}
+# functions whose comparisons and returns are kept in instruction order: which exit test of the loop comes first
+LANDMARKS = {"voxels": ["cast_bounded_ray"]}
+LANDMARK_OPS = ("SGreaterThanEqual", "FOrdGreaterThan", "SLessThan", "SGreaterThan", "IEqual", "INotEqual", "FOrdLessThanEqual", "LogicalNot",
+                "ReturnValue", "LoopMerge")
 
 
 def find_function(m, prefix):
@@ -88,6 +95,20 @@ def decision_chain(m, function, after, until):
     return out
 
 
+def landmarks(m, function):
+    out = []
+    for ins in m.functions()[function]:
+        if ins.name not in LANDMARK_OPS:
+            continue
+        if ins.name == "LoopMerge":
+            out.append(["loop"])
+        elif ins.name == "ReturnValue":
+            out.append(["return", m.tree(ins.words[0])])
+        else:
+            out.append([ins.name] + [m.tree(w) for w in ins.words[2:]])
+    return out
+
+
 def pins_of(name):
     path = os.path.join(REFERENCE_SHADERS, f"{name}.comp.spv")
     data = open(path, "rb").read()
@@ -99,7 +120,7 @@ def pins_of(name):
         "float_constants": [float(f"{v:.9g}") for v in m.float_constants()],
         "int_constants": m.int_constants(),
         "ext_insts": m.ext_inst_counts(),
-        "expressions": {}, "returns": {}, "decisions": {},
+        "expressions": {}, "returns": {}, "decisions": {}, "calls": {}, "landmarks": {},
     }
     for prefix, var, k in EXPRESSIONS.get(name, []):
         fn = find_function(m, prefix)
@@ -107,6 +128,10 @@ def pins_of(name):
         out["expressions"][f"{prefix}/{var}#{k}"] = stores[k]
     for prefix in RETURNS.get(name, []):
         out["returns"][prefix] = m.returns(find_function(m, prefix))
+    for prefix in CALLS.get(name, []):
+        out["calls"][prefix] = [m.names.get(i.words[2], "?").split("(")[0] for i in m.functions()[find_function(m, prefix)] if i.name == "FunctionCall"]
+    for prefix in LANDMARKS.get(name, []):
+        out["landmarks"][prefix] = landmarks(m, find_function(m, prefix))
     for prefix, after, until in DECISIONS.get(name, []):
         out["decisions"][f"{prefix}/{until}"] = decision_chain(m, find_function(m, prefix), after, until)
     return out

@@ -273,6 +273,50 @@ def test_select_order_of_the_transition_and_the_locked_planes():
     assert "uint32_t dx = delta.x > 0.0f ? 4 : 0;" in ORACLE_SRC
 
 
+def oracle_function_body(signature):
+    """Text of the oracle function whose definition starts with `signature`, braces balanced."""
+    i = ORACLE_SRC.index(signature)
+    j = ORACLE_SRC.index("{", i)
+    depth, k = 0, j
+    while True:
+        depth += {"{": 1, "}": -1}.get(ORACLE_SRC[k], 0)
+        if depth == 0:
+            return ORACLE_SRC[j:k + 1]
+        k += 1
+
+
+def test_call_order_and_loop_exits():
+    """The ORDER of things with side effects: the rand() draws of a hit (voxels.comp:326-371: the specular test first, then the three
+    components of rand_dir, dx, dy, and random_hemisphere's two after the sun ray), and the exit tests of cast_bounded_ray's loop
+    (voxels.comp:163-177, 204-234: trip cap, then distance, then the leaf test; has_next's three conditions; the pop loop's two)."""
+    v = PINS["voxels"]
+    assert v["calls"]["main"] == ["cast_ray", "node_color", "node_emmitance", "rand", "rand", "rand", "rand", "rand", "rand", "cast_ray",
+                                  "random_hemisphere", "node_color"]
+    assert v["calls"]["random_hemisphere"] == ["rand", "rand"] and v["calls"]["cast_ray"] == ["cast_bounded_ray"]
+    body = oracle_function_body("static int trace_pixel(")
+    tokens = re.findall(r"\b(cast_bounded_ray|node_color|node_emmitance|rng\.rand|random_hemisphere)\(", body)
+    assert [{"cast_bounded_ray": "cast_ray", "rng.rand": "rand"}.get(t, t) for t in tokens] == v["calls"]["main"]
+    hemi = oracle_function_body("static V3 random_hemisphere(")
+    assert re.findall(r"rng\.rand\(\)", hemi) == ["rng.rand()"] * 2 and hemi.index("phi") < hemi.index("d.x = ")      # phi's draw first
+    assert v["calls"]["cast_bounded_ray"] == ["ray_cube_intersection", "current_octant", "octant_center", "octant_center", "current_octant",
+                                               "ray_cube_intersection", "octant_center", "ray_cube_intersection"]
+    marks = v["landmarks"]["cast_bounded_ray"]
+    assert marks == [
+        ["LogicalNot", "intersect"], ["return", "False"], ["loop"],
+        ["SGreaterThanEqual", "iterations", "2048"], ["return", "True"],
+        ["FOrdGreaterThan", "time", "max_distance"], ["return", "False"],
+        ["SLessThan", "value", "0"], ["return", "True"],
+        ["INotEqual", "(BitwiseAnd directional_octant 4)", "0"], ["INotEqual", "(BitwiseAnd directional_octant 2)", "0"],
+        ["INotEqual", "(BitwiseAnd directional_octant 1)", "0"],
+        ["FOrdLessThanEqual", "next_time", "exit"], ["INotEqual", "transition", "0"], ["IEqual", "(BitwiseAnd directional_octant transition)", "0"],
+        ["SGreaterThan", "value", "0"], ["loop"], ["IEqual", "top", "0"], ["return", "False"], ["IEqual", "node", "-1"], ["return", marks[-1][1]]]
+    walk = oracle_function_body("bool cast_bounded_ray(const Scene& sc")
+    order = ["if (!intersect) return false", "iterations >= 2048", "time > max_distance", "value < 0",
+             "next_time <= exit && transition != 0 && (directional_octant & transition) == 0", "value > 0", "top == 0", "node == -1"]
+    at = [walk.index(t) for t in order]
+    assert at == sorted(at)
+
+
 def test_constants_workgroups_and_builtins():
     v, t, d = PINS["voxels"], PINS["temporal"], PINS["denoise"]
     assert v["local_size"] == t["local_size"] == d["local_size"] == [16, 16, 1]
