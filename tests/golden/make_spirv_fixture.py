@@ -61,9 +61,9 @@ DECISIONS = {"voxels": [("cast_bounded_ray", "plane", "transition")]}
 # functions whose sequence of calls (in instruction order = source order: glslang does not reorder) is kept: the order of the rand() draws
 CALLS = {"voxels": ["main", "cast_bounded_ray", "cast_ray", "random_hemisphere"]}
 # functions whose comparisons and returns are kept in instruction order: which exit test of the loop comes first
-LANDMARKS = {"voxels": ["cast_bounded_ray"]}
+LANDMARKS = {"voxels": ["cast_bounded_ray"], "temporal": ["main"], "denoise": ["main"]}
 LANDMARK_OPS = ("SGreaterThanEqual", "FOrdGreaterThan", "SLessThan", "SGreaterThan", "IEqual", "INotEqual", "FOrdLessThanEqual", "LogicalNot",
-                "ReturnValue", "LoopMerge")
+                "ReturnValue", "LoopMerge", "SLessThanEqual", "FOrdLessThan", "FOrdGreaterThanEqual")
 
 
 def find_function(m, prefix):

@@ -300,7 +300,7 @@ def test_call_order_and_loop_exits():
     assert re.findall(r"rng\.rand\(\)", hemi) == ["rng.rand()"] * 2 and hemi.index("phi") < hemi.index("d.x = ")      # phi's draw first
     assert v["calls"]["cast_bounded_ray"] == ["ray_cube_intersection", "current_octant", "octant_center", "octant_center", "current_octant",
                                                "ray_cube_intersection", "octant_center", "ray_cube_intersection"]
-    marks = v["landmarks"]["cast_bounded_ray"]
+    marks = [m for m in v["landmarks"]["cast_bounded_ray"] if m[0] != "FOrdLessThan"]     # without dir_mask's three sign tests (pinned above)
     assert marks == [
         ["LogicalNot", "intersect"], ["return", "False"], ["loop"],
         ["SGreaterThanEqual", "iterations", "2048"], ["return", "True"],
@@ -314,6 +314,29 @@ def test_call_order_and_loop_exits():
     order = ["if (!intersect) return false", "iterations >= 2048", "time > max_distance", "value < 0",
              "next_time <= exit && transition != 0 && (directional_octant & transition) == 0", "value > 0", "top == 0", "node == -1"]
     at = [walk.index(t) for t in order]
+    assert at == sorted(at)
+
+
+def test_comparisons_of_temporal_and_denoise():
+    """Which comparison is strict: temporal.comp:92 accepts texture coordinates in [0, 1] INCLUSIVE on both sides and only for
+    depth >= 0 (:68, :119), accepts a history texel when dist < (bias cutoff) depth (:113); denoise.comp:51-57 loops dy, dx over
+    [-r, r] inclusive and takes a tap when 0 <= n < size on both axes; radius == 0 bypasses the sums (:89)."""
+    t = PINS["temporal"]["landmarks"]["main"]
+    assert t == [["FOrdGreaterThanEqual", "depth", "0"], ["FOrdLessThanEqual", "0", "tex_coord[0]"], ["FOrdLessThanEqual", "tex_coord[0]", "1"],
+                 ["FOrdLessThanEqual", "0", "tex_coord[1]"], ["FOrdLessThanEqual", "tex_coord[1]", "1"],
+                 ["FOrdLessThan", "dist", "(FMul (FMul bias %290.blending_distance_cutoff) depth)"], ["FOrdGreaterThanEqual", "depth", "0"]]
+    body = oracle_function_body("void orc_temporal(")
+    order = ["if (depth >= 0.0f && has_history)", "0.0f <= tu_ && tu_ <= 1.0f && 0.0f <= tv_ && tv_ <= 1.0f",
+             "dist < (bias * tu->blending_distance_cutoff) * depth", "depth >= 0.0f ? vmix("]
+    at = [body.index(x) for x in order]
+    assert at == sorted(at)
+    d = [m for m in PINS["denoise"]["landmarks"]["main"] if m[0] != "INotEqual"]
+    assert d == [["loop"], ["SLessThanEqual", "dy", "r"], ["loop"], ["SLessThanEqual", "dx", "r"], ["SLessThanEqual", "0", "nx"],
+                 ["SLessThan", "nx", "size[0]"], ["SLessThanEqual", "0", "ny"], ["SLessThan", "ny", "size[1]"], ["IEqual", "%68.radius", "0"]]
+    body = oracle_function_body("void orc_denoise(")
+    order = ["for (int dy = -r; dy <= r; dy++)", "for (int dx = -r; dx <= r; dx++)", "0 <= nx && nx < width && 0 <= ny && ny < height",
+             "du->radius == 0 ? cc : sum / normalization"]
+    at = [body.index(x) for x in order]
     assert at == sorted(at)
 
 
