@@ -610,7 +610,7 @@ __device__ __forceinline__ void queue_append(const PathQueue& q, unsigned shard,
     }
 }
 
-// The same, for a queue that is sized by need instead of for the worst case (the compacted tail: vxrt_api.hip sizes it from what
+// The same, for a queue that is sized by need instead of for the worst case (the compacted tail: api_trace.hip sizes it from what
 // earlier launches queued): called from INSIDE the path loop by exactly the lanes that want to hand their path over.  Returns the
 // lane's record slot in the shard, or kNoSlot when the shard is full — the lane then keeps following its path itself, which gives
 // the same result (the hand-over only moves work).  The shard's counter keeps counting past the capacity, so the host sees how

@@ -70,7 +70,7 @@ int main(void) {
 
 def test_sun_power_is_exactly_zero_below_the_kernels_bound(O):
     """The tracer skips pow(x, 1/sun_size^2) (voxels.comp:378-381) for x below TraceArgs::sun_zero_below =
-    float(exp(-88 / y) * (1 - 1e-4)) (csrc/vxrt_api.hip frame_constants, csrc/trace_common.h sun_power_of) because
+    float(exp(-88 / y) * (1 - 1e-4)) (csrc/api_trace.hip frame_constants, csrc/trace_common.h sun_power_of) because
     vx_pow(x, y) = vx_exp(y * vx_log(x)) is +0 there.  Checked on the contract's own vx_pow: the 2^21 binary32 values just below
     the bound, a log-uniform sample of everything below it, zero and the denormals — for the default exponent 400 and others."""
     rng = np.random.default_rng(3)
