@@ -178,17 +178,20 @@ def measure_view(Context, Camera, TRACE, pos, mrgb, cam, device, bounces, inflig
 def pick_schedule(world, steps, inflight=0, batch=0):
     """Launches in flight and frames per launch for `world` ranks and a timed block of `steps` frames (0 = choose).
     A frame's longest tile is a serial chain of ~0.15-0.3 ms however few rows a rank owns, so a rank needs that much work in
-    flight: 16-32 frames per launch, and the more launches overlapping the smaller its share of the frame (measured per rank with
-    scripts/exp_rank_emulation.py, round 3 with the sky cull: 2x16 for 1 rank, 3x16 for 2 / 4 / 8 ranks — 3x32 was ahead before the cull
-    made the sky tiles cheap, now 173 against 181 Gray/s at 8 emulated ranks).  Never more than 3 trace streams: with the
+    flight: 16 frames per launch, and the more launches overlapping the smaller its share (measured per rank with
+    scripts/exp_rank_emulation.py, round 3: 2x16 for 1 rank, 3x16 for 2 / 4 / 8 ranks).  Never more than 3 trace streams: with the
     context's own stream that makes 4, and RCCL / torch bring streams of their own; a process gets GPU_MAX_HW_QUEUES = 8 hardware
     queues here (set above), and streams beyond the queues share one and serialise (scripts/exp_first_context.py).
-    A short block (fewer frames than two full launches per stream) is dealt to THREE launches in equal parts — 20 steps = 7 + 7 + 6
-    frames: a block starts on an idle GPU and ends with a drain, and three staggered launches overlap one's tail launch with the
-    others' head launches best (measured for 20 steps: 10 x 2: 24.0, 5 x 4: 24.7, 7 x 3: 24.9 Gray/s; steady state 27.0)."""
+    A short block (fewer frames than two full launches per stream) starts on an idle GPU and ends with a drain; its frames are dealt
+    in equal parts to 3 / 2 / 1 launches for 1 / 2 / >= 4 ranks (scripts/exp_short_block.py, 20 steps, ms per block, rank 0 alone on
+    the GPU: 1 rank 7x3 2.35, 10x2 2.41, 20x1 2.53; 2 ranks 10x2 1.25, 7x3 1.26; 4 ranks 20x1 0.715, 7x3 0.721; 8 ranks 20x1
+    0.404, 7x3 0.426 — the smaller a rank's share, the more a launch is its longest tile's chain and nothing else, and one launch
+    pays that chain once)."""
     short = steps < 2 * 16 * (inflight if inflight > 0 else (2 if world == 1 else 3))
     if inflight <= 0:
-        inflight = 3 if (world > 1 or short) else 2
+        inflight = ((3 if world == 1 else 2 if world == 2 else 1) if short else (2 if world == 1 else 3))
+        if short and steps > 32 * inflight:
+            inflight = min(3, -(-steps // 32))
     if batch <= 0:
         batch = 16
         if short:

@@ -147,6 +147,8 @@ def test_bench_schedule_choice():
     assert bench.pick_schedule(1, 1000) == (2, 16) and bench.pick_schedule(2, 1000) == (3, 16)
     assert bench.pick_schedule(4, 1000) == (3, 16) and bench.pick_schedule(8, 1000) == (3, 16)   # never more than 3 trace streams
     assert bench.pick_schedule(1, 20) == (3, 7)                     # the driver's --steps 20: three launches of 7, 7 and 6 frames
+    assert bench.pick_schedule(2, 20) == (2, 10) and bench.pick_schedule(4, 20) == (1, 20) and bench.pick_schedule(8, 20) == (1, 20)
+    assert bench.pick_schedule(8, 50) == (2, 25) and bench.pick_schedule(8, 95) == (3, 32)
     for world in (1, 2, 4, 8):
         for steps in (1, 2, 5, 20, 63, 64, 100):
             inflight, batch = bench.pick_schedule(world, steps)
