@@ -256,7 +256,7 @@ def trace_bench(args):
         cam = (cam[0], -cam[1], cam[2])
 
     ctx = Context(WIDTH, HEIGHT, device=device, max_bounces=args.bounces, rank=rank, nranks=world, band_rows=BAND_ROWS,
-                  frames_in_flight=args.inflight, frames_per_launch=args.batch)
+                  frames_in_flight=args.inflight, frames_per_launch=args.batch, tracer=args.tracer)
     ctx.recreate_octree(pos, mrgb)
     ctx.camera = Camera(*cam)
 
@@ -511,6 +511,7 @@ def main():
     ap.add_argument("--band-rows", type=int, default=0, help="--pipeline: rows per band (default: >= 8 radius, a multiple of 16)")
     ap.add_argument("--view", default="bench", choices=["bench", "close", "away"])
     ap.add_argument("--bounces", type=int, default=BOUNCES, help="diagnostic only; the benchmark is 4")
+    ap.add_argument("--tracer", type=int, default=0, help="diagnostic only (vxrt_config.tracer; 2 / 3 / 5 need the variants build); the benchmark is 0")
     ap.add_argument("--inflight", type=int, default=0,
                     help="trace launches that may be on the GPU together, one HIP stream each (default: 2 on one GPU, 3 per rank otherwise)")
     ap.add_argument("--batch", type=int, default=0,

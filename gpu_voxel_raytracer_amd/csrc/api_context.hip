@@ -106,15 +106,16 @@ int alloc_images(vxrt_ctx* c) {
                 // G/8 blocks x 256 items per trip, so a segment receives at most its eighth of the paths rounded up to
                 // a whole trip: paths/8 + 32 G.
                 const size_t cap = waves * 64 / kSegments + size_t(c->shade_blocks) * 32 + 1024;
-                const size_t per_path = 2 * 64 + 2 * 48 + 32;  // state x2, rays x2, results
-                const size_t counts_bytes = size_t(c->cfg.max_bounces + 1) * kSegments * 64;
+                const size_t per_path = 2 * 64 + 2 * 64 + 2 * 32;  // state x2, rays x2, results x2
+                const size_t counts_bytes = size_t(c->cfg.max_bounces + 1) * (kSegments + 1) * 64;   // + the ray pool's cursor per stage
                 HIP_TRY(hipMalloc(&sq.rq_block, kSegments * cap * per_path + counts_bytes + 256));
                 char* p = static_cast<char*>(sq.rq_block);
                 sq.rq.state[0] = reinterpret_cast<float4*>(p); p += kSegments * cap * 64;
                 sq.rq.state[1] = reinterpret_cast<float4*>(p); p += kSegments * cap * 64;
-                sq.rq.rays[0] = reinterpret_cast<float4*>(p); p += kSegments * cap * 48;
-                sq.rq.rays[1] = reinterpret_cast<float4*>(p); p += kSegments * cap * 48;
-                sq.rq.results = reinterpret_cast<uint4*>(p); p += kSegments * cap * 32;
+                sq.rq.rays[0] = reinterpret_cast<float4*>(p); p += kSegments * cap * 64;
+                sq.rq.rays[1] = reinterpret_cast<float4*>(p); p += kSegments * cap * 64;
+                sq.rq.results[0] = reinterpret_cast<uint4*>(p); p += kSegments * cap * 32;
+                sq.rq.results[1] = reinterpret_cast<uint4*>(p); p += kSegments * cap * 32;
                 sq.rq.counts = reinterpret_cast<unsigned*>(p);
                 sq.rq.seg_capacity = unsigned(cap);
             }

@@ -172,8 +172,8 @@ struct DenoiseArgs {
 constexpr unsigned kSegments = 8;  // dense queue segments; a block appends to segment blockIdx % 8 with one atomic
 struct RayQueue {
     float4* state[2];        // [kSegments][seg_capacity][4 float4]  path state, ping-pong between segments of a path
-    float4* rays[2];         // [kSegments][seg_capacity][3 float4]  (origin, flags) (sun dir) (bounce dir)
-    uint4* results;          // [kSegments][seg_capacity][2]         what the walk of each ray ended with
+    float4* rays[2];         // [kSegments][seg_capacity][4 float4]  (origin, flags) (sun d, 1/d.x) (1/d.yz, bounce d.xy) (d.z, 1/d)
+    uint4* results[2];       // [kSegments][seg_capacity][2]         what the walk of each ray ended with, ping-pong like the rays
     unsigned* counts;        // [max_bounces + 1][kSegments] counters, 16 uints (one 64-byte line) apart, zero at frame start
     unsigned seg_capacity;
 };
@@ -187,6 +187,8 @@ unsigned trace_tile_count(int width, int local_rows);  // blocks per frame of tr
 void trace_tile_dims(int* w, int* h);                  // pixels per block  // monolithic: one pixel per lane, all bounces
 #if VXRT_VARIANTS
 // ray queues: primary_kernel, then shade / trace-rays launches per path segment with per-lane ray refill
+// trace_pool.hip: the rays of one stage of the ray queue, `waves` persistent one-wave blocks with per-lane refill
+hipError_t launch_pool_rays(const TraceArgs& a, const RayQueue& q, int stage, int waves, hipStream_t s);
 hipError_t launch_trace_rayqueue(const TraceArgs& a, const PathQueue& hits, unsigned* count_sets[3], unsigned* launch_counter,
                                  const RayQueue& q, int shade_blocks, int trace_blocks, unsigned min_rays_per_wave, hipStream_t s);
 #endif

@@ -162,85 +162,6 @@ __device__ __forceinline__ int walk_step(Walk& w, const SceneView& sc, float max
     return kWalkOn;
 }
 
-// The same trip of the loop as walk_step, written WITHOUT divergent branches: every lane executes one fixed
-// instruction sequence (classification, the descend/pop "move" computed speculatively, select-commits); only
-// the three memory operations sit under a lane predicate.  For incoherent rays the lanes of a wave are in
-// different branches of walk_step and the wave executes their union at ~40 % lane utilisation
-// (SQ_THREAD_CYCLES_VALU); here the cost per trip is constant and every live lane makes progress.
-__device__ __forceinline__ int walk_step_uniform(Walk& w, const SceneView& sc, float max_distance, uint2* stack) {
-    const int iterations = w.iterations + 1;
-    const uint32_t bit = 1u << w.octant;
-    const bool is_leaf = (w.rec.masks & (bit << 8)) != 0u;
-    const bool is_child = (w.rec.masks & bit) != 0u;
-
-    // next sibling through the node's mid planes                     voxels.comp:191-203
-    const f3 t_mid = (w.center - w.o) * w.inv;
-    const uint32_t directional = w.octant ^ w.dir_mask;
-    const float mx = (directional & 4u) ? kAlmostInfinity : t_mid.x;
-    const float my = (directional & 2u) ? kAlmostInfinity : t_mid.y;
-    const float mz = (directional & 1u) ? kAlmostInfinity : t_mid.z;
-    const float next_time = vx_min(vx_min(mx, my), mz);
-    const uint32_t transition = (mx == next_time) ? 4u : ((my == next_time) ? 2u : ((mz == next_time) ? 1u : 0u));
-    const uint32_t next_octant = w.octant ^ transition;
-    const bool has_next = next_time <= w.exit && transition != 0u && (directional & transition) == 0u;
-
-    // how this trip ends, in the shader's order of checks (voxels.comp:166-177, 228)
-    int status = kWalkOn;
-    if (!is_child && !has_next && w.has_next_mask == 0u) status = kWalkMiss;
-    if (is_leaf) status = kWalkLeaf;
-    if (w.time > max_distance) status = kWalkMiss;
-    if (iterations >= 2048) status = kWalkCap;
-    const bool live = status == kWalkOn;
-    const bool move = live && (is_child || !has_next);
-    const bool descend = move && is_child;
-    const bool pop = move && !is_child;
-
-    // memory operations, each under its lane predicate
-    if (descend && has_next) stack[w.lvl * kStackStride] = make_uint2(w.rec.masks | next_octant << 16, w.rec.base);
-    const uint32_t l = 31u - uint32_t(__clz(int(w.has_next_mask | 1u)));
-    uint2 raw = make_uint2(0u, 0u);
-    if (descend) raw = *reinterpret_cast<const uint2*>(sc.svo + (w.rec.base + __popc(w.rec.masks & (bit - 1u))));
-    if (pop) {
-        uint2 r = stack[l * kStackStride];
-        asm volatile("" : "+v"(r.x), "+v"(r.y));  // keep it an LDS read (no flat_load merge with the global load)
-        raw = r;
-    }
-
-    // the node the move goes to (computed by every lane, committed by the moving ones)
-    const uint32_t up = w.lvl - l;
-    const uint32_t nix = is_child ? ((w.ix << 1) | ((w.octant >> 2) & 1u)) : (w.ix >> up);
-    const uint32_t niy = is_child ? ((w.iy << 1) | ((w.octant >> 1) & 1u)) : (w.iy >> up);
-    const uint32_t niz = is_child ? ((w.iz << 1) | (w.octant & 1u)) : (w.iz >> up);
-    const uint32_t nlvl = is_child ? w.lvl + 1u : l;
-    const float nsize = __builtin_ldexpf(sc.root_size, -int(nlvl));
-    const f3 ncenter = sc.root_min + mk3(float(nix) + 0.5f, float(niy) + 0.5f, float(niz) + 0.5f) * nsize;
-    float node_entry, node_exit;
-    slab(w.o, w.inv, w.sg, ncenter, 0.5f * nsize, node_entry, node_exit);
-    const uint32_t child_octant = octant_of(w.o + w.d * w.time, ncenter);
-
-    // commit
-    w.iterations = iterations;
-    const uint32_t mask_push = (descend && has_next) ? (1u << w.lvl) : 0u;
-    const uint32_t mask_pop = pop ? (1u << l) : 0u;
-    w.has_next_mask = (w.has_next_mask | mask_push) & ~mask_pop;
-    const float moved_time = is_child ? vx_max(w.time, node_entry) : w.exit;          // voxels.comp:220 / :236
-    const uint32_t moved_octant = is_child ? child_octant : ((raw.x >> 16) & 7u);    // voxels.comp:216 / :242
-    w.time = move ? moved_time : (live ? next_time : w.time);                        // voxels.comp:224
-    w.octant = move ? moved_octant : (live ? next_octant : w.octant);
-    w.exit = move ? node_exit : w.exit;
-    w.ix = move ? nix : w.ix;
-    w.iy = move ? niy : w.iy;
-    w.iz = move ? niz : w.iz;
-    w.lvl = move ? nlvl : w.lvl;
-    w.size = move ? nsize : w.size;
-    w.center.x = move ? ncenter.x : w.center.x;
-    w.center.y = move ? ncenter.y : w.center.y;
-    w.center.z = move ? ncenter.z : w.center.z;
-    w.rec.masks = move ? (raw.x & 0xffffu) : w.rec.masks;
-    w.rec.base = move ? raw.y : w.rec.base;
-    return status;
-}
-
 // ---- the walk for regular rays ---------------------------------------------------------------------------------
 // A ray is "regular" when every component of 1/dir is finite and non-zero (all but ~1e-7 of the rays: a direction
 // component that is exactly 0 needs an exactly-0.5 noise sample).  For such rays no NaN can arise in the walk — every
@@ -635,6 +556,7 @@ __device__ __forceinline__ unsigned queue_count(const PathQueue& q, unsigned sha
 }
 
 constexpr unsigned kFlagSun = 1u, kFlagBounce = 2u;
+constexpr unsigned kFlagSunTraced = 4u, kFlagBounceTraced = 8u;   // ray queues: the ray's result is already stored (an irregular ray)
 struct Shaded {  // what shading a hit produces
     f3 sample, blend, pend_sun, pend_emit, origin, sun_dir, bounce_dir;
     uint32_t ambient_rays, flags;

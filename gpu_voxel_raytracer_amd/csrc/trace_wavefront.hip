@@ -1,5 +1,6 @@
 // trace_wavefront.hip — queue-based variants of the tracer (gfx950): one launch per path segment.
 #include "trace_common.h"
+#include "ray_queue.h"
 
 namespace vxrt {
 namespace {
@@ -93,29 +94,6 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const TraceArgs a, cons
 // blockIdx % 8 (block-wide prefix through LDS), so trace waves can split the rays evenly without a scan.
 // The per-path operation order is that of voxels.comp, the results are bit-identical to trace_kernel's.
 // ------------------------------------------------------------------------------------------------------
-#ifndef VXRT_REFILL_LANES
-#define VXRT_REFILL_LANES 16
-#endif
-constexpr int kRefillLanes = VXRT_REFILL_LANES;  // refill when this many lanes of the wave are idle (or all the rest are done)
-
-struct SegTable {  // the 8 segment counts of one stage as exclusive prefix sums
-    unsigned pre[kSegments + 1];
-};
-__device__ __forceinline__ SegTable load_segments(const unsigned* counts, int stage) {
-    SegTable t;
-    t.pre[0] = 0;
-#pragma unroll
-    for (unsigned s = 0; s < kSegments; s++) t.pre[s + 1] = t.pre[s] + counts[(unsigned(stage) * kSegments + s) * kCountStride];
-    return t;
-}
-// dense path index -> slot in the segmented arrays
-__device__ __forceinline__ unsigned segment_slot(const SegTable& t, unsigned j, unsigned cap) {
-    unsigned s = 0, first = 0;  // select chain with compile-time indices: no runtime-indexed array (that would go to scratch)
-#pragma unroll
-    for (unsigned k = 1; k < kSegments; k++)
-        if (j >= t.pre[k]) { s = k; first = t.pre[k]; }
-    return s * cap + (j - first);
-}
 
 // Block-wide dense append: returns this thread's slot in segment blockIdx % 8 of stage `stage` (or ~0u).
 __device__ __forceinline__ unsigned dense_append(const RayQueue& q, int stage, bool keep, unsigned* lds_counts, int tid) {
@@ -141,6 +119,7 @@ __device__ __forceinline__ unsigned dense_append(const RayQueue& q, int stage, b
 // kFirst: paths come from primary_kernel's sharded hit queue (hit already resolved); otherwise from stage-1.
 template <bool kFirst>
 __global__ __launch_bounds__(kBlock) void shade_kernel(const TraceArgs a, const PathQueue hits, const RayQueue q, unsigned* zero, int stage) {
+    extern __shared__ uint2 lds_stack[];   // for the literal walk of an irregular ray
     __shared__ unsigned lds_counts[8];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -170,6 +149,9 @@ __global__ __launch_bounds__(kBlock) void shade_kernel(const TraceArgs a, const 
     const float4* rays_in = q.rays[(stage + 1) & 1];
     float4* state_out = q.state[stage & 1];
     float4* rays_out = q.rays[stage & 1];
+    const uint4* results_in = q.results[(stage + 1) & 1];
+    uint4* results_out = q.results[stage & 1];
+    uint32_t rays_cast = 0;
 
     for (unsigned trip = 0; trip < trips; trip++) {
         const unsigned item = trip * per_trip + blockIdx.x * unsigned(kBlock) + unsigned(tid);
@@ -201,22 +183,23 @@ __global__ __launch_bounds__(kBlock) void shade_kernel(const TraceArgs a, const 
             const unsigned slot = segment_slot(seg, item, q.seg_capacity);
             const float4 s0 = state_in[size_t(slot) * 4], s1 = state_in[size_t(slot) * 4 + 1], s2 = state_in[size_t(slot) * 4 + 2],
                          s3 = state_in[size_t(slot) * 4 + 3];
-            const float4 r0 = rays_in[size_t(slot) * 3];
+            const float4 r0 = rays_in[size_t(slot) * 4];
             sample = xyz4(s0); rng.index = __float_as_uint(s0.w);
             blend = xyz4(s1); pix = __float_as_uint(s1.w);
             ambient_rays = __float_as_uint(s2.w);
             const uint32_t flags = __float_as_uint(r0.w);
             const f3 o = xyz4(r0);
             if (flags & kFlagSun) {  // voxels.comp:357-367: the sun sample counts unless something is in the way
-                const uint4 rs = q.results[size_t(slot) * 2];
+                const uint4 rs = results_in[size_t(slot) * 2];
                 if ((rs.w >> 16 & 3u) == unsigned(kWalkMiss)) sample = sample + xyz4(s2);
                 sample = sample + xyz4(s3);
             }
             bool finished = true;
             if (flags & kFlagBounce) {
-                const uint4 rb = q.results[size_t(slot) * 2 + 1];
+                const uint4 rb = results_in[size_t(slot) * 2 + 1];
                 const unsigned status = rb.w >> 16 & 3u;
-                const f3 d = xyz4(rays_in[size_t(slot) * 3 + 2]);
+                const float4 r2 = rays_in[size_t(slot) * 4 + 2];
+                const f3 d = mk3(r2.z, r2.w, rays_in[size_t(slot) * 4 + 3].x);
                 if (status == unsigned(kWalkMiss)) {
                     sample = sample + sky * blend;                                        // voxels.comp:384
                 } else {
@@ -260,73 +243,36 @@ __global__ __launch_bounds__(kBlock) void shade_kernel(const TraceArgs a, const 
             so[1] = make_float4(sh.blend.x, sh.blend.y, sh.blend.z, __uint_as_float(pix));
             so[2] = make_float4(sh.pend_sun.x, sh.pend_sun.y, sh.pend_sun.z, __uint_as_float(sh.ambient_rays));
             so[3] = make_float4(sh.pend_emit.x, sh.pend_emit.y, sh.pend_emit.z, 0.0f);
-            float4* ro = rays_out + size_t(slot) * 3;
-            ro[0] = make_float4(sh.origin.x, sh.origin.y, sh.origin.z, __uint_as_float(sh.flags));
-            ro[1] = make_float4(sh.sun_dir.x, sh.sun_dir.y, sh.sun_dir.z, 0.0f);
-            ro[2] = make_float4(sh.bounce_dir.x, sh.bounce_dir.y, sh.bounce_dir.z, 0.0f);
-        }
-    }
-}
-
-// Persistent waves trace the rays of stage `stage` (2 per path: sun, bounce).  Result per ray:
-//   x = bits(time), y = leaf index, z = voxel x | y << 16, w = voxel z | status << 16 | node level << 20.
-__global__ __launch_bounds__(kBlock) void trace_rays_kernel(const TraceArgs a, const RayQueue q, int stage, unsigned min_rays_per_wave) {
-    extern __shared__ uint2 lds_stack[];
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const SceneView sc = make_scene(a);
-    uint2* stack = lds_stack + tid;
-    const SegTable seg = load_segments(q.counts, stage);
-    const unsigned n_paths = seg.pre[kSegments];
-    const unsigned total_rays = n_paths * 2u;
-    const unsigned total_waves = gridDim.x * 4u;
-    unsigned per_wave = (total_rays + total_waves - 1u) / total_waves;
-    if (per_wave < min_rays_per_wave) per_wave = min_rays_per_wave;
-    const unsigned w_index = blockIdx.x * 4u + unsigned(wave);
-    unsigned cursor = w_index * per_wave;
-    const unsigned end = cursor + per_wave < total_rays ? cursor + per_wave : total_rays;
-    const float4* rays = q.rays[stage & 1];
-
-    Walk w;
-    bool active = false;
-    unsigned res_slot = 0;
-    uint32_t rays_cast = 0;
-    if (cursor < end) {
-        for (;;) {
-            const unsigned long long idle = __ballot(!active);
-            const int n_idle = __popcll(idle);
-            if (cursor < end && (n_idle >= kRefillLanes || n_idle == 64)) {
-                const unsigned rank = __builtin_amdgcn_mbcnt_hi(unsigned(idle >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(idle), 0u));
-                const unsigned left = end - cursor;
-                const unsigned take = unsigned(n_idle) < left ? unsigned(n_idle) : left;
-                if (!active && rank < take) {
-                    // rays [0, N) are the paths' sun rays (all towards the sun, origins in tile order: coherent),
-                    // rays [N, 2N) their bounce rays (random directions)
-                    const unsigned g = cursor + rank;
-                    const unsigned which = g >= n_paths ? 1u : 0u;
-                    const unsigned slot = segment_slot(seg, which ? g - n_paths : g, q.seg_capacity);
-                    const float4 r0 = rays[size_t(slot) * 3];
-                    res_slot = slot * 2u + which;
-                    if (__float_as_uint(r0.w) & (which ? kFlagBounce : kFlagSun)) {
-                        const f3 d = xyz4(rays[size_t(slot) * 3 + 1 + which]);
-                        rays_cast++;
-                        if (walk_begin(w, sc, xyz4(r0), d)) active = true;
-                        else q.results[res_slot] = make_uint4(0u, 0u, 0u, unsigned(kWalkMiss) << 16);
+            // 1 / d is made here, where every lane has a ray; a ray with a zero or NaN direction component (~1e-7 of them) is
+            // walked on the spot by the shader's literal text, so that the ray pool holds regular rays only
+            unsigned flags = sh.flags;
+            f3 si = splat3(0.0f), bi = splat3(0.0f);
+#pragma unroll
+            for (unsigned which = 0; which < 2u; which++) {
+                if ((flags & (which ? kFlagBounce : kFlagSun)) == 0u) continue;
+                const f3 d = which ? sh.bounce_dir : sh.sun_dir;
+                const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                if (which) bi = inv; else si = inv;
+                if (!ray_is_regular(inv)) {
+                    Walk g;
+                    int status = kWalkMiss;
+                    uint4 r = make_uint4(0u, 0u, 0u, unsigned(kWalkMiss) << 16);
+                    if (walk_begin(g, sc, sh.origin, d)) {
+                        do { status = walk_step(g, sc, kAlmostInfinity, lds_stack + tid); } while (status == kWalkOn);
+                        const unsigned vx = (g.ix << 1) | ((g.octant >> 2) & 1u), vy = (g.iy << 1) | ((g.octant >> 1) & 1u), vz = (g.iz << 1) | (g.octant & 1u);
+                        r = make_uint4(__float_as_uint(g.time), status == kWalkLeaf ? walk_leaf_index(g) : 0u, vx | vy << 16,
+                                       vz | unsigned(status) << 16 | g.lvl << 20);
                     }
-                }
-                cursor += take;
-            } else if (n_idle == 64) {
-                break;
-            }
-            if (active) {
-                const int status = walk_step_uniform(w, sc, kAlmostInfinity, stack);
-                if (status != kWalkOn) {
-                    const unsigned vx = (w.ix << 1) | ((w.octant >> 2) & 1u), vy = (w.iy << 1) | ((w.octant >> 1) & 1u), vz = (w.iz << 1) | (w.octant & 1u);
-                    q.results[res_slot] = make_uint4(__float_as_uint(w.time), status == kWalkLeaf ? walk_leaf_index(w) : 0u, vx | vy << 16,
-                                                     vz | unsigned(status) << 16 | w.lvl << 20);
-                    active = false;
+                    results_out[size_t(slot) * 2 + which] = r;
+                    flags |= which ? kFlagBounceTraced : kFlagSunTraced;
+                    rays_cast++;
                 }
             }
+            float4* ro = rays_out + size_t(slot) * 4;
+            ro[0] = make_float4(sh.origin.x, sh.origin.y, sh.origin.z, __uint_as_float(flags));
+            ro[1] = make_float4(sh.sun_dir.x, sh.sun_dir.y, sh.sun_dir.z, si.x);
+            ro[2] = make_float4(si.y, si.z, sh.bounce_dir.x, sh.bounce_dir.y);
+            ro[3] = make_float4(sh.bounce_dir.z, bi.x, bi.y, bi.z);
         }
     }
     count_rays(a.ray_counter, rays_cast, lane);
@@ -351,7 +297,7 @@ hipError_t launch_trace_rayqueue(const TraceArgs& a, const PathQueue& hits_in, u
                                  const RayQueue& q, int shade_blocks, int trace_blocks, unsigned min_rays_per_wave, hipStream_t s) {
     dim3 grid((a.band.width + 15) / 16, (a.band.local_rows + 15) / 16);
     const size_t lds = size_t(a.stack_levels) * kBlock * sizeof(uint2);
-    hipError_t e = hipMemsetAsync(q.counts, 0, size_t(a.max_bounces + 1) * kSegments * kCountStride * sizeof(unsigned), s);
+    hipError_t e = hipMemsetAsync(q.counts, 0, size_t(a.max_bounces + 1) * (kSegments + 1) * kCountStride * sizeof(unsigned), s);
     if (e != hipSuccess) return e;
     // the sharded hit queue's counter sets rotate as in launch_trace_wavefront: launch J writes set (J+1)%3,
     // the consumer (launch J+1) reads it and clears set J%3
@@ -359,11 +305,11 @@ hipError_t launch_trace_rayqueue(const TraceArgs& a, const PathQueue& hits_in, u
     PathQueue hits = hits_in;
     hits.counts = count_sets[(J + 1) % 3];
     hipLaunchKernelGGL(primary_kernel, grid, dim3(kBlock), lds, s, a, hits, count_sets[(J + 2) % 3]);
-    hipLaunchKernelGGL(shade_kernel<true>, dim3(shade_blocks), dim3(kBlock), 0, s, a, hits, q, count_sets[J % 3], 0);
+    hipLaunchKernelGGL(shade_kernel<true>, dim3(shade_blocks), dim3(kBlock), lds, s, a, hits, q, count_sets[J % 3], 0);
     *launch_counter = J + 2;
     for (int stage = 0; stage < a.max_bounces; stage++) {
-        hipLaunchKernelGGL(trace_rays_kernel, dim3(trace_blocks), dim3(kBlock), lds, s, a, q, stage, min_rays_per_wave);
-        hipLaunchKernelGGL(shade_kernel<false>, dim3(shade_blocks), dim3(kBlock), 0, s, a, hits, q, nullptr, stage + 1);
+        if (hipError_t pe = launch_pool_rays(a, q, stage, trace_blocks * 4, s); pe != hipSuccess) return pe;
+        hipLaunchKernelGGL(shade_kernel<false>, dim3(shade_blocks), dim3(kBlock), lds, s, a, hits, q, nullptr, stage + 1);
     }
     return hipGetLastError();
 }

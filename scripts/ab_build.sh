@@ -8,6 +8,8 @@ python - "$tag" "$@" <<'PY'
 import sys
 from gpu_voxel_raytracer_amd import _build
 tag, flags = sys.argv[1], sys.argv[2:]
-_build.build(extra_flags=flags, out=_build.LIB.replace("libvxrt.so", f"libvxrt_{tag}.so"))
+variants = "-DVXRT_VARIANTS=1" in flags          # the variants' sources come with the flag
+flags = [f for f in flags if f != "-DVXRT_VARIANTS=1"]
+_build.build(extra_flags=flags, variants=variants, out=_build.LIB.replace("libvxrt.so", f"libvxrt_{tag}.so"))
 print("built", tag, flags)
 PY

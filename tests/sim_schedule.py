@@ -218,3 +218,38 @@ def refill_wave_cost(paths, T, c_small):
         if nxt >= npaths and not (state != 0).any():
             break
     return cost
+
+
+def steps_frames(frames, view="bench", w=1920, h=1080, bounces=4):
+    """orc_trace_steps for `frames` consecutive frame numbers of a camera at rest: [frames, h, w, 17]."""
+    pos, mrgb, size = scenes.load_scene("menger")
+    cam = scenes.bench_camera(size) if view == "bench" else scenes.close_camera(size)
+    octree = O.create_octree(pos, mrgb)
+    noise = O.noise_table()
+    u = O.Uniforms.default()
+    u.set_camera(cam[0], O.camera_axis_scaled(cam[0], cam[1], cam[2], w, h))
+    outs = []
+    for f in range(frames):
+        u.frame_number = 1 + f
+        out = np.zeros((h, w, 17), np.int32)
+        O.lib().orc_trace_steps(O._p(octree), O._p(noise), C.byref(u), C.c_int(bounces), C.c_int(0), C.c_int(0), C.c_int(w),
+                                C.c_int(h), O._p(out), C.c_int(os.cpu_count()))
+        outs.append(out)
+    return np.stack(outs)
+
+
+def lane_mappings(view="bench", frames=16, split=3):
+    """Round 3: which 64 (pixel, frame) pairs share a wave of the head kernel.  A launch renders 16 frames of a camera at rest, so a
+    wave could hold pw x ph pixels of pf frames instead of an 8 x 8 tile of one: the primary rays of a pixel are the same in every
+    frame and its first sun rays nearly so.  Prices head (rounds < split, lock step per wave) + tail (compacted, chunks of 64)."""
+    st = steps_frames(frames, view)[..., 1:]
+    F, h, w, R = st.shape
+    for pw, ph, pf in [(8, 8, 1), (8, 4, 2), (8, 2, 4), (8, 1, 8), (4, 2, 8), (4, 1, 16), (2, 2, 16), (4, 4, 4)]:
+        hh, ww, ff = h // ph * ph, w // pw * pw, F // pf * pf
+        a = st[:ff, :hh, :ww].reshape(ff // pf, pf, hh // ph, ph, ww // pw, pw, R).transpose(0, 2, 4, 1, 3, 5, 6).reshape(-1, 64, R)
+        head = a[:, :, :split]
+        hc = head.max(axis=1).sum() * C_STEP + (head > 0).any(axis=1).sum() * C_SHADE
+        tc = paths_sync_cost(a[a[:, :, split] > 0][:, split:])
+        util = [a[:, :, r].sum() / (64 * a[:, :, r].max(axis=1).sum()) for r in range(split)]
+        print(f"{pw}x{ph} px x {pf} frames: head {hc / F / 1e6:6.1f} M (lane utilisation of its rounds {util[0]:.2f} {util[1]:.2f} {util[2]:.2f})"
+              f"  tail {tc / F / 1e6:6.1f} M  total {(hc + tc) / F / 1e6:6.1f} M wave-instr per frame")
