@@ -203,7 +203,7 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
                 a.tail = PathQueue{sq.hitq[0], sets[(J + 1) % 3], c->shard_capacity};
                 a.tail_zero = sets[(J + 2) % 3];
                 a.tail_from = c->tail_from;
-                HIP_TRY(launch_trace(a, use_wide(c) && c->trace_variant == 4, ts));
+                HIP_TRY(launch_trace(a, use_wide(c) && c->trace_variant == 4, false, ts));
                 sq.launches = J + 1;
                 if (!sq.counts_pending) {   // how much room this launch wanted (the set stays untouched until launch J + 2 clears it)
                     HIP_TRY(hipMemcpyAsync(sq.host_counts, sets[(J + 1) % 3], 64 * 64, hipMemcpyDeviceToHost, ts));
@@ -223,7 +223,7 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
                     HIP_TRY(launch_bounces(a, use_wide(c), queues, sets, &sq.launches, c->trace_blocks, sq.hitq[1] ? c->tail_split : 0u, c->tail_from, ts));
                 }
             } else {
-                HIP_TRY(launch_trace(a, use_wide(c), ts));
+                HIP_TRY(launch_trace(a, use_wide(c), scene_bytes > (size_t(256) << 20), ts));
             }
             if (timed) HIP_TRY(hipEventRecord(p.b, ts));
             // Re-sort the tiles for this stream's coming frames from the costs just measured: after its first

@@ -179,7 +179,8 @@ struct RayQueue {
 };
 
 // `wide`: walk the wide records (TraceArgs::wide) instead of the 8-byte ones; same results
-hipError_t launch_trace(const TraceArgs& a, bool wide, hipStream_t s);
+// hbm_scene: the kernel compiled for one more wave per SIMD (a scene beyond the Infinity Cache)
+hipError_t launch_trace(const TraceArgs& a, bool wide, bool hbm_scene, hipStream_t s);
 // test hook: the walk (cast_ray) for caller-given rays; out = 8 floats per ray (hit, time, bits(leaf word), normal, 0, 0)
 hipError_t launch_path_log(const TraceArgs& a, bool wide, int x, int y, float* log, hipStream_t s);
 hipError_t launch_cast_probe(const TraceArgs& a, bool wide, const float* origins, const float* dirs, float* out, unsigned n, hipStream_t s);

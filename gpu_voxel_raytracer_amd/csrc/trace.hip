@@ -47,6 +47,9 @@ namespace {
 #ifndef VXRT_TRACE_WAVES
 #define VXRT_TRACE_WAVES 5   // waves per SIMD the register allocation aims for (96 VGPRs)
 #endif
+#ifndef VXRT_TRACE_WAVES_HBM
+#define VXRT_TRACE_WAVES_HBM 6   // the same for a scene beyond the Infinity Cache, whose walk waits on HBM (80 VGPRs, with spills): see launch_trace
+#endif
 // Sky cull.  True only when the primary ray (o, d) PROVABLY makes cast_bounded_ray return false, decided without walking:
 //  * the ray is regular (every component of 1 / d finite and non-zero) and, by a slab test in plain binary32, misses the box
 //    TraceArgs::cull_min/max — the smallest box of cells of tree level L = min(depth, 7) that holds every voxel, grown by a margin
@@ -85,8 +88,8 @@ __device__ __forceinline__ void store_primary_miss(const TraceArgs& a, const Fra
 constexpr int kTB = VXRT_TRACE_BLOCK;
 constexpr int kTileW = kTB == 64 ? 8 : 16, kTileH = kTB == 256 ? 16 : 8;
 
-template <bool kWide>
-__global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void trace_kernel(const TraceArgs a) {
+template <bool kWide, int kWaves>
+__global__ __launch_bounds__(kTB, kWaves) void trace_kernel(const TraceArgs a) {
     extern __shared__ uint4 lds_stack[];  // the threads' frames: Caster<kWide>
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -439,16 +442,20 @@ unsigned trace_tile_count(int width, int local_rows) {
 
 void trace_tile_dims(int* w, int* h) { *w = kTileW; *h = kTileH; }
 
-hipError_t launch_trace(const TraceArgs& a, bool wide, hipStream_t s) {
+// hbm_scene: the scene does not fit the Infinity Cache (BASELINE config 5: 5.6 GB), so a descend waits for HBM and one more wave per
+// SIMD hides more of that than its spilled registers cost: 2.25 -> 2.08 ms (outside view), 15.5 -> 14.1 ms (tunnel) at 4K, 8 bounces;
+// 8 waves: 3.79 / 26.1 ms.  On a cache-resident scene the same change loses 3-5 %.
+hipError_t launch_trace(const TraceArgs& a, bool wide, bool hbm_scene, hipStream_t s) {
     dim3 grid(trace_tile_count(a.band.width, a.band.local_rows) * unsigned(a.batch));
     const size_t lds = caster_lds_bytes(a, wide, kTB);
 #if VXRT_VARIANTS
     if (wide) {
-        hipLaunchKernelGGL(trace_kernel<true>, grid, dim3(kTB), lds, s, a);
+        hipLaunchKernelGGL((trace_kernel<true, VXRT_TRACE_WAVES>), grid, dim3(kTB), lds, s, a);
         return hipGetLastError();
     }
 #endif
-    hipLaunchKernelGGL(trace_kernel<false>, grid, dim3(kTB), lds, s, a);
+    if (hbm_scene) hipLaunchKernelGGL((trace_kernel<false, VXRT_TRACE_WAVES_HBM>), grid, dim3(kTB), lds, s, a);
+    else hipLaunchKernelGGL((trace_kernel<false, VXRT_TRACE_WAVES>), grid, dim3(kTB), lds, s, a);
     return hipGetLastError();
 }
 
