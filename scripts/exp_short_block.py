@@ -7,8 +7,11 @@ from gpu_voxel_raytracer_amd import Context, Camera, TRACE, scenes
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 pos, mrgb, size = scenes.load_scene("menger")
 cam = scenes.bench_camera(size)
+deals = ((3, 7), (1, 20), (2, 10), (4, 5), (2, 5), (3, 4), (1, 10))
+if os.environ.get("UNEVEN"):   # unequal parts: a launch of `batch` frames, then the rest
+    deals = ((1, 20), (2, 10), (2, 12), (2, 14), (2, 16), (3, 8), (3, 10))
 for nranks in (1, 2, 4, 8):
-    for infl, batch in ((3, 7), (1, 20), (2, 10), (4, 5), (2, 5), (3, 4), (1, 10)):
+    for infl, batch in deals:
         with Context(1920, 1080, max_bounces=4, rank=0, nranks=nranks, frames_in_flight=infl, frames_per_launch=batch, band_rows=8) as ctx:
             ctx.recreate_octree(pos, mrgb); ctx.camera = Camera(*cam)
             for _ in range(20):
