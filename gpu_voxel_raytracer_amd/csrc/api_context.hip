@@ -323,6 +323,7 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) try {
     if (const char* v = getenv("VXRT_RAYS_PER_WAVE")) c->rays_per_wave = unsigned(atoi(v));
     c->shade_blocks = (c->shade_blocks < 8 ? 8 : (c->shade_blocks > 2048 ? 2048 : c->shade_blocks) + 7) / 8 * 8;
     if (const char* v = getenv("VXRT_TRACE_BLOCKS")) c->trace_blocks = atoi(v);
+    if (const char* v = getenv("VXRT_FRAME_LANES")) c->frame_lanes = atoi(v);
     if (c->inflight < 1 || c->inflight > 16) { set_error("frames_in_flight must be 1..16"); return fail(VXRT_E_INVALID); }
     c->batch = cfg->frames_per_launch == 0 ? 1 : int(cfg->frames_per_launch);
     if (const char* v = getenv("VXRT_BATCH")) c->batch = atoi(v);

@@ -181,6 +181,7 @@ struct vxrt_ctx {
     int last_schedule = 0;
     int use_tile_order = 1;
     int trace_blocks = 2048;
+    int frame_lanes = 1;   // trace_kernel may put 8 frames of a pixel row into a wave (TraceArgs::frame_lanes)
     int path_blocks = 512;  // tracer 5: blocks of path_kernel (each wave takes an equal range of the queue, >= 512 paths)
     int tail_from = 1;  // tracer 4: the hit number at which live paths move to the compacted launches
     unsigned tail_split = 0;  // ... bit k: the tail compacts again and starts a new launch at path segment k

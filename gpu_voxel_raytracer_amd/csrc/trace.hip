@@ -88,8 +88,15 @@ __device__ __forceinline__ void store_primary_miss(const TraceArgs& a, const Fra
 constexpr int kTB = VXRT_TRACE_BLOCK;
 constexpr int kTileW = kTB == 64 ? 8 : 16, kTileH = kTB == 256 ? 16 : 8;
 
-template <bool kWide, int kWaves>
+// kFrameLanes: which 64 (pixel, frame) pairs share a wave.  false: an 8 x 8 pixel tile of ONE frame of the launch.  true (the frames
+// of the launch share one camera, 8 or 16 of them): one 8-pixel ROW of a tile in EIGHT consecutive frames, lane = frame * 8 + column —
+// a pixel's primary ray is the same in every frame and its first sun rays nearly so, so the lanes of a wave leave the walk's lock-step
+// rounds closer together (priced on the oracle's step counts, tests/sim_schedule.py: lane_mappings: - 12 % wave-instructions in this
+// kernel; measured + 7 % on the bench view); each frame's stores stay whole 128-byte row segments (4 x 2 pixels x 8 frames, 64-byte
+// segments, is priced 3 % better and measured 6 % worse).  The per-pixel operations are the same either way.
+template <bool kWide, int kWaves, bool kFrameLanes>
 __global__ __launch_bounds__(kTB, kWaves) void trace_kernel(const TraceArgs a) {
+    static_assert(!kFrameLanes || kTB == 64, "frame lanes: one wave per block");
     extern __shared__ uint4 lds_stack[];  // the threads' frames: Caster<kWide>
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -101,26 +108,36 @@ __global__ __launch_bounds__(kTB, kWaves) void trace_kernel(const TraceArgs a) {
     // a launch covers `batch` consecutive frames (same camera, frame numbers frame_number ..): the blocks of one tile
     // position in all frames are neighbours in launch order, so longest-first holds across the whole batch
     const unsigned batch = unsigned(a.batch);
-    const unsigned fb = blockIdx.x % batch, ord = blockIdx.x / batch;
-    const FrameOut fo = a.out[fb];
+    unsigned fb, ord, row_in_tile;
+    if (kFrameLanes) {   // block = (tile, row of the tile, group of 8 frames)
+        const unsigned groups = (batch + 7u) / 8u;
+        fb = (blockIdx.x % groups) * 8u + unsigned(lane >> 3);
+        row_in_tile = (blockIdx.x / groups) % 8u;
+        ord = blockIdx.x / (groups * 8u);
+    } else {
+        fb = blockIdx.x % batch;
+        row_in_tile = unsigned(lane >> 3);
+        ord = blockIdx.x / batch;
+    }
     const bool gbuf = ((a.gbuf_frames >> fb) & 1u) != 0u;   // this frame's normal/depth and albedo/node images are wanted
     const unsigned tile = a.tile_order ? a.tile_order[ord] : ord;
     const int x = int(tile % tiles_x) * kTileW + (wave & 1) * 8 + (lane & 7);
-    const int lrow = int(tile / tiles_x) * kTileH + (wave >> 1) * 8 + (lane >> 3);
+    const int lrow = int(tile / tiles_x) * kTileH + (wave >> 1) * 8 + int(row_in_tile);
     const int lband = lrow / a.band.band_rows;
     const int y = (lband * a.band.nranks + a.band.rank) * a.band.band_rows + (lrow - lband * a.band.band_rows);
-    const bool active = x < a.band.width && lrow < a.band.local_rows && y < a.band.height;
+    const bool active = x < a.band.width && lrow < a.band.local_rows && y < a.band.height && fb < batch;
+    const unsigned cam_index = kFrameLanes ? 0u : fb;   // kFrameLanes: one camera for the launch (trace_frames checks)
 
     uint32_t rays = 0;
     const unsigned tail_shard = (blockIdx.x * unsigned(kTB / 64) + unsigned(wave)) % kShards;
     if (a.tail.recs != nullptr) zero_counts(a.tail_zero, tid);
     bool walk = active;
     if (active) {   // the sky cull: a pixel whose primary ray certainly misses needs no walk
-        const Cam& cam = a.cams[fb];
+        const Cam& cam = a.cams[cam_index];
         const f3 o = ld3(cam.o);
         const f3 d = norm3((float(x) * ld3(cam.r) - float(y) * ld3(cam.u)) + ld3(cam.f));  // voxels.comp:299-303
         if (primary_miss_is_certain(a, o, d)) {
-            store_primary_miss(a, fo, size_t(lrow) * a.band.width + x, d, gbuf);
+            store_primary_miss(a, a.out[fb], size_t(lrow) * a.band.width + x, d, gbuf);
             rays = 1;
             walk = false;
         }
@@ -136,7 +153,7 @@ __global__ __launch_bounds__(kTB, kWaves) void trace_kernel(const TraceArgs a) {
 
         const f3 sun_dir = ld3(a.sun_dir), sun_color = ld3(a.sun_color), sky = ld3(a.sky_color);
 
-        const Cam& cam = a.cams[fb];
+        const Cam& cam = a.cams[cam_index];
         f3 o = ld3(cam.o);
         f3 d = norm3((float(x) * ld3(cam.r) - float(y) * ld3(cam.u)) + ld3(cam.f));  // voxels.comp:299-303
 
@@ -197,8 +214,8 @@ __global__ __launch_bounds__(kTB, kWaves) void trace_kernel(const TraceArgs a) {
                     float sun_power = sun_power_of(a, d);
                     sample = sample + (sky + sun_color * sun_power) * blend;
                     if (gbuf) {
-                        store_out(fo.nd + pix, make_float4(kAlmostInfinity, kAlmostInfinity, kAlmostInfinity, -1.0f));
-                        store_out(fo.albedo + pix, make_float4(1.0f, 1.0f, 1.0f, __int_as_float(0xffffff)));
+                        store_out(a.out[fb].nd + pix, make_float4(kAlmostInfinity, kAlmostInfinity, kAlmostInfinity, -1.0f));
+                        store_out(a.out[fb].albedo + pix, make_float4(1.0f, 1.0f, 1.0f, __int_as_float(0xffffff)));
                     }
                 } else {
                     sample = sample + sky * blend;
@@ -211,9 +228,9 @@ __global__ __launch_bounds__(kTB, kWaves) void trace_kernel(const TraceArgs a) {
             const f3 color = bounce == 0 ? splat3(1.0f) : node_color(hit.node);
             const f3 emit = node_emittance(hit.node, a.emit_strength);
             if (bounce == 0 && gbuf) {  // first-hit G-buffer                   voxels.comp:320-324,392-396
-                store_out(fo.nd + pix, make_float4(n.x, n.y, n.z, hit.time));
+                store_out(a.out[fb].nd + pix, make_float4(n.x, n.y, n.z, hit.time));
                 f3 alb = (hit.node & kEmitBit) == 0 ? node_color(hit.node) : splat3(1.0f);
-                store_out(fo.albedo + pix, make_float4(alb.x, alb.y, alb.z, __int_as_float(hit.node)));
+                store_out(a.out[fb].albedo + pix, make_float4(alb.x, alb.y, alb.z, __int_as_float(hit.node)));
             }
             // Hand the path over, in the state bounce_kernel resumes from — unless the queue is full (it is sized from what earlier
             // launches queued, not for the worst case): then this lane goes on as in the all-in-one kernel.  The record is stored
@@ -280,7 +297,7 @@ __global__ __launch_bounds__(kTB, kWaves) void trace_kernel(const TraceArgs a) {
 
         if (!handed_over) {
             f3 out = sample / float(ambient_rays);  // voxels.comp:391
-            store_out(fo.color + pix, make_float4(out.x, out.y, out.z, 1.0f));
+            store_out(a.out[fb].color + pix, make_float4(out.x, out.y, out.z, 1.0f));
         }
     }
 
@@ -445,17 +462,22 @@ void trace_tile_dims(int* w, int* h) { *w = kTileW; *h = kTileH; }
 // hbm_scene: the scene does not fit the Infinity Cache (BASELINE config 5: 5.6 GB), so a descend waits for HBM and one more wave per
 // SIMD hides more of that than its spilled registers cost: 2.25 -> 2.08 ms (outside view), 15.5 -> 14.1 ms (tunnel) at 4K, 8 bounces;
 // 8 waves: 3.79 / 26.1 ms.  On a cache-resident scene the same change loses 3-5 %.
-hipError_t launch_trace(const TraceArgs& a, bool wide, bool hbm_scene, hipStream_t s) {
-    dim3 grid(trace_tile_count(a.band.width, a.band.local_rows) * unsigned(a.batch));
+hipError_t launch_trace(const TraceArgs& args, bool wide, bool hbm_scene, hipStream_t s) {
+    TraceArgs a = args;
+    if (hbm_scene || wide || kTB != 64) a.frame_lanes = 0;   // those kernels exist with one frame per wave only
+    // frame lanes: a tile's 8 rows x ceil(batch / 8) groups of 8 frames; otherwise one block per tile and frame
+    const unsigned per_tile = a.frame_lanes ? 8u * ((unsigned(a.batch) + 7u) / 8u) : unsigned(a.batch);
+    dim3 grid(trace_tile_count(a.band.width, a.band.local_rows) * per_tile);
     const size_t lds = caster_lds_bytes(a, wide, kTB);
 #if VXRT_VARIANTS
     if (wide) {
-        hipLaunchKernelGGL((trace_kernel<true, VXRT_TRACE_WAVES>), grid, dim3(kTB), lds, s, a);
+        hipLaunchKernelGGL((trace_kernel<true, VXRT_TRACE_WAVES, false>), grid, dim3(kTB), lds, s, a);
         return hipGetLastError();
     }
 #endif
-    if (hbm_scene) hipLaunchKernelGGL((trace_kernel<false, VXRT_TRACE_WAVES_HBM>), grid, dim3(kTB), lds, s, a);
-    else hipLaunchKernelGGL((trace_kernel<false, VXRT_TRACE_WAVES>), grid, dim3(kTB), lds, s, a);
+    if (hbm_scene) hipLaunchKernelGGL((trace_kernel<false, VXRT_TRACE_WAVES_HBM, false>), grid, dim3(kTB), lds, s, a);
+    else if (a.frame_lanes) hipLaunchKernelGGL((trace_kernel<false, VXRT_TRACE_WAVES, kTB == 64>), grid, dim3(kTB), lds, s, a);
+    else hipLaunchKernelGGL((trace_kernel<false, VXRT_TRACE_WAVES, false>), grid, dim3(kTB), lds, s, a);
     return hipGetLastError();
 }
 
