@@ -182,20 +182,24 @@ def pick_schedule(world, steps, inflight=0, batch=0):
     scripts/exp_rank_emulation.py, round 3: 2x16 for 1 rank, 3x16 for 2 / 4 / 8 ranks).  Never more than 3 trace streams: with the
     context's own stream that makes 4, and RCCL / torch bring streams of their own; a process gets GPU_MAX_HW_QUEUES = 8 hardware
     queues here (set above), and streams beyond the queues share one and serialise (scripts/exp_first_context.py).
-    A short block (fewer frames than two full launches per stream) starts on an idle GPU and ends with a drain; its frames are dealt
-    in equal parts to 3 / 2 / 1 launches for 1 / 2 / >= 4 ranks (scripts/exp_short_block.py, 20 steps, ms per block, rank 0 alone on
-    the GPU: 1 rank 7x3 2.35, 10x2 2.41, 20x1 2.53; 2 ranks 10x2 1.25, 7x3 1.26; 4 ranks 20x1 0.715, 7x3 0.721; 8 ranks 20x1
-    0.404, 7x3 0.426 — the smaller a rank's share, the more a launch is its longest tile's chain and nothing else, and one launch
-    pays that chain once)."""
+    A short block (fewer frames than two full launches per stream) starts on an idle GPU and ends with a drain.  Its frames go out in
+    launches of 8 on three streams for 1 and 2 ranks, of 16 on two streams for 4 ranks — whole groups of 8 frames, so that
+    trace_kernel's waves hold 8 frames of a pixel row (VXRT_OPT_FRAME_LANES) — and as ONE launch from 8 ranks on: the smaller a rank's
+    share, the more a launch is its longest tile's chain and nothing else, and one launch pays that chain once
+    (scripts/exp_short_block.py with LANES=1, 20 steps, ms per block, rank 0 alone on the GPU: 1 rank 8+8+4 2.33, 7+7+6 2.36, 20 2.50;
+    2 ranks 8+8+4 1.227, 16+4 1.227, 7+7+6 1.262; 4 ranks 16+4 0.700, 8+8+4 0.704, 20 0.714; 8 ranks 20 0.402, 16+4 0.411, 8+8+4 0.423)."""
     short = steps < 2 * 16 * (inflight if inflight > 0 else (2 if world == 1 else 3))
+    if inflight <= 0 and batch <= 0 and short:
+        if world <= 2:
+            return 3, min(8, steps)
+        if world < 8:
+            return 2, min(16, steps)
+        inflight = min(3, -(-steps // 32))
+        return inflight, max(1, -(-steps // inflight))
     if inflight <= 0:
-        inflight = ((3 if world == 1 else 2 if world == 2 else 1) if short else (2 if world == 1 else 3))
-        if short and steps > 32 * inflight:
-            inflight = min(3, -(-steps // 32))
+        inflight = 2 if world == 1 else 3
     if batch <= 0:
-        batch = 16
-        if short:
-            batch = max(1, min(32, -(-steps // inflight)))
+        batch = max(1, min(32, -(-steps // inflight))) if short else 16
     return inflight, batch
 
 

@@ -21,9 +21,11 @@ int local_band_count(const BandMap& b) {
 
 void free_images(vxrt_ctx* c) {
     for (vxrt_ctx::Slot& sl : c->ring) {
-        for (float4** p : {&sl.sampled_color, &sl.albedo, &sl.nd}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        sl.sampled_color = sl.albedo = sl.nd = nullptr;   // pieces of ring_arena
         if (sl.own) (void)hipEventDestroy(sl.own);
     }
+    if (c->ring_arena) (void)hipFree(c->ring_arena);
+    c->ring_arena = nullptr;
     c->ring.clear();
     free_halo(c);
     float4** imgs[] = {&c->accum[0], &c->accum[1], &c->denoised, &c->spp_sum};
@@ -54,12 +56,16 @@ int alloc_images(vxrt_ctx* c) {
         return VXRT_E_INVALID;
     }
     // inflight frames being traced + the frame in the post stages + the temporal history
+    // ONE allocation for the whole ring (each image on a 2 MiB boundary): a hundred separate 33 MB allocations land wherever the
+    // driver finds room, and the trace stage's rate then differs by up to 4 % from process to process (101.3 .. 105.6 ms per 960
+    // bench frames, each process steady to 0.1 %)
     c->ring.resize(size_t(c->inflight) * size_t(c->batch) + 2);
+    const size_t pitch = (bytes + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ring_arena), pitch * 3 * c->ring.size()));
+    HIP_TRY(hipMemsetAsync(c->ring_arena, 0, pitch * 3 * c->ring.size(), c->stream));
+    size_t piece = 0;
     for (vxrt_ctx::Slot& sl : c->ring) {
-        for (float4** p : {&sl.sampled_color, &sl.albedo, &sl.nd}) {
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), bytes));
-            HIP_TRY(hipMemsetAsync(*p, 0, bytes, c->stream));
-        }
+        for (float4** p : {&sl.sampled_color, &sl.albedo, &sl.nd}) *p = reinterpret_cast<float4*>(c->ring_arena + pitch * piece++);
         HIP_TRY(hipEventCreateWithFlags(&sl.own, hipEventDisableTiming));
         sl.trace_done = sl.last_use = nullptr;
         sl.last_use_recorded = false;
@@ -284,6 +290,10 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) try {
     vxrt_default_denoise(&c->denoise);
     int rc = VXRT_OK;
     auto fail = [&](int code) { vxrt_destroy(c); return code; };
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) c->wave_slots = unsigned(cus) * 4u * 5u;
+    }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipStreamCreate"));
     if (hipEventCreateWithFlags(&c->halo_event, hipEventDisableTiming) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipEventCreate"));
     if (const char* v = getenv("VXRT_SKY_CULL")) c->sky_cull = atoi(v) != 0;   // A/B and tests
@@ -324,6 +334,7 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) try {
     c->shade_blocks = (c->shade_blocks < 8 ? 8 : (c->shade_blocks > 2048 ? 2048 : c->shade_blocks) + 7) / 8 * 8;
     if (const char* v = getenv("VXRT_TRACE_BLOCKS")) c->trace_blocks = atoi(v);
     if (const char* v = getenv("VXRT_FRAME_LANES")) c->frame_lanes = atoi(v);
+    if (const char* v = getenv("VXRT_SPREAD")) c->spread_override = atoi(v);
     if (c->inflight < 1 || c->inflight > 16) { set_error("frames_in_flight must be 1..16"); return fail(VXRT_E_INVALID); }
     c->batch = cfg->frames_per_launch == 0 ? 1 : int(cfg->frames_per_launch);
     if (const char* v = getenv("VXRT_BATCH")) c->batch = atoi(v);
@@ -445,6 +456,10 @@ int vxrt_set_option(vxrt_ctx* c, vxrt_option option, uint32_t value) try {
             if (value > 1) { set_error("sky cull must be 0 or 1"); return VXRT_E_INVALID; }
             c->sky_cull = int(value);
             return VXRT_OK;
+        case VXRT_OPT_FRAME_LANES:
+            if (value > 1) { set_error("frame lanes must be 0 or 1"); return VXRT_E_INVALID; }
+            c->frame_lanes = int(value);
+            return VXRT_OK;
         case VXRT_OPT_HALO_ROWS:
             if (value > 4096) { set_error("halo rows must be 0..4096"); return VXRT_E_INVALID; }
             c->halo_min_rows = value;
@@ -526,6 +541,7 @@ int vxrt_get_stats(vxrt_ctx* c, vxrt_stats* out) try {
     out->halo_unpack_ms = c->ms[4];
     out->halo_exchanges = c->halo_exchanges;
     out->cull_box_valid = c->box_valid ? 1u : 0u;
+    out->frame_lane_launches = c->frame_lane_launches;
     memcpy(out->cull_box_min, c->box_min, sizeof c->box_min);
     memcpy(out->cull_box_max, c->box_max, sizeof c->box_max);
     out->timed_frames = c->timed_frames;
@@ -555,6 +571,7 @@ int vxrt_reset_stats(vxrt_ctx* c) try {
     c->queue_overflow_paths = 0;
     c->ms[0] = c->ms[1] = c->ms[2] = c->ms[3] = c->ms[4] = 0.0;
     c->halo_exchanges = 0;
+    c->frame_lane_launches = 0;
     return VXRT_OK;
 } VXRT_CATCH
 

@@ -206,6 +206,7 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
                 a.tail_zero = sets[(J + 2) % 3];
                 a.tail_from = c->tail_from;
                 HIP_TRY(launch_trace(a, use_wide(c) && c->trace_variant == 4, false, ts));
+                if (a.frame_lanes && !(use_wide(c) && c->trace_variant == 4)) c->frame_lane_launches++;
                 sq.launches = J + 1;
                 if (!sq.counts_pending) {   // how much room this launch wanted (the set stays untouched until launch J + 2 clears it)
                     HIP_TRY(hipMemcpyAsync(sq.host_counts, sets[(J + 1) % 3], 64 * 64, hipMemcpyDeviceToHost, ts));
@@ -226,13 +227,14 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
                 }
             } else {
                 HIP_TRY(launch_trace(a, use_wide(c), scene_bytes > (size_t(256) << 20), ts));
+                if (a.frame_lanes && !use_wide(c) && scene_bytes <= (size_t(256) << 20)) c->frame_lane_launches++;
             }
             if (timed) HIP_TRY(hipEventRecord(p.b, ts));
             // Re-sort the tiles for this stream's coming frames from the costs just measured: after its first
             // frame, then every 8th (costs keep accumulating as a running maximum in between; ~7 us per sort).
             if (c->use_tile_order && (!sched.valid || sched.age >= 8)) {
                 const unsigned tiles = trace_tile_count(c->band.width, c->band.local_rows);
-                HIP_TRY(launch_tile_order(sched.cost, sched.order, sched.last_cost, sched.scratch, tiles, ts));
+                HIP_TRY(launch_tile_order(sched.cost, sched.order, sched.last_cost, sched.scratch, tiles, g * unsigned(c->inflight), c->wave_slots, c->spread_override, ts));
                 sched.valid = true;
                 sched.age = 0;
             }

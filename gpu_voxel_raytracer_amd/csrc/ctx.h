@@ -101,6 +101,7 @@ struct vxrt_ctx {
     std::vector<Slot> ring;
     int inflight = 1;
     std::vector<hipStream_t> trace_streams;   // inflight entries; entry 0 is `stream` when inflight == 1
+    char* ring_arena = nullptr;               // the ring's images: one allocation (alloc_images)
     std::vector<hipEvent_t> launch_events;    // two per trace stream, used alternately: "this launch has finished"
     std::vector<unsigned> launch_event_turn;
     int slot = 0;        // slot of the most recently traced frame
@@ -181,7 +182,10 @@ struct vxrt_ctx {
     int last_schedule = 0;
     int use_tile_order = 1;
     int trace_blocks = 2048;
-    int frame_lanes = 1;   // trace_kernel may put 8 frames of a pixel row into a wave (TraceArgs::frame_lanes)
+    int spread_override = -1;     // VXRT_SPREAD (tests, experiments): see launch_tile_order
+    unsigned wave_slots = 5120;   // waves of trace_kernel the device holds at once: CUs x 4 SIMDs x 5 (vxrt_create)
+    int frame_lanes = 1;   // trace_kernel may put 8 frames of a pixel row into a wave (TraceArgs::frame_lanes; VXRT_OPT_FRAME_LANES)
+    uint32_t frame_lane_launches = 0;
     int path_blocks = 512;  // tracer 5: blocks of path_kernel (each wave takes an equal range of the queue, >= 512 paths)
     int tail_from = 1;  // tracer 4: the hit number at which live paths move to the compacted launches
     unsigned tail_split = 0;  // ... bit k: the tail compacts again and starts a new launch at path segment k

@@ -196,7 +196,10 @@ hipError_t launch_trace_rayqueue(const TraceArgs& a, const PathQueue& hits, unsi
 #endif
 // longest-tile-first schedule for the next launch: order[] = tiles sorted by descending cost; cost[] is cleared
 // scratch: 256 * 128 uint32
-hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t* last_cost, uint32_t* scratch, unsigned tiles, hipStream_t s);
+// waves_x_launches: waves per tile of a launch x launches that share the chip; wave_slots: waves the chip holds at once;
+// spread_override: -1 = the sort decides how far the tiles that walk are spread over the launch, 0 .. 256 = that many 256ths
+hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t* last_cost, uint32_t* scratch, unsigned tiles, unsigned waves_x_launches,
+                             unsigned wave_slots, int spread_override, hipStream_t s);
 #if VXRT_VARIANTS
 // wavefront: primary_kernel + max_bounces x bounce_kernel; queues[2] ping-pong, count_sets[3] rotate
 hipError_t launch_trace_wavefront(const TraceArgs& a, const PathQueue queues[2], unsigned* count_sets[3], unsigned* launch_counter,

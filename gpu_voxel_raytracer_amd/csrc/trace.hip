@@ -86,6 +86,7 @@ __device__ __forceinline__ void store_primary_miss(const TraceArgs& a, const Fra
 }
 
 constexpr int kTB = VXRT_TRACE_BLOCK;
+constexpr uint32_t kLightCost = 1u;   // cost-map entry of a tile none of whose pixels walked (any walking wave records its duration, >= 4)
 constexpr int kTileW = kTB == 64 ? 8 : 16, kTileH = kTB == 256 ? 16 : 8;
 
 // kFrameLanes: which 64 (pixel, frame) pairs share a wave.  false: an 8 x 8 pixel tile of ONE frame of the launch.  true (the frames
@@ -129,7 +130,11 @@ __global__ __launch_bounds__(kTB, kWaves) void trace_kernel(const TraceArgs a) {
     const unsigned cam_index = kFrameLanes ? 0u : fb;   // kFrameLanes: one camera for the launch (trace_frames checks)
 
     uint32_t rays = 0;
-    const unsigned tail_shard = (blockIdx.x * unsigned(kTB / 64) + unsigned(wave)) % kShards;
+    // the shard of the tail queue this wave appends to: the top bits of a multiplicative hash of the wave's index — the waves that
+    // append (tiles that see geometry) sit at regular distances in the launch order (16 blocks per tile, every k-th tile), and
+    // index % 64 then filled half or a quarter of the shards while the others stayed empty
+    static_assert(kShards == 64, "6 hash bits");
+    const unsigned tail_shard = ((blockIdx.x * unsigned(kTB / 64) + unsigned(wave)) * 0x9E3779B1u) >> 26;
     if (a.tail.recs != nullptr) zero_counts(a.tail_zero, tid);
     bool walk = active;
     if (active) {   // the sky cull: a pixel whose primary ray certainly misses needs no walk
@@ -142,6 +147,7 @@ __global__ __launch_bounds__(kTB, kWaves) void trace_kernel(const TraceArgs a) {
             walk = false;
         }
     }
+    const bool light_wave = __ballot(walk) == 0ull;   // nobody walks: sky (or beyond the frame's edge) — see tile_scatter_kernel
     if (walk) {
         bool handed_over = false;  // this lane's path continues in bounce_kernel (TraceArgs::tail)
         const Caster<kWide> caster(a, lds_stack, tid);
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(kTB, kWaves) void trace_kernel(const TraceArgs a) {
     count_rays(a.ray_counter, rays, lane);
     if (a.tile_cost && lane == 0) {
         const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_start;
-        atomicMax(a.tile_cost + tile, dt > 0xffffffffull ? 0xffffffffu : uint32_t(dt));
+        atomicMax(a.tile_cost + tile, light_wave ? kLightCost : (dt > 0xffffffffull ? 0xffffffffu : (dt < 4ull ? 4u : uint32_t(dt))));
     }
 }
 
@@ -332,7 +338,21 @@ __global__ __launch_bounds__(256) void tile_hist_kernel(const uint32_t* cost, ui
 
 // block_hist[k][b] -> the position in `order` where block b's tiles of bin k start (bins in descending cost, blocks in order).
 // 4 waves x 32 bins; lane = block (blocks <= 64): an exclusive wave scan per bin, then the bins' bases.
-__global__ __launch_bounds__(256) void tile_scan_kernel(uint32_t* block_hist, unsigned blocks) {
+// lower bound of the costs with key k (the inverse of tile_key)
+__device__ __forceinline__ unsigned long long key_cost(unsigned k) {
+    if (k < 4u) return k;
+    const unsigned e = (k + 4u) >> 2, m = (k + 4u) & 3u;
+    return (unsigned long long)(4u + m) << (e - 2u);
+}
+
+// ... and decides how far the tiles that walk are spread over the launch (tile_scatter_kernel), in 1/256: the launch lasts about
+// T = (sum of the tiles' costs) x waves_x_launches / wave_slots (waves per tile x launches that share the chip; a tile's cost is its
+// longest wave's duration), its longest chain L = the largest cost; the chains must have started by T - L, and they get shorter down
+// the order, so the tiles that walk are spread over the first 1 - 2 L / T of the launch — not at all when the launch is little more
+// than its chains (a rank's share of a frame at 4 or 8 ranks: there longest-first is 3 % faster, measured; with a whole frame per
+// rank spreading is 1-3 % faster and steadier)
+__global__ __launch_bounds__(256) void tile_scan_kernel(uint32_t* block_hist, unsigned blocks, unsigned waves_x_launches, unsigned wave_slots,
+                                                        int spread_override) {
     __shared__ unsigned total[kSortBins], base[kSortBins];
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (unsigned k = wave * 32u; k < wave * 32u + 32u; k++) {
@@ -349,10 +369,40 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(uint32_t* block_hist, un
     if (threadIdx.x == 0) {
         unsigned sum = 0;
         for (unsigned i = 0; i < kSortBins; i++) { base[i] = sum; sum += total[i]; }
+        block_hist[kSortBins * kSortBlocks] = base[kSortBins - 1u - 3u];   // tiles with cost >= 4: somebody walked (bins are in descending cost)
+        unsigned long long all = 0, longest = 0;
+        for (unsigned i = 0; i < kSortBins; i++) {
+            const unsigned long long c = key_cost(kSortBins - 1u - i);
+            all += c * total[i];
+            if (longest == 0 && total[i] != 0u) longest = c;
+        }
+        const unsigned long long T = all * waves_x_launches / (wave_slots ? wave_slots : 1u);
+        unsigned spread = T > 2u * longest ? unsigned((T - 2u * longest) * 256u / T) : 0u;
+        if (spread_override >= 0) spread = unsigned(spread_override);
+        block_hist[kSortBins * kSortBlocks + 1u] = spread;
     }
     __syncthreads();
     for (unsigned k = wave * 32u; k < wave * 32u + 32u; k++)
         if (lane < blocks) block_hist[k * blocks + lane] += base[k];
+}
+
+// Where the tile of sorted rank r (descending cost) goes in the launch order.  Plain longest-first puts every tile that walks ahead
+// of every tile of sky: the chip then runs a VALU-bound phase followed by a store-bound one, and the trace stage's rate came to
+// depend on the noise of the measured costs (100.7 .. 106.1 ms per 960 bench frames from process to process, against a steady 100.9
+// in plain row-major order, where sky and geometry tiles alternate by themselves).  So: the nh tiles that walk keep their
+// descending order — the longest chains still start first — but are SPREAD over the launch, each followed by k = nl / nh of the nl
+// tiles that only store (kLightCost); what is left of those comes last.  With more walking than light tiles the order stays
+// longest-first (a view without sky is bound by its chains).
+__device__ __forceinline__ unsigned spread_position(unsigned r, unsigned n, unsigned nh, unsigned spread256) {
+    const unsigned nl = n - nh;
+    if (nh == 0u) return r;
+    // k even: an odd period.  Blocks reach the CUs in a fixed rotation of their index, and with an even period the tiles that walk
+    // met the same half (period 2) or quarter (4) of the CUs launch after launch: 22 instead of 31 Gray/s on the bench view
+    const unsigned k = unsigned((unsigned long long)nl * spread256 / 256u / nh) & ~1u, period = k + 1u;
+    if (k == 0u) return r;
+    if (r < nh) return r * period;
+    const unsigned q = r - nh, turn = q / k;
+    return turn < nh ? turn * period + 1u + (q - turn * k) : nh * period + (q - nh * k);
 }
 
 __global__ __launch_bounds__(256) void tile_scatter_kernel(uint32_t* cost, uint32_t* order, uint32_t* last_cost, const uint32_t* block_offs,
@@ -360,10 +410,11 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(uint32_t* cost, uint3
     __shared__ unsigned offs[kSortBins];
     if (threadIdx.x < kSortBins) offs[threadIdx.x] = block_offs[threadIdx.x * gridDim.x + blockIdx.x];
     __syncthreads();
+    const unsigned heavy = block_offs[kSortBins * kSortBlocks], spread256 = block_offs[kSortBins * kSortBlocks + 1u];
     const unsigned t0 = blockIdx.x * per_block, t1 = t0 + per_block < tiles ? t0 + per_block : tiles;
     for (unsigned t = t0 + threadIdx.x; t < t1; t += 256u) {
         const uint32_t c = cost[t];
-        order[atomicAdd(&offs[kSortBins - 1u - tile_key(c)], 1u)] = t;
+        order[spread_position(atomicAdd(&offs[kSortBins - 1u - tile_key(c)], 1u), tiles, heavy, spread256)] = t;
         last_cost[t] = c;
         cost[t] = 0u;
     }
@@ -481,13 +532,13 @@ hipError_t launch_trace(const TraceArgs& args, bool wide, bool hbm_scene, hipStr
     return hipGetLastError();
 }
 
-hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t* last_cost, uint32_t* scratch, unsigned tiles, hipStream_t s) {
+hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t* last_cost, uint32_t* scratch, unsigned tiles, unsigned waves_x_launches,
+                             unsigned wave_slots, int spread_override, hipStream_t s) {
     const unsigned blocks = (tiles + 255u) / 256u < kSortBlocks ? (tiles + 255u) / 256u : kSortBlocks;
     const unsigned per_block = (tiles + blocks - 1u) / blocks;
     hipLaunchKernelGGL(tile_hist_kernel, dim3(blocks), dim3(256), 0, s, cost, scratch, tiles, per_block);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(256), 0, s, scratch, blocks);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(256), 0, s, scratch, blocks, waves_x_launches, wave_slots, spread_override);
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(blocks), dim3(256), 0, s, cost, order, last_cost, scratch, tiles, per_block);
     return hipGetLastError();
 }
-
 }  // namespace vxrt

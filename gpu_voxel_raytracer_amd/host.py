@@ -106,10 +106,10 @@ class Stats(C.Structure):
                 ("reserved0", C.c_uint32), ("queue_bytes", C.c_uint64),
                 ("queue_overflow_paths", C.c_uint64), ("halo_pack_ms", C.c_double), ("halo_unpack_ms", C.c_double),
                 ("halo_exchanges", C.c_uint64), ("cull_box_valid", C.c_uint32), ("cull_box_min", C.c_float * 3),
-                ("cull_box_max", C.c_float * 3), ("reserved1", C.c_uint32)]
+                ("cull_box_max", C.c_float * 3), ("frame_lane_launches", C.c_uint32)]
 
 
-OPT_DENOISE_MODE, OPT_TAIL_CAPACITY, OPT_SCENE_FORMAT, OPT_HALO_ROWS, OPT_SKY_CULL = 1, 2, 3, 4, 5
+OPT_DENOISE_MODE, OPT_TAIL_CAPACITY, OPT_SCENE_FORMAT, OPT_HALO_ROWS, OPT_SKY_CULL, OPT_FRAME_LANES = 1, 2, 3, 4, 5, 6
 
 
 class HaloInfo(C.Structure):

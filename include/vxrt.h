@@ -165,7 +165,7 @@ typedef struct vxrt_stats {
     uint32_t cull_box_valid;  /* the sky cull's box (VXRT_OPT_SKY_CULL): every occupied cell of tree level min(depth, 7),       */
     float cull_box_min[3];    /* world units, before the per-frame margin is added                                              */
     float cull_box_max[3];
-    uint32_t reserved1;
+    uint32_t frame_lane_launches; /* trace launches whose waves held 8 frames of a pixel row (VXRT_OPT_FRAME_LANES)              */
 } vxrt_stats;
 
 /* Run-time options (none of them changes what a frame means; defaults are the reference's behaviour).
@@ -189,9 +189,13 @@ typedef struct vxrt_stats {
  *                          disoccluded, the reference's rule for a reprojection that leaves the screen (temporal.comp:92).
  *   VXRT_OPT_SKY_CULL      1 (default): a pixel whose primary ray provably misses the scene — it misses, with a margin, the box of the
  *                          tree's occupied cells at level min(depth, 7) — gets voxels.comp's miss outputs without walking the octree
- *                          (same values: csrc/trace.hip, primary_miss_is_certain states the proof).  0: every primary ray walks.     */
+ *                          (same values: csrc/trace.hip, primary_miss_is_certain states the proof).  0: every primary ray walks.
+ *   VXRT_OPT_FRAME_LANES   1 (default): a trace launch of 8, 16, 24 or 32 frames of one camera (vxrt_render_frames / vxrt_render_spp with
+ *                          frames_per_launch a multiple of 8) gives each wave a row of 8 pixels in 8 consecutive frames instead of
+ *                          an 8 x 8 tile of one frame — the same per-pixel operations, more coherent waves (a pixel's primary ray is the
+ *                          same in every frame).  0: always one frame per wave.  vxrt_stats.frame_lane_launches counts the former.  */
 typedef enum vxrt_option { VXRT_OPT_DENOISE_MODE = 1, VXRT_OPT_TAIL_CAPACITY = 2, VXRT_OPT_SCENE_FORMAT = 3, VXRT_OPT_HALO_ROWS = 4,
-                           VXRT_OPT_SKY_CULL = 5 } vxrt_option;
+                           VXRT_OPT_SKY_CULL = 5, VXRT_OPT_FRAME_LANES = 6 } vxrt_option;
 int vxrt_set_option(vxrt_ctx* ctx, vxrt_option option, uint32_t value);
 
 /* ---- context: replaces Context::new / create_bindings / resize (src/context.rs:595-660, 936-1016,
@@ -363,7 +367,8 @@ int vxrt_debug_cast_rays(vxrt_ctx* ctx, const float* origins, const float* dirs,
 int vxrt_debug_path_log(vxrt_ctx* ctx, int32_t x, int32_t y, float* log, int32_t* casts);
 
 /* Diagnostics: duration (shader clocks) of each 16x16 tile of the last traced frame, row-major over
- * ceil(width/16) x ceil(local_rows/16) tiles — the data the longest-tile-first scheduler works from. */
+ * ceil(width/16) x ceil(local_rows/16) tiles — the data the longest-tile-first scheduler works from.  A tile none of
+ * whose pixels walked the octree (sky, culled) reads 1; a tile that walked, its longest wave's duration (>= 4). */
 int vxrt_debug_tile_costs(vxrt_ctx* ctx, uint32_t* out, size_t n);
 
 const char* vxrt_status_string(int status);

@@ -10,6 +10,8 @@ cam = scenes.bench_camera(size)
 deals = ((3, 7), (1, 20), (2, 10), (4, 5), (2, 5), (3, 4), (1, 10))
 if os.environ.get("UNEVEN"):   # unequal parts: a launch of `batch` frames, then the rest
     deals = ((1, 20), (2, 10), (2, 12), (2, 14), (2, 16), (3, 8), (3, 10))
+if os.environ.get("LANES"):    # round 3, frame lanes: launches of 8 or 16 frames hold 8 frames per wave
+    deals = ((3, 7), (3, 8), (2, 8), (2, 16), (1, 16), (1, 20), (1, 8), (2, 10))
 for nranks in (1, 2, 4, 8):
     for infl, batch in deals:
         with Context(1920, 1080, max_bounces=4, rank=0, nranks=nranks, frames_in_flight=infl, frames_per_launch=batch, band_rows=8) as ctx:

@@ -195,7 +195,7 @@ def test_frames_in_flight_give_identical_frames(O, H, scenes, noise, inflight):
         assert not np.array_equal(hist, ctx.read(3))
 
 
-@pytest.mark.parametrize("batch,inflight,tracer", [(2, 1, 0), (4, 2, 0), (5, 3, 1), (16, 1, 0), (32, 2, 0)])
+@pytest.mark.parametrize("batch,inflight,tracer", [(2, 1, 0), (4, 2, 0), (5, 3, 1), (8, 2, 0), (16, 1, 0), (24, 1, 1), (32, 2, 0)])
 def test_frames_per_launch_give_identical_frames(O, H, scenes, noise, batch, inflight, tracer):
     """frames_per_launch > 1: vxrt_render_frames traces up to B consecutive frames (camera at rest) with one launch of the
     tracer; temporal / denoise still run per frame.  Every image after every call must equal the unbatched pipeline's, which the

@@ -148,6 +148,9 @@ def test_full_size_bench_config_crops(O, H, scenes, noise):
 @pytest.mark.parametrize("env", [
     {"VXRT_TRACE_VARIANT": "0", "VXRT_TILE_ORDER": "0"},      # monolithic kernel, tiles in raster order
     {"VXRT_TRACE_VARIANT": "0", "VXRT_TILE_ORDER": "1"},      # ... longest-tile-first (default)
+    {"VXRT_SPREAD": "256"},                                   # ... with the tiles that walk spread over the whole launch, sky tiles in between
+    {"VXRT_SPREAD": "128", "VXRT_INFLIGHT": "2"},             # ... over half of it
+    {"VXRT_SPREAD": "0"},                                     # ... not at all
     {"VXRT_TRACE_VARIANT": "2", "VXRT_TRACE_SPLIT": "0x1"},   # wavefront: primary launch + one launch for all segments
     {"VXRT_TRACE_VARIANT": "2", "VXRT_TRACE_SPLIT": "0x5"},   # wavefront: queues compacted before segments 0 and 2
     {"VXRT_TRACE_VARIANT": "2", "VXRT_TRACE_SPLIT": "0xff", "VXRT_TRACE_BLOCKS": "64"},  # every segment its own launch; few waves loop over many chunks
@@ -500,3 +503,45 @@ def test_sun_power_shortcut_with_other_sun_sizes(O, H, scenes, noise, sun_size):
             for i, label in enumerate(("colour", "nd", "albedo")):
                 assert_bits_equal(ctx.read(i), ref[i], f"{label}, sun_size {sun_size}, cull {cull}")
             assert ctx.stats().rays == ref[3]
+
+
+@pytest.mark.parametrize("w,h,nranks,rank,batch,tracer", [(150, 70, 1, 0, 8, 0), (150, 70, 3, 1, 16, 0), (97, 41, 1, 0, 24, 1), (64, 48, 2, 1, 32, 4)])
+def test_frame_lanes_change_nothing(O, H, scenes, noise, w, h, nranks, rank, batch, tracer):
+    """VXRT_OPT_FRAME_LANES: a launch of 8 / 16 / 24 / 32 frames of one camera gives each wave of trace_kernel a row of 8 pixels in 8
+    frames instead of an 8 x 8 tile of one frame (csrc/trace.hip).  Frame sizes that are no multiples of 8, row bands, the all-in-one
+    kernel and the head + tail pair: every image of the launch's last frame equals the oracle's, the ray total of ALL its frames
+    equals the oracle's sum, and a launch that is no multiple of 8 frames (or moves the camera) falls back to one frame per wave."""
+    from gpu_voxel_raytracer_amd import TRACE, Camera, Context
+    pos, mrgb, size = scenes.load_scene("castle")
+    cam = scenes.close_camera(size)
+    octree = O.create_octree(pos, mrgb)
+    u = O.Uniforms.default()
+    u.set_camera(cam[0], O.camera_axis_scaled(cam[0], cam[1], cam[2], w, h))
+    bounces = 3
+    got = {}
+    for lanes in (1, 0):
+        with Context(w, h, max_bounces=bounces, noise=noise, tracer=tracer, frames_per_launch=batch, frames_in_flight=2, rank=rank, nranks=nranks,
+                     band_rows=8) as ctx:
+            ctx.recreate_octree(pos, mrgb)
+            ctx.camera = Camera(*cam)
+            ctx.set_option(H.OPT_FRAME_LANES, lanes)
+            ctx.render_frames(TRACE, batch)
+            st = ctx.stats()
+            assert st.frame_lane_launches == (1 if lanes else 0)
+            got[lanes] = [ctx.read(i) for i in range(3)] + [st.rays]
+            rows = ctx.local_rows()
+            if lanes:
+                ctx.render_frames(TRACE, batch + 3)           # a second launch of `batch` frames, then 3 frames: no frame lanes for those
+                assert ctx.stats().frame_lane_launches == 2
+                pose = np.stack([np.asarray(cam[0], np.float32)] * batch), np.stack([np.asarray(cam[1], np.float32)] * batch)
+                ctx.render_path(TRACE, pose[0], pose[1], cam[2])   # a camera path: one camera per frame, one frame per wave
+                assert ctx.stats().frame_lane_launches == 2
+    u.frame_number = batch
+    ref = O.trace(octree, noise, u, w, h, bounces, crop=(0, 0, w, h))
+    for i, label in enumerate(("colour", "nd", "albedo")):
+        assert_bits_equal(got[1][i], ref[i][rows], f"{label} with frame lanes")
+        assert_bits_equal(got[0][i], got[1][i], f"{label}: one frame per wave against frame lanes")
+    assert got[0][3] == got[1][3]
+    if nranks == 1:
+        assert got[1][3] == sum(O.trace(octree, noise, (setattr(u, "frame_number", f) or u), w, h, bounces, crop=(0, 0, w, h))[3]
+                                for f in range(1, batch + 1))
