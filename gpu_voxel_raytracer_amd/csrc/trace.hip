@@ -515,7 +515,9 @@ void trace_tile_dims(int* w, int* h) { *w = kTileW; *h = kTileH; }
 // 8 waves: 3.79 / 26.1 ms.  On a cache-resident scene the same change loses 3-5 %.
 hipError_t launch_trace(const TraceArgs& args, bool wide, bool hbm_scene, hipStream_t s) {
     TraceArgs a = args;
-    if (hbm_scene || wide || kTB != 64) a.frame_lanes = 0;   // those kernels exist with one frame per wave only
+    // those kernels exist with one frame per wave only (for a scene in HBM, config 5 at 16 spp, frame lanes measured 7 % slower: 14.9
+    // against 13.9 ms per displayed frame — a wave's 64 pixels are neighbours in the tree, its 8 frames of 8 pixels less so)
+    if (hbm_scene || wide || kTB != 64) a.frame_lanes = 0;
     // frame lanes: a tile's 8 rows x ceil(batch / 8) groups of 8 frames; otherwise one block per tile and frame
     const unsigned per_tile = a.frame_lanes ? 8u * ((unsigned(a.batch) + 7u) / 8u) : unsigned(a.batch);
     dim3 grid(trace_tile_count(a.band.width, a.band.local_rows) * per_tile);
