@@ -154,8 +154,8 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
     a.out_color = a.out[0].color; a.out_nd = a.out[0].nd; a.out_albedo = a.out[0].albedo;
     a.batch = int(g);
     a.gbuf_frames = gbuf_frames;
-    // a wave of trace_kernel holds 8 frames of a row of 8 pixels when the launch has whole groups of 8 frames of ONE camera
-    a.frame_lanes = (c->frame_lanes && path_pos == nullptr && g % 8u == 0u && !use_wide(c)) ? 1 : 0;
+    // a wave of trace_kernel holds 8 (4) frames of one (two) rows of 8 pixels when the launch has whole groups of 8 (4) frames of ONE camera
+    a.frame_lanes = (c->frame_lanes && path_pos == nullptr && !use_wide(c)) ? (g % 8u == 0u ? 8 : (g % 4u == 0u ? 4 : 0)) : 0;
     // Sky cull: the scene's box grown by a margin m that dwarfs every rounding error of the walk and of the test itself.  The walk
     // visits a cell only if the ray passes within ~2^-21 (|origin| + root_size) of it (its plane times are fl(fl(p - o) * inv): two
     // roundings of quantities no larger than that); m = 0.01 + 2^-16 (max |origin| + 2 root_size) is at least 32 times as much.

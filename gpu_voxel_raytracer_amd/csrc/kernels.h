@@ -111,7 +111,7 @@ struct TraceArgs {
     // min(depth, 7), grown by a margin far above the walk's rounding.  A regular primary ray that misses it provably makes the walk
     // return "miss" (no leaf is near it and fewer than 1536 of the 2048 trips are possible), so its pixel takes the miss outputs of
     // voxels.comp:373-388 / :292-294 without walking.  cull = 0: off (no box, odd camera, VXRT_OPT_SKY_CULL 0).
-    int frame_lanes;       // trace_kernel: a wave holds a row of 8 pixels in 8 frames (one camera for the whole launch) instead of an 8 x 8 tile of one
+    int frame_lanes;       // trace_kernel: 0, or the frames a wave holds: 8 (of a row of 8 pixels) or 4 (of two rows) — one camera for the launch, whole groups
     int cull;
     float cull_min[3], cull_max[3];
 };

@@ -89,15 +89,15 @@ constexpr int kTB = VXRT_TRACE_BLOCK;
 constexpr uint32_t kLightCost = 1u;   // cost-map entry of a tile none of whose pixels walked (any walking wave records its duration, >= 4)
 constexpr int kTileW = kTB == 64 ? 8 : 16, kTileH = kTB == 256 ? 16 : 8;
 
-// kFrameLanes: which 64 (pixel, frame) pairs share a wave.  false: an 8 x 8 pixel tile of ONE frame of the launch.  true (the frames
-// of the launch share one camera, 8 or 16 of them): one 8-pixel ROW of a tile in EIGHT consecutive frames, lane = frame * 8 + column —
+// kF: which 64 (pixel, frame) pairs share a wave.  1: an 8 x 8 pixel tile of ONE frame of the launch.  8 or 4 (the frames of the launch
+// share one camera and come in whole groups of kF): 8 / kF ROWS of a tile in kF consecutive frames, lane = (frame, row, column) —
 // a pixel's primary ray is the same in every frame and its first sun rays nearly so, so the lanes of a wave leave the walk's lock-step
 // rounds closer together (priced on the oracle's step counts, tests/sim_schedule.py: lane_mappings: - 12 % wave-instructions in this
-// kernel; measured + 7 % on the bench view); each frame's stores stay whole 128-byte row segments (4 x 2 pixels x 8 frames, 64-byte
-// segments, is priced 3 % better and measured 6 % worse).  The per-pixel operations are the same either way.
-template <bool kWide, int kWaves, bool kFrameLanes>
+// kernel for kF = 8, - 10 % for 4; measured + 7 % on the bench view); each frame's stores stay whole 128-byte row segments (4 x 2
+// pixels x 8 frames, 64-byte segments, is priced 3 % better and measured 6 % worse).  The per-pixel operations are the same either way.
+template <bool kWide, int kWaves, int kF>
 __global__ __launch_bounds__(kTB, kWaves) void trace_kernel(const TraceArgs a) {
-    static_assert(!kFrameLanes || kTB == 64, "frame lanes: one wave per block");
+    static_assert(kF == 1 || ((kF == 4 || kF == 8) && kTB == 64), "frame lanes: one wave per block");
     extern __shared__ uint4 lds_stack[];  // the threads' frames: Caster<kWide>
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -106,20 +106,15 @@ __global__ __launch_bounds__(kTB, kWaves) void trace_kernel(const TraceArgs a) {
     // geometry, and started last they would leave the chip idling behind a few long waves.
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     const unsigned tiles_x = unsigned(a.band.width + kTileW - 1) / unsigned(kTileW);
-    // a launch covers `batch` consecutive frames (same camera, frame numbers frame_number ..): the blocks of one tile
-    // position in all frames are neighbours in launch order, so longest-first holds across the whole batch
+    // a launch covers `batch` consecutive frames (same camera, frame numbers frame_number ..): the `batch` blocks of one tile
+    // position are neighbours in launch order, so longest-first holds across the whole batch.  block = (tile, part of the tile,
+    // group of kF frames): kF parts of 8 / kF rows, batch / kF groups
     const unsigned batch = unsigned(a.batch);
-    unsigned fb, ord, row_in_tile;
-    if (kFrameLanes) {   // block = (tile, row of the tile, group of 8 frames)
-        const unsigned groups = (batch + 7u) / 8u;
-        fb = (blockIdx.x % groups) * 8u + unsigned(lane >> 3);
-        row_in_tile = (blockIdx.x / groups) % 8u;
-        ord = blockIdx.x / (groups * 8u);
-    } else {
-        fb = blockIdx.x % batch;
-        row_in_tile = unsigned(lane >> 3);
-        ord = blockIdx.x / batch;
-    }
+    constexpr unsigned kRows = 8u / unsigned(kF);
+    const unsigned groups = batch / unsigned(kF);
+    const unsigned fb = (blockIdx.x % groups) * unsigned(kF) + unsigned(lane >> 3) / kRows;
+    const unsigned row_in_tile = ((blockIdx.x / groups) % unsigned(kF)) * kRows + unsigned(lane >> 3) % kRows;
+    const unsigned ord = blockIdx.x / batch;
     const bool gbuf = ((a.gbuf_frames >> fb) & 1u) != 0u;   // this frame's normal/depth and albedo/node images are wanted
     const unsigned tile = a.tile_order ? a.tile_order[ord] : ord;
     const int x = int(tile % tiles_x) * kTileW + (wave & 1) * 8 + (lane & 7);
@@ -127,12 +122,11 @@ __global__ __launch_bounds__(kTB, kWaves) void trace_kernel(const TraceArgs a) {
     const int lband = lrow / a.band.band_rows;
     const int y = (lband * a.band.nranks + a.band.rank) * a.band.band_rows + (lrow - lband * a.band.band_rows);
     const bool active = x < a.band.width && lrow < a.band.local_rows && y < a.band.height && fb < batch;
-    const unsigned cam_index = kFrameLanes ? 0u : fb;   // kFrameLanes: one camera for the launch (trace_frames checks)
+    const unsigned cam_index = kF > 1 ? 0u : fb;   // kF > 1: one camera for the launch (trace_frames checks)
 
     uint32_t rays = 0;
-    // the shard of the tail queue this wave appends to: the top bits of a multiplicative hash of the wave's index — the waves that
-    // append (tiles that see geometry) sit at regular distances in the launch order (16 blocks per tile, every k-th tile), and
-    // index % 64 then filled half or a quarter of the shards while the others stayed empty
+    // the shard of the tail queue this wave appends to: the top bits of a multiplicative hash of the wave's index, because the waves
+    // that append (tiles that see geometry) can sit at regular distances in the launch order (tile_scatter_kernel)
     static_assert(kShards == 64, "6 hash bits");
     const unsigned tail_shard = ((blockIdx.x * unsigned(kTB / 64) + unsigned(wave)) * 0x9E3779B1u) >> 26;
     if (a.tail.recs != nullptr) zero_counts(a.tail_zero, tid);
@@ -518,19 +512,19 @@ hipError_t launch_trace(const TraceArgs& args, bool wide, bool hbm_scene, hipStr
     // those kernels exist with one frame per wave only (for a scene in HBM, config 5 at 16 spp, frame lanes measured 7 % slower: 14.9
     // against 13.9 ms per displayed frame — a wave's 64 pixels are neighbours in the tree, its 8 frames of 8 pixels less so)
     if (hbm_scene || wide || kTB != 64) a.frame_lanes = 0;
-    // frame lanes: a tile's 8 rows x ceil(batch / 8) groups of 8 frames; otherwise one block per tile and frame
-    const unsigned per_tile = a.frame_lanes ? 8u * ((unsigned(a.batch) + 7u) / 8u) : unsigned(a.batch);
-    dim3 grid(trace_tile_count(a.band.width, a.band.local_rows) * per_tile);
+    dim3 grid(trace_tile_count(a.band.width, a.band.local_rows) * unsigned(a.batch));   // kF parts x batch / kF groups per tile
     const size_t lds = caster_lds_bytes(a, wide, kTB);
 #if VXRT_VARIANTS
     if (wide) {
-        hipLaunchKernelGGL((trace_kernel<true, VXRT_TRACE_WAVES, false>), grid, dim3(kTB), lds, s, a);
+        hipLaunchKernelGGL((trace_kernel<true, VXRT_TRACE_WAVES, 1>), grid, dim3(kTB), lds, s, a);
         return hipGetLastError();
     }
 #endif
-    if (hbm_scene) hipLaunchKernelGGL((trace_kernel<false, VXRT_TRACE_WAVES_HBM, false>), grid, dim3(kTB), lds, s, a);
-    else if (a.frame_lanes) hipLaunchKernelGGL((trace_kernel<false, VXRT_TRACE_WAVES, kTB == 64>), grid, dim3(kTB), lds, s, a);
-    else hipLaunchKernelGGL((trace_kernel<false, VXRT_TRACE_WAVES, false>), grid, dim3(kTB), lds, s, a);
+    constexpr int kF8 = kTB == 64 ? 8 : 1, kF4 = kTB == 64 ? 4 : 1;
+    if (hbm_scene) hipLaunchKernelGGL((trace_kernel<false, VXRT_TRACE_WAVES_HBM, 1>), grid, dim3(kTB), lds, s, a);
+    else if (a.frame_lanes == 8) hipLaunchKernelGGL((trace_kernel<false, VXRT_TRACE_WAVES, kF8>), grid, dim3(kTB), lds, s, a);
+    else if (a.frame_lanes == 4) hipLaunchKernelGGL((trace_kernel<false, VXRT_TRACE_WAVES, kF4>), grid, dim3(kTB), lds, s, a);
+    else hipLaunchKernelGGL((trace_kernel<false, VXRT_TRACE_WAVES, 1>), grid, dim3(kTB), lds, s, a);
     return hipGetLastError();
 }
 

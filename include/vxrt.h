@@ -190,10 +190,11 @@ typedef struct vxrt_stats {
  *   VXRT_OPT_SKY_CULL      1 (default): a pixel whose primary ray provably misses the scene — it misses, with a margin, the box of the
  *                          tree's occupied cells at level min(depth, 7) — gets voxels.comp's miss outputs without walking the octree
  *                          (same values: csrc/trace.hip, primary_miss_is_certain states the proof).  0: every primary ray walks.
- *   VXRT_OPT_FRAME_LANES   1 (default): a trace launch of 8, 16, 24 or 32 frames of one camera (vxrt_render_frames / vxrt_render_spp with
- *                          frames_per_launch a multiple of 8) gives each wave a row of 8 pixels in 8 consecutive frames instead of
- *                          an 8 x 8 tile of one frame — the same per-pixel operations, more coherent waves (a pixel's primary ray is the
- *                          same in every frame).  0: always one frame per wave.  vxrt_stats.frame_lane_launches counts the former.  */
+ *   VXRT_OPT_FRAME_LANES   1 (default): a trace launch of a multiple of 8 (of 4) frames of one camera (vxrt_render_frames / vxrt_render_spp
+ *                          with such a frames_per_launch) gives each wave one row (two rows) of 8 pixels in 8 (4) consecutive frames
+ *                          instead of an 8 x 8 tile of one frame — the same per-pixel operations, more coherent waves (a pixel's primary
+ *                          ray is the same in every frame).  0: always one frame per wave.  vxrt_stats.frame_lane_launches counts the
+ *                          former.  Not used for scenes beyond the Infinity Cache (measured slower there).                            */
 typedef enum vxrt_option { VXRT_OPT_DENOISE_MODE = 1, VXRT_OPT_TAIL_CAPACITY = 2, VXRT_OPT_SCENE_FORMAT = 3, VXRT_OPT_HALO_ROWS = 4,
                            VXRT_OPT_SKY_CULL = 5, VXRT_OPT_FRAME_LANES = 6 } vxrt_option;
 int vxrt_set_option(vxrt_ctx* ctx, vxrt_option option, uint32_t value);

@@ -505,10 +505,11 @@ def test_sun_power_shortcut_with_other_sun_sizes(O, H, scenes, noise, sun_size):
             assert ctx.stats().rays == ref[3]
 
 
-@pytest.mark.parametrize("w,h,nranks,rank,batch,tracer", [(150, 70, 1, 0, 8, 0), (150, 70, 3, 1, 16, 0), (97, 41, 1, 0, 24, 1), (64, 48, 2, 1, 32, 4)])
+@pytest.mark.parametrize("w,h,nranks,rank,batch,tracer", [(150, 70, 1, 0, 8, 0), (150, 70, 3, 1, 16, 0), (97, 41, 1, 0, 24, 1), (64, 48, 2, 1, 32, 4),
+                                                         (150, 70, 1, 0, 4, 0), (97, 41, 2, 0, 12, 0), (64, 48, 1, 0, 20, 1)])
 def test_frame_lanes_change_nothing(O, H, scenes, noise, w, h, nranks, rank, batch, tracer):
     """VXRT_OPT_FRAME_LANES: a launch of 8 / 16 / 24 / 32 frames of one camera gives each wave of trace_kernel a row of 8 pixels in 8
-    frames instead of an 8 x 8 tile of one frame (csrc/trace.hip).  Frame sizes that are no multiples of 8, row bands, the all-in-one
+    frames (of 4 / 12 / 20 / 28 frames: two rows in 4 frames) instead of an 8 x 8 tile of one frame (csrc/trace.hip).  Frame sizes that are no multiples of 8, row bands, the all-in-one
     kernel and the head + tail pair: every image of the launch's last frame equals the oracle's, the ray total of ALL its frames
     equals the oracle's sum, and a launch that is no multiple of 8 frames (or moves the camera) falls back to one frame per wave."""
     from gpu_voxel_raytracer_amd import TRACE, Camera, Context
