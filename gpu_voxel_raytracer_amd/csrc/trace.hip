@@ -359,18 +359,31 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(uint32_t* block_hist, un
         if (lane < blocks) block_hist[k * blocks + lane] = x - v;
         if (lane == 63u) total[k] = x;
     }
+    __shared__ unsigned long long all_cost;
+    __shared__ unsigned first_bin, half_total;
+    if (threadIdx.x == 0) { all_cost = 0ull; first_bin = kSortBins; }
+    __syncthreads();
+    if (threadIdx.x < kSortBins) {   // bins' bases (an exclusive scan over the 128 totals, 64 per wave), the summed cost, the first bin in use
+        const unsigned i = threadIdx.x, v = total[i];
+        unsigned x = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned y = __shfl_up(x, off, 64);
+            if (int(lane) >= off) x += y;
+        }
+        base[i] = x - v;
+        if (i == 63u) half_total = x;
+        if (v != 0u) {
+            atomicAdd(&all_cost, key_cost(kSortBins - 1u - i) * v);
+            atomicMin(&first_bin, i);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64u && threadIdx.x < kSortBins) base[threadIdx.x] += half_total;
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned sum = 0;
-        for (unsigned i = 0; i < kSortBins; i++) { base[i] = sum; sum += total[i]; }
         block_hist[kSortBins * kSortBlocks] = base[kSortBins - 1u - 3u];   // tiles with cost >= 4: somebody walked (bins are in descending cost)
-        unsigned long long all = 0, longest = 0;
-        for (unsigned i = 0; i < kSortBins; i++) {
-            const unsigned long long c = key_cost(kSortBins - 1u - i);
-            all += c * total[i];
-            if (longest == 0 && total[i] != 0u) longest = c;
-        }
-        const unsigned long long T = all * waves_x_launches / (wave_slots ? wave_slots : 1u);
+        const unsigned long long longest = first_bin < kSortBins ? key_cost(kSortBins - 1u - first_bin) : 0ull;
+        const unsigned long long T = all_cost * waves_x_launches / (wave_slots ? wave_slots : 1u);
         unsigned spread = T > 2u * longest ? unsigned((T - 2u * longest) * 256u / T) : 0u;
         if (spread_override >= 0) spread = unsigned(spread_override);
         block_hist[kSortBins * kSortBlocks + 1u] = spread;
