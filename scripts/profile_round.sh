@@ -6,7 +6,7 @@
 #   3. rocprofv3 --pmc SQ_* (one pass)            -> VALU instruction counts / lane utilisation per kernel
 #   4. rocprofv3 --kernel-trace --stats with ONE launch in flight (--inflight 1) -> each kernel's duration alone on the chip: the
 #      per-kernel roofline (algorithmic bytes of a launch / its average duration) can be recomputed from this CSV
-#   5. the PMC passes again at the DRIVER's schedule (--steps 20 --warmup 5: 7 + 7 + 6 frames on three streams)
+#   5. the PMC passes again at the DRIVER's schedule (--steps 20 --warmup 5: 8 + 8 + 4 frames on three streams)
 # Every rocprofv3 command has the program itself after "--" (no env / sh wrappers).
 tag=${1:-run}
 export TMPDIR=/tmp
