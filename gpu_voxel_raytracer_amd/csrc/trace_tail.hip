@@ -37,19 +37,7 @@ __global__ __launch_bounds__(kTailBlock, VXRT_BOUNCE_WAVES) void bounce_kernel(c
     const unsigned total_waves = gridDim.x * unsigned(kTailBlock / 64);
     uint32_t rays = 0;
 
-#ifndef VXRT_TAIL_DYNAMIC
-#define VXRT_TAIL_DYNAMIC 0
-#endif
-#if VXRT_TAIL_DYNAMIC
-    (void)total_waves;
-    for (;;) {   // chunks are handed out one at a time: a wave that drew short rays takes more of them
-        unsigned c = 0;
-        if (lane == 0) c = atomicAdd(in.counts + 1, 1u);
-        c = unsigned(__builtin_amdgcn_readfirstlane(int(c)));
-        if (c >= total_chunks) break;
-#else
     for (unsigned c = blockIdx.x * unsigned(kTailBlock / 64) + unsigned(wave); c < total_chunks; c += total_waves) {
-#endif
         const unsigned long long above = __ballot(incl > c);
         const int q = __ffsll((long long)above) - 1;                       // shard that holds chunk c
         const unsigned first = __shfl(incl - my_chunks, q, 64);           // chunks before shard q

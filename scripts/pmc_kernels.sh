@@ -10,7 +10,7 @@ python3 - <<PY
 import csv,glob,collections,re
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(glob.glob("gpurun_out/pk_$tag/*/*counter_collection.csv")[0])):
-    m=re.search(r"(primary_kernel|trace_kernel|bounce_kernel|path_kernel|shade_kernel<\w+>|trace_rays_kernel|pool_rays_kernel|pool_shade_kernel<\w+>)",r["Kernel_Name"])
+    m=re.search(r"(primary_kernel|trace_kernel|bounce_kernel|path_kernel|shade_kernel<\w+>|trace_rays_kernel|pool_rays_kernel|sun_kernel|resolve_kernel)",r["Kernel_Name"])
     if not m: continue
     agg[m[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,c in agg.items():
