@@ -314,7 +314,7 @@ def trace_bench(args):
             # what the profile shows: VALU issue, not bandwidth, limits this stage (the `valu` object below).  The HBM
             # figures stay because the path is nominally HBM-bound work (no contraction, no MFMA): achieved = algorithmic bytes of
             # the K steps / the block's wall time; frac follows from wall time and nothing else.
-            "bound": "valu", "nominal_bound": "hbm", "kernel": "trace_kernel + bounce_kernel (one trace stage)",
+            "bound": "hbm", "limited_by": "valu issue (see valu)", "kernel": "trace_kernel + bounce_kernel (one trace stage)",
             "achieved": round(wall, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(wall / HBM_PEAK_GBS, 5),
             "algorithmic_bytes_per_step": int(alg),
             "traffic": None, "traffic_source": None,
@@ -370,9 +370,12 @@ def trace_bench(args):
             out["timing"]["latency_ms_one_frame_at_a_time"] = round(measure_latency(Context, Camera, TRACE, pos, mrgb, cam, device, args.bounces), 4)
             extra = {}
             if args.view == "bench":
+                # blocks of 480 frames: the steady-state schedule, whatever --steps made of the headline's
+                view_inflight, view_batch = pick_schedule(world, 480)
                 extra["close_view"] = dict(measure_view(Context, Camera, TRACE, pos, mrgb, scenes.close_camera(size), device, args.bounces,
-                                                        args.inflight, args.batch),
-                                           workload=f"vox/{SCENE}.vox {WIDTH}x{HEIGHT}, {args.bounces} bounces, camera 'close' (geometry fills the frame)")
+                                                        view_inflight, view_batch),
+                                           workload=f"vox/{SCENE}.vox {WIDTH}x{HEIGHT}, {args.bounces} bounces, camera 'close' (geometry fills the frame); "
+                                                    f"{view_batch} frames per launch x {view_inflight} launches in flight")
             if default_cfg and not args.no_config5:
                 try:
                     c5cam = scenes.config5_cameras()["outside"]
@@ -491,7 +494,7 @@ def pipeline_bench(args):
                "stage_ms_per_frame": {"trace": round(st.trace_ms / args.steps, 4), "temporal": round(st.temporal_ms / args.steps, 4),
                                       "denoise": round(st.denoise_ms / args.steps, 4),
                                       "denoise_synchronous_pass": round(sync_st.denoise_ms / args.steps, 4)},
-               "roofline": {"bound": "valu", "nominal_bound": "hbm", "kernel": "whole frame loop", "achieved": round(alg * args.steps / elapsed / 1e9, 2),
+               "roofline": {"bound": "hbm", "limited_by": "valu issue", "kernel": "whole frame loop", "achieved": round(alg * args.steps / elapsed / 1e9, 2),
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5), "traffic": None}}
         print(json.dumps(out), flush=True)
     ctx.close()
