@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kTB, kWaves) void trace_kernel(const TraceArgs a) {
     const int lband = lrow / a.band.band_rows;
     const int y = (lband * a.band.nranks + a.band.rank) * a.band.band_rows + (lrow - lband * a.band.band_rows);
     const bool active = x < a.band.width && lrow < a.band.local_rows && y < a.band.height && fb < batch;
-    const unsigned cam_index = kF > 1 ? 0u : fb;   // kF > 1: one camera for the launch (trace_frames checks)
+    const unsigned cam_index = fb;   // per lane when kF > 1: the frames of a wave may have cameras of their own (vxrt_render_path)
 
     uint32_t rays = 0;
     // the shard of the tail queue this wave appends to: the top bits of a multiplicative hash of the wave's index, because the waves

@@ -191,7 +191,8 @@ typedef struct vxrt_stats {
  *                          tree's occupied cells at level min(depth, 7) — gets voxels.comp's miss outputs without walking the octree
  *                          (same values: csrc/trace.hip, primary_miss_is_certain states the proof).  0: every primary ray walks.
  *   VXRT_OPT_FRAME_LANES   1 (default): a trace launch of a multiple of 8 (of 4) frames of one camera (vxrt_render_frames / vxrt_render_spp
- *                          with such a frames_per_launch) gives each wave one row (two rows) of 8 pixels in 8 (4) consecutive frames
+ *                          with such a frames_per_launch), or of a camera path that moves the image by less than ~16 pixels across
+ *                          8 (4) frames (vxrt_render_path), gives each wave one row (two rows) of 8 pixels in 8 (4) consecutive frames
  *                          instead of an 8 x 8 tile of one frame — the same per-pixel operations, more coherent waves (a pixel's primary
  *                          ray is the same in every frame).  0: always one frame per wave.  vxrt_stats.frame_lane_launches counts the
  *                          former.  Not used for scenes beyond the Infinity Cache (measured slower there).                            */

@@ -378,7 +378,7 @@ def test_samples_per_pixel(O, H, scenes, noise, spp, batch, inflight):
             ctx.render_spp(ALL, 0)
 
 
-@pytest.mark.parametrize("batch,inflight", [(4, 2), (16, 1), (3, 3)])
+@pytest.mark.parametrize("batch,inflight", [(4, 2), (16, 1), (3, 3), (8, 2)])
 def test_camera_path_batched_equals_frame_by_frame(O, H, scenes, noise, batch, inflight):
     """vxrt_render_path: frames along a moving camera, several per trace launch (each through its own camera, temporal reprojecting
     from the previous frame's) == set_camera + render, frame by frame — which test_moving_camera_reprojection pins to the oracle."""
@@ -386,7 +386,7 @@ def test_camera_path_batched_equals_frame_by_frame(O, H, scenes, noise, batch, i
     w, h, bounces, radius = 144, 96, 4, 2
     pos, mrgb, size = scenes.load_scene("castle")
     p0, d0, fov = scenes.close_camera(size)
-    n = 11
+    n = 19   # launches of 8 (4) frames whose camera moves this little keep the frame lanes: every lane reads its own frame's camera
     path_p = np.stack([p0 + np.float32(0.05 * k) * np.array([1, 0.2, 0.3], np.float32) for k in range(n)]).astype(np.float32)
     path_d = np.stack([d0 + np.float32(0.01 * k) * np.array([0, 1, 0], np.float32) for k in range(n)]).astype(np.float32)
     with Context(w, h, max_bounces=bounces, noise=noise) as one, \
@@ -394,7 +394,7 @@ def test_camera_path_batched_equals_frame_by_frame(O, H, scenes, noise, batch, i
         for ctx in (one, many):
             ctx.recreate_octree(pos, mrgb)
             ctx.denoise_uniforms.radius = radius
-        for flags, lo, hi in ((ALL, 0, 5), (TRACE, 5, 7), (ALL, 7, n)):
+        for flags, lo, hi in ((ALL, 0, 8), (TRACE, 8, 10), (ALL, 10, n)):
             for k in range(lo, hi):
                 one.camera = Camera(path_p[k], path_d[k], fov)
                 one.render(flags)
@@ -402,6 +402,7 @@ def test_camera_path_batched_equals_frame_by_frame(O, H, scenes, noise, batch, i
             for img, label in zip(range(5), ("colour", "nd", "albedo", "accum", "denoised")):
                 assert_bits_equal(many.read(img), one.read(img), f"{label} after frames {lo}..{hi - 1}, batch {batch}")
             assert many.stats().rays == one.stats().rays
+        assert (many.stats().frame_lane_launches > 0) == (batch % 4 == 0)
         # and a frame at rest afterwards still reprojects from the path's last camera
         one.render(ALL)
         many.render(ALL)

@@ -511,7 +511,8 @@ def test_frame_lanes_change_nothing(O, H, scenes, noise, w, h, nranks, rank, bat
     """VXRT_OPT_FRAME_LANES: a launch of 8 / 16 / 24 / 32 frames of one camera gives each wave of trace_kernel a row of 8 pixels in 8
     frames (of 4 / 12 / 20 / 28 frames: two rows in 4 frames) instead of an 8 x 8 tile of one frame (csrc/trace.hip).  Frame sizes that are no multiples of 8, row bands, the all-in-one
     kernel and the head + tail pair: every image of the launch's last frame equals the oracle's, the ray total of ALL its frames
-    equals the oracle's sum, and a launch that is no multiple of 8 frames (or moves the camera) falls back to one frame per wave."""
+    equals the oracle's sum, and a launch that is no multiple of 4 frames (or whose camera sweeps across the scene) falls back to one
+    frame per wave; a camera path that barely moves keeps the frame lanes (each lane reads its frame's camera)."""
     from gpu_voxel_raytracer_amd import TRACE, Camera, Context
     pos, mrgb, size = scenes.load_scene("castle")
     cam = scenes.close_camera(size)
@@ -535,8 +536,12 @@ def test_frame_lanes_change_nothing(O, H, scenes, noise, w, h, nranks, rank, bat
                 ctx.render_frames(TRACE, batch + 3)           # a second launch of `batch` frames, then 3 frames: no frame lanes for those
                 assert ctx.stats().frame_lane_launches == 2
                 pose = np.stack([np.asarray(cam[0], np.float32)] * batch), np.stack([np.asarray(cam[1], np.float32)] * batch)
-                ctx.render_path(TRACE, pose[0], pose[1], cam[2])   # a camera path: one camera per frame, one frame per wave
-                assert ctx.stats().frame_lane_launches == 2
+                ctx.render_path(TRACE, pose[0], pose[1], cam[2])   # a camera path that barely moves: frame lanes, a camera per lane
+                assert ctx.stats().frame_lane_launches == 3
+                side = np.cross(np.asarray(cam[1], np.float32), np.array([0.0, 1.0, 0.0], np.float32)).astype(np.float32)
+                swing = np.stack([pose[1][k] if k % 2 == 0 else side for k in range(batch)])   # every other frame looks 90 degrees away
+                ctx.render_path(TRACE, pose[0], swing, cam[2])     # ... that sweeps across the scene: one frame per wave
+                assert ctx.stats().frame_lane_launches == 3
     u.frame_number = batch
     ref = O.trace(octree, noise, u, w, h, bounces, crop=(0, 0, w, h))
     for i, label in enumerate(("colour", "nd", "albedo")):
