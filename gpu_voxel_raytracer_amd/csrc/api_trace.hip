@@ -228,8 +228,8 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
                 a.tail = PathQueue{sq.hitq[0], sets[(J + 1) % 3], c->shard_capacity};
                 a.tail_zero = sets[(J + 2) % 3];
                 a.tail_from = c->tail_from;
-                HIP_TRY(launch_trace(a, use_wide(c) && c->trace_variant == 4, false, ts));
-                if (a.frame_lanes && !(use_wide(c) && c->trace_variant == 4)) c->frame_lane_launches++;
+                HIP_TRY(launch_trace(a, use_wide(c) && c->trace_variant == 4, scene_bytes > (size_t(256) << 20), ts));
+                if (a.frame_lanes && !(use_wide(c) && c->trace_variant == 4) && scene_bytes <= (size_t(256) << 20)) c->frame_lane_launches++;
                 sq.launches = J + 1;
                 if (!sq.counts_pending) {   // how much room this launch wanted (the set stays untouched until launch J + 2 clears it)
                     HIP_TRY(hipMemcpyAsync(sq.host_counts, sets[(J + 1) % 3], 64 * 64, hipMemcpyDeviceToHost, ts));
