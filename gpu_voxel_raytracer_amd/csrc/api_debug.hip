@@ -26,6 +26,25 @@ int vxrt_debug_tile_costs(vxrt_ctx* c, uint32_t* out, size_t n) try {
     return VXRT_OK;
 } VXRT_CATCH
 
+// Diagnostics: the launch order the last sort made (kernel tiles, 8x8 pixels), the costs it was made from, how many tiles walked and
+// how far they were spread.  order / cost: n = ceil(width/8) * ceil(local_rows/8) entries each (either may be null).
+int vxrt_debug_tile_order(vxrt_ctx* c, uint32_t* order, uint32_t* cost, size_t n, uint32_t* walking_tiles, uint32_t* spread_256) try {
+    if (!valid_ctx(c)) { set_error("null argument"); return VXRT_E_INVALID; }
+    const size_t tiles = trace_tile_count(c->band.width, c->band.local_rows);
+    if (n != tiles || c->schedules.empty()) { set_error("tile count mismatch"); return VXRT_E_INVALID; }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = sync_all(c)) return rc;
+    const vxrt_ctx::TileSchedule& t = c->schedules[size_t(c->last_schedule)];
+    if (!t.valid) { set_error("no tile order yet (it is made after a stream's first launch)"); return VXRT_E_INVALID; }
+    if (order) HIP_TRY(hipMemcpy(order, t.order, tiles * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (cost) HIP_TRY(hipMemcpy(cost, t.last_cost, tiles * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    uint32_t two[2] = {0, 0};
+    HIP_TRY(hipMemcpy(two, t.scratch + 128 * 64, sizeof two, hipMemcpyDeviceToHost));   // tile_scan_kernel: [bins * blocks] walking tiles, [+ 1] spread
+    if (walking_tiles) *walking_tiles = two[0];
+    if (spread_256) *spread_256 = two[1];
+    return VXRT_OK;
+} VXRT_CATCH
+
 // ---- blue noise (include/vxrt_bluenoise.h, csrc/noise.hip, csrc/noise_zip.cpp) ----------------------------------
 int vxrt_blue_noise(int32_t device, uint32_t seed, uint32_t size, uint32_t first_layer, uint32_t layers, float* out) try {
     if (!out || layers == 0) { set_error("null argument"); return VXRT_E_INVALID; }

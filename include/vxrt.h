@@ -373,6 +373,12 @@ int vxrt_debug_path_log(vxrt_ctx* ctx, int32_t x, int32_t y, float* log, int32_t
  * whose pixels walked the octree (sky, culled) reads 1; a tile that walked, its longest wave's duration (>= 4). */
 int vxrt_debug_tile_costs(vxrt_ctx* ctx, uint32_t* out, size_t n);
 
+/* Diagnostics: the launch order of the tracer's 8x8-pixel tiles as the last sort made it (order[k] = tile index, row-major over
+ * ceil(width/8) x ceil(local_rows/8)), the per-tile costs it was made from, the number of tiles that walked the octree and how far
+ * they were spread over the launch, in 1/256 (0 = plain longest-first; csrc/trace.hip: tile_scatter_kernel).  order and cost may
+ * be null; n = the tile count.  VXRT_E_INVALID before a stream's first sort. */
+int vxrt_debug_tile_order(vxrt_ctx* ctx, uint32_t* order, uint32_t* cost, size_t n, uint32_t* walking_tiles, uint32_t* spread_256);
+
 const char* vxrt_status_string(int status);
 const char* vxrt_last_error(void);               /* thread-local detail of the last failing call */
 uint32_t vxrt_abi_version(void);

@@ -551,3 +551,46 @@ def test_frame_lanes_change_nothing(O, H, scenes, noise, w, h, nranks, rank, bat
     if nranks == 1:
         assert got[1][3] == sum(O.trace(octree, noise, (setattr(u, "frame_number", f) or u), w, h, bounces, crop=(0, 0, w, h))[3]
                                 for f in range(1, batch + 1))
+
+
+def _tile_key(c):
+    """csrc/trace.hip: tile_key — the sort's bins: 4 * log2 of the cost with two mantissa bits."""
+    c = int(c)
+    if c < 4:
+        return c
+    e = c.bit_length() - 1
+    return ((e << 2) | ((c >> (e - 2)) & 3)) - 4
+
+
+@pytest.mark.parametrize("w,h,batch,inflight,frames", [(1920, 1080, 16, 2, 96), (256, 144, 1, 1, 3), (640, 360, 8, 3, 72)])
+def test_tile_order_is_a_permutation_that_spreads_the_walking_tiles(H, scenes, noise, w, h, batch, inflight, frames):
+    """The launch order of trace_kernel's tiles (csrc/trace.hip: tile_hist / tile_scan / tile_scatter_kernel, read back through
+    vxrt_debug_tile_order): every tile exactly once; the tiles that walked the octree in descending order of their cost bins; each
+    followed by k tiles of sky, k even, as far as the sort decided to spread them (a long launch against its chains) — not at all for
+    a small frame one launch at a time, whose order is plain longest-first."""
+    import ctypes as C
+    from gpu_voxel_raytracer_amd import TRACE, Camera, Context
+    pos, mrgb, size = scenes.load_scene("menger")
+    with Context(w, h, max_bounces=4, noise=noise, tracer=4, frames_per_launch=batch, frames_in_flight=inflight) as ctx:
+        ctx.recreate_octree(pos, mrgb)
+        ctx.camera = Camera(*scenes.bench_camera(size))
+        ctx.render_frames(TRACE, frames)
+        n = ((w + 7) // 8) * ((h + 7) // 8)
+        order, cost = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        walking, spread = C.c_uint32(0), C.c_uint32(0)
+        H._check(H.lib().vxrt_debug_tile_order(ctx._h, order.ctypes.data_as(C.c_void_p), cost.ctypes.data_as(C.c_void_p), C.c_size_t(n),
+                                               C.byref(walking), C.byref(spread)), "vxrt_debug_tile_order")
+    assert np.array_equal(np.sort(order), np.arange(n, dtype=np.uint32))            # a permutation
+    heavy = cost[order] >= 4                                                        # in launch order: did the tile walk?
+    nh, nl = int(heavy.sum()), int(n - heavy.sum())
+    assert walking.value == nh and 0 < nh < n and ((cost == 1) | (cost >= 4)).all()  # a tile of sky records 1 (no tile is left out: cost 0)
+    keys = np.array([_tile_key(c) for c in cost[order][heavy]])
+    assert (np.diff(keys) <= 0).all()                                               # the walking tiles: longest first
+    k = (nl * spread.value // 256 // nh) & ~1
+    at = np.flatnonzero(heavy)
+    if k == 0:
+        assert np.array_equal(at, np.arange(nh))
+    else:
+        assert np.array_equal(at, np.arange(nh) * (k + 1))
+    big = w * h * batch >= 1920 * 1080 * 16
+    assert (spread.value > 0) == big and (k > 0) == big, (spread.value, k)
