@@ -14,7 +14,7 @@ Timing: a timed BLOCK is exactly K steps, bracketed by a barrier + device synchr
 repeated back to back (>= 50 times and for >= 1 s of GPU time) and the MEDIAN block is reported, so that a short block
 (the driver's --steps 20 is 2.5 ms) is not at the mercy of one launch's jitter; `blocks` and the spread are in the line.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W]     N > 1 without a launcher: bench.py starts its N ranks itself (spawn_ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
   ... bench.py --pipeline   the whole frame loop instead (BASELINE configs[3]: castle 3840x2160, 4 spp, temporal + denoise
                             r = 8 with the RCCL halo exchange between ranks), halo bytes and exchange time reported apart.
@@ -203,7 +203,90 @@ def pick_schedule(world, steps, inflight=0, batch=0):
     return inflight, batch
 
 
-def init_dist():
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` (N > 1) started without a launcher (no WORLD_SIZE in the environment): start the N ranks as CHILD
+    processes of this one, one per GPU, with the rendezvous variables torch.distributed.run would set, relay rank 0's one JSON line
+    and exit with the children's status.  This parent makes no HIP / torch.cuda call (it does not even import torch) and never
+    replaces itself (no os.exec*); a rank that fails ends the job with a non-zero status — nothing is restarted."""
+    import signal
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=os.environ.get("MASTER_PORT") or str(free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs between processes on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    deadline = time.time() + float(os.environ.get("VXRT_BENCH_SPAWN_TIMEOUT", "1500"))
+    line, status, pending = None, 0, set(range(n))
+    import threading
+    out_lines = []
+    reader = threading.Thread(target=lambda: out_lines.extend(procs[0].stdout), daemon=True)
+    reader.start()
+    while pending:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is not None:
+                pending.discard(r)
+                if rc != 0 and status == 0:
+                    status = rc if rc > 0 else 128 - rc
+                    print(f"bench.py: rank {r} exited with status {rc}; stopping the other ranks", file=sys.stderr)
+        if status != 0 or time.time() > deadline:
+            if status == 0:
+                status = 124
+                print("bench.py: ranks did not finish in time; stopping them", file=sys.stderr)
+            for r in pending:                    # exactly the processes started above, by PID
+                procs[r].send_signal(signal.SIGTERM)
+            for r in pending:
+                try:
+                    procs[r].wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    for l in out_lines:
+        if l.startswith("{"):
+            line = l.strip()
+        else:
+            sys.stderr.write(l)
+    if status == 0 and line is None:
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        status = 1
+    if line is not None and status == 0:
+        print(line, flush=True)
+    sys.exit(status)
+
+
+def world_info(dist, torch, world, rank, device, backend):
+    """The `rccl` object of an N > 1 line: the backend the ranks talked over and which device every rank drove (all-gathered: index,
+    PCI bus id, name), so that N distinct GPUs can be seen in the line itself."""
+    if dist is None:
+        return None
+    p = torch.cuda.get_device_properties(device)
+    bus = "%04x:%02x:%02x" % tuple(int(getattr(p, k, -1)) & 0xffff for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    mine = {"rank": rank, "device": int(device), "pci": bus, "name": p.name, "host": os.uname().nodename, "pid": os.getpid()}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    ver = None
+    if backend == "nccl":
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            ver = None
+    return {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "rccl_version": ver, "world_size": world,
+            "distinct_devices": len({(e["host"], e["pci"], e["device"]) for e in everyone}), "devices": everyone}
+
+
+def init_dist(need_gpu=True):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -213,12 +296,30 @@ def init_dist():
         import torch
         import torch.distributed as dist
         device = local_rank % max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(device)
+        if need_gpu:
+            torch.cuda.set_device(device)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend)
     return world, rank, device, dist, torch, backend
+
+
+def dry_run(args):
+    """VXRT_BENCH_DRY=1: the ranks rendezvous, report the world they see and leave — no context, no kernel.  What the CPU suite uses
+    to test the launcher (tests/test_distributed_cpu.py); not a benchmark."""
+    world, rank, device, dist, torch, backend = init_dist(need_gpu=False)
+    info = None
+    if dist is not None:
+        everyone = [None] * world
+        dist.all_gather_object(everyone, {"rank": rank, "local_rank": device, "pid": os.getpid()})
+        info = {"backend": backend, "world_size": world, "devices": everyone}
+        if os.environ.get("VXRT_BENCH_DRY_FAIL_RANK") == str(rank):
+            sys.exit(3)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "dry run", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "rccl": info}), flush=True)
 
 
 def reduce_max(dist, torch, dev, values):
@@ -246,10 +347,7 @@ def block_count(est_block_s, asked):
 
 def trace_bench(args):
     world, rank, device, dist, torch, backend = init_dist()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world          # a launcher's WORLD_SIZE decides (main() starts the ranks itself when there is none)
     red_dev = "cuda" if backend == "nccl" else "cpu"
     args.inflight, args.batch = pick_schedule(world, args.steps, args.inflight, args.batch)
     from gpu_voxel_raytracer_amd import Camera, Context, TIMED, TRACE, scenes
@@ -298,6 +396,7 @@ def trace_bench(args):
         frames_timed += st.timed_frames
         local_px = st.pixels // max(args.steps, 1)
     scene_bytes = st.scene_bytes
+    rccl = world_info(dist, torch, world, rank, device, backend)
 
     if rank == 0:
         order = np.argsort(times)
@@ -365,6 +464,8 @@ def trace_bench(args):
                                "overlapping); latency_ms_one_frame_at_a_time is one vxrt_render(TRACE) per frame, each waited for"},
             "roofline": roof,
         }
+        if rccl is not None:
+            out["rccl"] = rccl
         if world == 1 and not args.no_extras:
             # secondary figures, measured in this run after the headline block (none of them is `value`)
             out["timing"]["latency_ms_one_frame_at_a_time"] = round(measure_latency(Context, Camera, TRACE, pos, mrgb, cam, device, args.bounces), 4)
@@ -472,6 +573,7 @@ def pipeline_bench(args):
     elapsed, _, rays, st = timed_block(True)
     sync_elapsed, x, _, sync_st = timed_block(False) if world > 1 else (elapsed, 0.0, rays, st)
     info = ctx.halo_info()
+    rccl = world_info(dist, torch, world, rank, device, backend)
     if rank == 0:
         px = w * h
         alg = (48 * spp + 16 * spp + 16 + 80 + 64) * px     # spp trace frames + their average + temporal + denoise
@@ -500,6 +602,8 @@ def pipeline_bench(args):
                                               "its own beside this frame's denoise, so they are longer than alone and do not add up to ms_per_step"},
                "roofline": {"bound": "hbm", "limited_by": "valu issue", "kernel": "whole frame loop", "achieved": round(alg * args.steps / elapsed / 1e9, 2),
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5), "traffic": None}}
+        if rccl is not None:
+            out["rccl"] = rccl
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist is not None:
@@ -529,6 +633,10 @@ def main():
                     help="consecutive frames per trace launch (vxrt_config.frames_per_launch; default: 16, 32 from 4 ranks on; a short block "
                          "is dealt to the launches in equal parts)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus, sys.argv[1:])      # does not return
+    if os.environ.get("VXRT_BENCH_DRY") == "1":
+        return dry_run(args)
     if args.pipeline:
         args.steps = args.steps or 24
         args.warmup = 4 if args.warmup < 0 else args.warmup

@@ -232,16 +232,53 @@ def exchange_halo(ctx, dist, rank, nranks, device, torch):
     HaloExchange(ctx, dist, rank, nranks, device, torch).exchange()
 
 
+OPT_HALO_ROWS = 4      # vxrt_option VXRT_OPT_HALO_ROWS (include/vxrt.h)
+
+
+def halo_rows_for_motion(cam_a, cam_b, width, height, near, band_rows, margin=2):
+    """Rows of the neighbours' history a rank must see so that temporal.comp's reprojection (shaders/temporal.comp:75-113) from the
+    frame of camera `cam_b` into the frame of camera `cam_a` stays inside what it has: the largest vertical image motion, in rows,
+    of a point at distance >= `near` along any pixel's ray, + `margin` (the bilinear footprint's second row and rounding), capped
+    at band_rows (then every row of the neighbours travels).  A camera is (origin, right, up, forward) as Camera.axis_scaled gives
+    them (pixel ray = x right - y up + forward, shaders/voxels.comp:299-303).  Along a pixel's ray the reprojected row is a
+    linear-fractional function of 1 / distance, so its extremes over [near, inf) are at the two ends; over the screen the motion is
+    evaluated on a 33 x 33 grid of pixels including the borders.  Every rank computes the same number from the same cameras — the
+    message sizes of an exchange must agree.  This is what the exchange AFTER frame a must carry for frame b, so a frame loop sets
+    it one frame ahead (a camera path), or from the last motion with a margin of its own (interactive)."""
+    oa, ra, ua, fa = (np.asarray(v, np.float64) for v in cam_a)
+    ob, rb, ub, fb = (np.asarray(v, np.float64) for v in cam_b)
+    try:
+        inv = np.linalg.inv(np.stack([ra, ua, fa], axis=1))
+    except np.linalg.LinAlgError:
+        return int(band_rows)
+    xs, ys = np.meshgrid(np.linspace(0, width - 1, 33), np.linspace(0, height - 1, 33))
+    d = xs[..., None] * rb - ys[..., None] * ub + fb
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    worst = 0.0
+    for dist in (float(near), 1e9):
+        s = (ob + dist * d - oa) @ inv.T
+        ok = s[..., 2] > 1e-12
+        if not ok.all():
+            return int(band_rows)              # a point behind the old camera: no bound
+        rows = np.abs(-(s[..., 1] / s[..., 2]) - ys)
+        worst = max(worst, float(rows.max()))
+    if not np.isfinite(worst):
+        return int(band_rows)
+    return int(min(band_rows, np.ceil(worst - 1e-6) + margin))
+
+
 def finish_frame(ctx, nranks, radius, halo, overlap=True, extra_flags=0):
     """What follows a frame's TRACE | TEMPORAL on a rank: the halo exchange and the denoise stage, overlapped.
-    radius 0: the denoise stage has no window (and may have been fused into the temporal pass already); the exchange still runs —
-    the next frame's temporal stage reads the neighbours' history rows.  extra_flags: e.g. TIMED."""
+    radius 0: the denoise stage has no window (render_frame fuses it into the temporal pass; a caller that comes here with the
+    stage still to do gets the pass-through between the two halves of the exchange); the exchange still runs — the next frame's
+    temporal stage reads the neighbours' history rows.  extra_flags: e.g. TIMED."""
     if nranks < 2:
         ctx.render_stage(DENOISE | extra_flags)
         return
     if radius == 0:
+        halo.start()
         ctx.render_stage(DENOISE | extra_flags)
-        halo.exchange()
+        halo.finish()
     elif overlap:
         halo.start()
         ctx.render_stage(DENOISE_INTERIOR | extra_flags)
@@ -252,12 +289,24 @@ def finish_frame(ctx, nranks, radius, halo, overlap=True, extra_flags=0):
         ctx.render_stage(DENOISE | extra_flags)
 
 
-def render_frame(ctx, dist, rank, nranks, device, torch, radius, halo=None, overlap=True):
+def render_frame(ctx, dist, rank, nranks, device, torch, radius, halo=None, overlap=True, halo_rows=None):
     """One frame of Context::render (src/context.rs:2004-2075) on a rank: trace -> temporal -> [halo] -> denoise.
-    halo: a HaloExchange to re-use across frames (one is made for the call otherwise)."""
-    ctx.render(TRACE | TEMPORAL)
+    halo: a HaloExchange to re-use across frames (one is made for the call otherwise).
+    halo_rows: VXRT_OPT_HALO_ROWS for THIS frame's exchange, i.e. what the NEXT frame's reprojection may reach
+    (halo_rows_for_motion(this frame's camera, the next frame's, ...)); None leaves the option as it is (default 1 row: a camera at
+    rest or drifting less than a row per frame)."""
     if nranks > 1 and halo is None:
         halo = HaloExchange(ctx, dist, rank, nranks, device, torch)
+    if nranks > 1 and halo_rows is not None:
+        ctx.set_option(OPT_HALO_ROWS, int(halo_rows))
+    if radius == 0:
+        # no window: the denoise stage is a per-pixel pass that the library fuses into the temporal kernel when both are asked for
+        # together (32 B/px read and 16 B/px written less than a pass of its own), and the exchange follows
+        ctx.render(TRACE | TEMPORAL | DENOISE)
+        if nranks > 1:
+            halo.exchange()
+        return
+    ctx.render(TRACE | TEMPORAL)
     finish_frame(ctx, nranks, radius, halo, overlap)
 
 

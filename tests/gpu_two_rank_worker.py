@@ -1,7 +1,9 @@
-"""Worker of tests/test_gpu_distributed.py (not collected by pytest): one of N ranks that SHARE this box's GPU, launched with
-torch.distributed.run over gloo.  Every rank renders its bands of each frame through gpu_voxel_raytracer_amd.distributed
-(trace + temporal -> halo exchange, staged through host memory because gloo carries CPU tensors -> denoise); rank 0 stitches
-the ranks' rows, renders the same frames in a single context and prints one JSON line with the comparison."""
+"""Worker of tests/test_gpu_distributed.py (not collected by pytest): one of N ranks launched with torch.distributed.run.
+VXRT_TEST_BACKEND = "gloo" (default): the ranks SHARE this box's GPU 0 and the halo is staged through host memory, because gloo
+carries CPU tensors.  "nccl": one GPU per rank (LOCAL_RANK), the halo travels GPU to GPU over RCCL — the path a node runs; needs
+as many GPUs as ranks.  Every rank renders its bands of each frame through gpu_voxel_raytracer_amd.distributed (trace + temporal
+-> halo exchange -> denoise); rank 0 stitches the ranks' rows, renders the same frames in a single context and prints one JSON
+line with the comparison."""
 import json
 import os
 import sys
@@ -17,10 +19,23 @@ def main():
     import torch.distributed as dist
     from gpu_voxel_raytracer_amd import ACCUM_COLOR, ALL, DENOISED, SAMPLED_COLOR, Camera, Context, distributed, scenes
     from gpu_voxel_raytracer_amd.host import OPT_HALO_ROWS
-    dist.init_process_group("gloo")
+    backend = os.environ.get("VXRT_TEST_BACKEND", "gloo")
+    if backend == "nccl":
+        dev = int(os.environ.get("LOCAL_RANK", "0"))
+        assert dev < torch.cuda.device_count(), "the nccl mode needs one GPU per rank"
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        comm, red = None, torch.device("cuda", dev)      # messages GPU to GPU; reductions on the device
+    else:
+        dev = 0
+        dist.init_process_group(backend)
+        comm, red = "cpu", "cpu"
+    gpu = torch.device("cuda", dev)
     rank, world = dist.get_rank(), dist.get_world_size()
     w, h, bounces, radius = 320, 200, 3, int(os.environ.get("VXRT_TEST_RADIUS", "3"))
-    band, halo_rows = int(os.environ.get("VXRT_TEST_BAND", "16")), int(os.environ.get("VXRT_TEST_HALO_ROWS", "1"))
+    band, halo_rows = int(os.environ.get("VXRT_TEST_BAND", "16")), os.environ.get("VXRT_TEST_HALO_ROWS", "1")
+    auto_rows = halo_rows == "auto"      # sized frame by frame from the camera path (distributed.halo_rows_for_motion)
+    halo_rows = 1 if auto_rows else int(halo_rows)
     pos, mrgb, size = scenes.load_scene("castle")
     p0, d0, fov = scenes.close_camera(size)
     layout = distributed.BandLayout(w, h, world, band, radius=radius)
@@ -31,21 +46,28 @@ def main():
              "fast": [(p0, d0), (p0, d0 + np.float32(0.12 * float(np.linalg.norm(d0))) * np.array([0, -1, 0], np.float32))]}   # ~0.12 rad: 17 rows
     out = {}
     for name, path in paths.items():
-        ctx = Context(w, h, device=0, max_bounces=bounces, rank=rank, nranks=world, band_rows=band)
+        ctx = Context(w, h, device=dev, max_bounces=bounces, rank=rank, nranks=world, band_rows=band)
         ctx.recreate_octree(pos, mrgb)
         ctx.denoise_uniforms.radius = radius
         ctx.set_option(OPT_HALO_ROWS, halo_rows)
-        halo = distributed.HaloExchange(ctx, dist, rank, world, torch.device("cuda", 0), torch, comm_device="cpu")
-        for cp, cd in path:
+        halo = distributed.HaloExchange(ctx, dist, rank, world, gpu, torch, comm_device=comm)
+        chosen = []
+        for k, (cp, cd) in enumerate(path):
             ctx.camera = Camera(cp, cd, fov)
-            distributed.render_frame(ctx, dist, rank, world, torch.device("cuda", 0), torch, radius, halo=halo)
-        imgs = {k: distributed.gather_image(ctx.read(i), layout, rank, dist, torch, "cpu")
+            rows = None
+            if auto_rows:       # this frame's exchange carries what the NEXT frame's reprojection can reach
+                nxt = path[min(k + 1, len(path) - 1)]
+                axes = [(c[0],) + Camera(c[0], c[1], fov).axis_scaled(w, h) for c in ((cp, cd), nxt)]
+                rows = distributed.halo_rows_for_motion(axes[0], axes[1], w, h, near=0.25, band_rows=band)
+                chosen.append(rows)
+            distributed.render_frame(ctx, dist, rank, world, gpu, torch, radius, halo=halo, halo_rows=rows)
+        imgs = {k: distributed.gather_image(ctx.read(i), layout, rank, dist, torch, red)
                 for k, i in (("sampled", SAMPLED_COLOR), ("accum", ACCUM_COLOR), ("denoised", DENOISED))}
-        rays = torch.tensor([ctx.stats().rays])
+        rays = torch.tensor([ctx.stats().rays], device=red)
         dist.all_reduce(rays)
         ctx.close()
         if rank == 0:
-            single = Context(w, h, device=0, max_bounces=bounces)
+            single = Context(w, h, device=dev, max_bounces=bounces)
             single.recreate_octree(pos, mrgb)
             single.denoise_uniforms.radius = radius
             for cp, cd in path:
@@ -63,9 +85,11 @@ def main():
             res["accum_differs_only_where_treated_as_disocclusion"] = bool(
                 (imgs["accum"][diff][:, :3] == imgs["sampled"][diff][:, :3]).all() and (imgs["accum"][diff][:, 3] == 0.5).all())
             res["geometry_pixels"] = int((single.read(1)[..., 3] >= 0).sum())
+            res["halo_rows_chosen"] = chosen
             single.close()
             out[name] = res
     if rank == 0:
+        out["backend"], out["world_size"] = backend, world
         print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()

@@ -198,3 +198,76 @@ def test_band_layout_row_rule_is_the_librarys():
         assert band % 16 == 0 and 48 <= band <= max(64, 8 * radius)
         most = max(len(D.BandLayout(w := 64, h, n, band).rows(r)) for r in range(n))
         assert all(most <= max(len(D.BandLayout(w, h, n, other).rows(r)) for r in range(n)) for other in range(48, max(64, 8 * radius) + 1, 16))
+
+
+def _bench(args, env):
+    import subprocess
+    import sys
+    envd = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=300, env={**envd, **env})
+
+
+def test_bench_launcher_starts_n_ranks_and_relays_one_line():
+    """`python bench.py --gpus N` without a launcher (the driver's command) starts N child ranks itself (bench.spawn_ranks) and relays
+    rank 0's line — rehearsed without a GPU: VXRT_BENCH_DRY=1 makes the ranks rendezvous over gloo, all-gather who they are and leave."""
+    import json
+    out = _bench(["--gpus", "3", "--steps", "20", "--warmup", "5"], {"VXRT_BENCH_DRY": "1", "VXRT_BENCH_BACKEND": "gloo"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and d["steps"] == 20 and d["warmup"] == 5
+    assert d["rccl"]["world_size"] == 3 and [e["rank"] for e in d["rccl"]["devices"]] == [0, 1, 2]
+    assert len({e["pid"] for e in d["rccl"]["devices"]}) == 3      # three processes, none of them the parent
+
+
+def test_bench_launcher_fails_when_a_rank_fails():
+    """A rank that exits non-zero ends the job with that status: no line, nothing restarted, the other ranks stopped."""
+    out = _bench(["--gpus", "2"], {"VXRT_BENCH_DRY": "1", "VXRT_BENCH_BACKEND": "gloo", "VXRT_BENCH_DRY_FAIL_RANK": "1"})
+    assert out.returncode == 3 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "rank 1 exited with status 3" in out.stderr
+
+
+def test_bench_parent_never_touches_the_gpu_or_execs():
+    """The launcher half of bench.py imports neither torch nor the library and never replaces the process."""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "spawn_ranks")
+    names = {n.names[0].name for n in ast.walk(fn) if isinstance(n, ast.Import)} | {n.module for n in ast.walk(fn) if isinstance(n, ast.ImportFrom)}
+    assert names <= {"signal", "subprocess", "threading"}, names
+    assert not [n for n in ast.walk(tree) if isinstance(n, ast.Attribute) and (n.attr.startswith(("execv", "execl", "spawn", "posix_spawn")))]
+    top = {n.names[0].name for n in tree.body if isinstance(n, ast.Import)} | {n.module for n in tree.body if isinstance(n, ast.ImportFrom)}
+    assert "torch" not in top and not any(m and m.startswith("gpu_voxel") for m in top)
+
+
+def test_halo_rows_for_motion_bounds_the_reprojection(H):
+    """distributed.halo_rows_for_motion against brute force: for cameras a -> b, every point at distance >= near on every pixel's ray
+    of frame b reprojects into frame a (temporal.comp:75-85) within the returned number of rows, less the margin, of its own row;
+    a camera at rest needs the margin only; a jump larger than a band is capped at the band height."""
+    from gpu_voxel_raytracer_amd import distributed as D
+    w, h, fov = 320, 200, H.Camera().fov
+    rng = np.random.default_rng(5)
+
+    def axes(p, d):
+        return (np.asarray(p, np.float32),) + H.Camera(p, d, fov).axis_scaled(w, h)
+    p0, d0 = np.array([3.0, 2.0, -7.0], np.float32), np.array([0.1, -0.2, 1.0], np.float32)
+    assert D.halo_rows_for_motion(axes(p0, d0), axes(p0, d0), w, h, 0.25, 64) == 2
+    cases = [(p0 + np.float32(0.01) * np.array([1, 0.5, 0], np.float32), d0), (p0, d0 + np.array([0, -0.12, 0], np.float32)),
+             (p0 + np.array([0, 0.3, 0.2], np.float32), d0 + np.array([0.05, 0.03, 0], np.float32))]
+    for p1, d1 in cases:
+        a, b = axes(p0, d0), axes(p1, d1)
+        rows = D.halo_rows_for_motion(a, b, w, h, 0.25, 10 ** 6)
+        oa, ra, ua, fa = (np.asarray(v, np.float64) for v in a)
+        ob, rb, ub, fb = (np.asarray(v, np.float64) for v in b)
+        inv = np.linalg.inv(np.stack([ra, ua, fa], 1))
+        xs, ys = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+        dirs = xs[..., None] * rb - ys[..., None] * ub + fb
+        dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+        worst = 0.0
+        for dist in np.concatenate([[0.25, 1e8], 0.25 + rng.exponential(5.0, 6)]):
+            s = (ob + dist * dirs - oa) @ inv.T
+            worst = max(worst, float(np.abs(-(s[..., 1] / s[..., 2]) - ys).max()))
+        assert worst <= rows - 2 + 0.51, (worst, rows)      # the 33 x 33 grid holds the borders, where the motion peaks
+        assert rows <= worst + 3
+        assert D.halo_rows_for_motion(a, b, w, h, 0.25, 16) == min(16, rows)

@@ -67,3 +67,101 @@ def test_pipeline_bench_two_ranks_on_one_gpu():
     assert hl["pack_ms"] > 0 and hl["unpack_ms"] > 0 and hl["exchange_ms_synchronous"] > 0 and d["value"] > 100.0
     s = d["stage_ms_per_frame"]
     assert s["trace"] > 0 and s["temporal"] > 0 and s["denoise"] > 0
+
+
+def run_bench(args, env=None, timeout=900):
+    """bench.py started the way the driver starts it: `python bench.py --gpus N ...`, no launcher around it."""
+    envd = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout,
+                         env={**envd, **(env or {})})
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def gpu_count():
+    import torch
+    return torch.cuda.device_count()       # counts devices without initialising the GPU in this process
+
+
+needs_two_gpus = pytest.mark.skipif(gpu_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2 --steps 20 --warmup 5` with no WORLD_SIZE in the environment — the driver's command — starts its two
+    ranks as child processes (bench.spawn_ranks), relays ONE line with n_gpus 2 and the world the ranks saw.  Over gloo here, the two
+    ranks sharing the one GPU; test_ranks_over_rccl_bench is the same command over RCCL on a box with two GPUs."""
+    d = run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--blocks", "5"], env={"VXRT_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "strong" and d["value"] > 1000.0
+    w = d["rccl"]
+    assert w["backend"] == "gloo" and w["world_size"] == 2 and [e["rank"] for e in w["devices"]] == [0, 1]
+    assert len({e["pid"] for e in w["devices"]}) == 2 and "x2" in d["config"]["parallelism"]
+
+
+def test_halo_messages_over_rccl_on_one_gpu():
+    """The RCCL branch of distributed.HaloExchange on this box's ONE GPU: a world of one rank whose context is rank 0 of 2, with both
+    neighbours mapped onto the rank itself.  What travels is wrong by construction (a rank receives its own rows), so the test is about
+    the transport and nothing else: batch_isend_irecv issued on the side stream, Work.wait() under torch.cuda.stream, and the tag-less
+    in-order matching of the two messages that go to the same peer when nranks == 2 (NCCL ignores tags): the message addressed to the
+    previous rank must land in the buffer for "from the next rank" and vice versa, bit for bit, several frames in a row, while the
+    context's own stream keeps rendering."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_rccl_self_worker.py")], capture_output=True, text=True, timeout=600,
+                         env={**os.environ, "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": free_port(), "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["backend"] == "nccl" and d["frames"] >= 3 and d["message_bytes"] > 100000
+    assert d["to_prev_arrived_as_from_next"] and d["to_next_arrived_as_from_prev"] and d["messages_differ"], d
+    assert d["exchanges"] == d["frames"], d
+
+
+@needs_two_gpus
+@pytest.mark.parametrize("nproc,radius", [(2, 3), (2, 0)])
+def test_ranks_over_rccl_stitch_to_the_single_context_frame(nproc, radius):
+    """test_ranks_in_processes_stitch_to_the_single_context_frame with one GPU per rank and the halo GPU to GPU over RCCL."""
+    if gpu_count() < nproc:
+        pytest.skip("fewer GPUs than ranks")
+    d = launch(nproc, [os.path.join(ROOT, "tests", "gpu_two_rank_worker.py")], env={"VXRT_TEST_RADIUS": str(radius), "VXRT_TEST_BACKEND": "nccl"})
+    assert d["backend"] == "nccl" and d["world_size"] == nproc
+    for name in ("rest", "slow"):
+        r = d[name]
+        assert r["rays_equal"] and r["geometry_pixels"] > 10000
+        assert r["sampled_differing_pixels"] == 0 and r["accum_differing_pixels"] == 0 and r["denoised_differing_pixels"] == 0, (name, r)
+    f = d["fast"]
+    assert f["rays_equal"] and f["sampled_differing_pixels"] == 0 and f["accum_differs_only_where_treated_as_disocclusion"], f
+
+
+@needs_two_gpus
+def test_ranks_over_rccl_history_halo_sized_for_the_motion():
+    d = launch(2, [os.path.join(ROOT, "tests", "gpu_two_rank_worker.py")],
+               env={"VXRT_TEST_RADIUS": "2", "VXRT_TEST_BAND": "32", "VXRT_TEST_HALO_ROWS": "32", "VXRT_TEST_BACKEND": "nccl"})
+    for name in ("rest", "slow", "fast"):
+        r = d[name]
+        assert r["rays_equal"] and r["sampled_differing_pixels"] == 0 and r["accum_differing_pixels"] == 0 and r["denoised_differing_pixels"] == 0, (name, r)
+
+
+@needs_two_gpus
+def test_ranks_over_rccl_bench():
+    """The driver's commands on two GPUs: the trace-stage bench and the frame loop with the halo over RCCL, each one line, each showing
+    two distinct devices."""
+    d = run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5"])
+    assert d["n_gpus"] == 2 and d["rccl"]["backend"].startswith("nccl") and d["rccl"]["distinct_devices"] == 2 and d["value"] > 10000.0
+    p = run_bench(["--gpus", "2", "--pipeline", "--steps", "4", "--warmup", "1"])
+    assert p["n_gpus"] == 2 and p["rccl"]["distinct_devices"] == 2 and "RCCL" in p["config"]["parallelism"]
+    assert p["halo"]["bytes_per_rank_per_frame"] > 0 and p["value"] > 100.0
+
+
+def test_halo_rows_sized_from_the_camera_path_keep_every_motion_exact():
+    """The frame loop sizes each exchange for the NEXT frame's reprojection (distributed.halo_rows_for_motion from the two cameras,
+    near plane 0.25): at rest the margin, a slow drift a few rows, the 17-row pan the whole 32-row band — and then two ranks equal the
+    single context bit for bit on every path, the fast pan included.  The motion bound up to which N ranks and one rank are bit-equal
+    is therefore band_rows - 2 rows of vertical image motion per frame (beyond it, rows of a band two bands away would be needed:
+    those reprojections are treated as disocclusions, the reference's rule for off-screen ones)."""
+    d = launch(2, [os.path.join(ROOT, "tests", "gpu_two_rank_worker.py")],
+               env={"VXRT_TEST_RADIUS": "2", "VXRT_TEST_BAND": "32", "VXRT_TEST_HALO_ROWS": "auto"})
+    for name in ("rest", "slow", "fast"):
+        r = d[name]
+        assert r["rays_equal"] and r["sampled_differing_pixels"] == 0 and r["accum_differing_pixels"] == 0 and r["denoised_differing_pixels"] == 0, (name, r)
+    assert d["rest"]["halo_rows_chosen"] == [2, 2, 2]
+    assert max(d["slow"]["halo_rows_chosen"]) <= 8
+    assert d["fast"]["halo_rows_chosen"][0] >= 19 and d["fast"]["halo_rows_chosen"][1] == 2
