@@ -224,9 +224,106 @@ float4* image_ptr(vxrt_ctx* c, vxrt_image which) {
 
 }  // namespace vxrt
 
+namespace vxrt {
+// One option, at vxrt_create_tuned (at_create: nothing is allocated yet) or later through vxrt_set_option.  The options that size
+// what vxrt_create allocates exist at creation only.
+int apply_option(vxrt_ctx* c, uint32_t option, uint32_t value, bool at_create) {
+    auto create_only = [&]() { if (!at_create) set_error("this option exists at vxrt_create_tuned only (it sizes what the context allocates)"); return at_create; };
+    auto needs_variants = [&](const char* what) {
+#if VXRT_VARIANTS
+        (void)what; return true;
+#else
+        set_error(what); return false;
+#endif
+    };
+    switch (option) {
+        case VXRT_OPT_DENOISE_MODE:
+            if (value > 3) { set_error("denoise mode must be 0 (exact) or 1 (tolerant), + 2 for the generic kernel"); return VXRT_E_INVALID; }
+            c->denoise_mode = int(value);
+            return VXRT_OK;
+        case VXRT_OPT_SCENE_FORMAT:
+            if (value > 1) { set_error("scene format must be 0 (8-byte records) or 1 (wide records)"); return VXRT_E_INVALID; }
+            if (value == 1 && !needs_variants("the wide scene records are not in this build of libvxrt (compile with -DVXRT_VARIANTS=1)")) return VXRT_E_INVALID;
+            if (value == 1 && c->has_scene && c->d_wide == nullptr) {
+                set_error("the wide records are built when a scene is set: choose the format before vxrt_set_voxels / vxrt_set_menger");
+                return VXRT_E_INVALID;
+            }
+            c->scene_format = int(value);
+            return VXRT_OK;
+        case VXRT_OPT_TAIL_CAPACITY:
+            if (at_create) { c->tail_capacity_override = int(value > 0x7fffffffu ? 0x7fffffffu : value); return VXRT_OK; }
+            if (c->trace_variant < 4) return VXRT_OK;   // the other tracers' queues are sized for the worst case
+            c->tail_capacity_override = int(value > 0x7fffffffu ? 0x7fffffffu : value);
+            return resize_tail_queues(c, value == 0 ? (c->shard_capacity_max / 8u < 4096u ? 4096u : c->shard_capacity_max / 8u) : value);
+        case VXRT_OPT_SKY_CULL:
+            if (value > 1) { set_error("sky cull must be 0 or 1"); return VXRT_E_INVALID; }
+            c->sky_cull = int(value);
+            return VXRT_OK;
+        case VXRT_OPT_FRAME_LANES:
+            if (value > 1) { set_error("frame lanes must be 0 or 1"); return VXRT_E_INVALID; }
+            c->frame_lanes = int(value);
+            return VXRT_OK;
+        case VXRT_OPT_HALO_ROWS:
+            if (value > 4096) { set_error("halo rows must be 0..4096"); return VXRT_E_INVALID; }
+            c->halo_min_rows = value;
+            return VXRT_OK;
+        case VXRT_OPT_TILE_ORDER:
+            if (value > 1) { set_error("tile order must be 0 (raster) or 1 (longest first)"); return VXRT_E_INVALID; }
+            c->use_tile_order = int(value);
+            return VXRT_OK;
+        case VXRT_OPT_TILE_SPREAD:      // 0..256: that many 256ths of the launch; VXRT_TILE_SPREAD_AUTO: the sort decides
+            if (value > 256 && value != VXRT_TILE_SPREAD_AUTO) { set_error("tile spread must be 0..256 or VXRT_TILE_SPREAD_AUTO"); return VXRT_E_INVALID; }
+            c->spread_override = value == VXRT_TILE_SPREAD_AUTO ? -1 : int(value);
+            return VXRT_OK;
+        case VXRT_OPT_TRACE_BLOCKS:
+            if (value < 1 || value > 65535) { set_error("trace blocks must be 1..65535"); return VXRT_E_INVALID; }
+            c->trace_blocks = int(value);
+            return VXRT_OK;
+        case VXRT_OPT_TAIL_FROM:        // sizes nothing, but a launch in flight must not see it change: creation only
+            if (!create_only()) return VXRT_E_INVALID;
+            c->tail_from = int(value > 64 ? 64 : value);
+            return VXRT_OK;
+        case VXRT_OPT_TAIL_SPLIT:
+            if (!create_only()) return VXRT_E_INVALID;
+            c->tail_split = value;
+            return VXRT_OK;
+        case VXRT_OPT_HOST_SCENE_BUILD:
+            if (value > 1) { set_error("host scene build must be 0 or 1"); return VXRT_E_INVALID; }
+            c->host_scene_build = int(value);
+            return VXRT_OK;
+        case VXRT_OPT_TRACER_OVERRIDE:  // the internal tracer number, past vxrt_config.tracer's auto rule (A/B runs of the variants)
+            if (!create_only()) return VXRT_E_INVALID;
+            if (value != 0 && value != 4 && !needs_variants("tracers 2, 3 and 5 are not in this build of libvxrt (compile with -DVXRT_VARIANTS=1: scripts/test_variants.sh)")) return VXRT_E_INVALID;
+            c->trace_variant = (value == 2 || value == 3 || value == 4 || value == 5) ? int(value) : 0;
+            if (c->trace_variant >= 4 && c->cfg.max_bounces < 2) c->trace_variant = 0;
+            c->auto_tracer = false;
+            return VXRT_OK;
+        case VXRT_OPT_TRACE_SPLIT:
+            if (!create_only()) return VXRT_E_INVALID;
+            c->trace_split = value;
+            return VXRT_OK;
+        case VXRT_OPT_PATH_BLOCKS:
+            if (!create_only()) return VXRT_E_INVALID;
+            c->path_blocks = int(value < 1 ? 1 : (value > 65535 ? 65535 : value));
+            return VXRT_OK;
+        case VXRT_OPT_SHADE_BLOCKS:
+            if (!create_only()) return VXRT_E_INVALID;
+            c->shade_blocks = int(value > 65535 ? 65535 : value);
+            return VXRT_OK;
+        case VXRT_OPT_RAYS_PER_WAVE:
+            if (!create_only()) return VXRT_E_INVALID;
+            c->rays_per_wave = value;
+            return VXRT_OK;
+        default:
+            set_error("unknown option");
+            return VXRT_E_INVALID;
+    }
+}
+}  // namespace vxrt
+
 extern "C" {
 
-uint32_t vxrt_abi_version(void) { return 4; }
+uint32_t vxrt_abi_version(void) { return 5; }
 uint32_t vxrt_build_features(void) { return VXRT_VARIANTS ? uint32_t(VXRT_FEATURE_VARIANTS) : 0u; }
 
 const char* vxrt_last_error(void) { return vxrt::last_error().c_str(); }
@@ -266,8 +363,10 @@ void vxrt_default_uniforms(vxrt_uniforms* u) {
 void vxrt_default_temporal(vxrt_temporal* t) { t->sample_blending = 0.5f; t->maximum_blending = 0.98f; t->blending_distance_cutoff = 1e-2f; }
 void vxrt_default_denoise(vxrt_denoise* d) { d->radius = 0; d->sigma_distance = 2.0f; d->sigma_range = 1.5f; d->albedo_factor = 1.0f; }
 
-int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) try {
-    if (!cfg || !out) { set_error("null argument"); return VXRT_E_INVALID; }
+int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) { return vxrt_create_tuned(cfg, nullptr, 0, out); }
+
+int vxrt_create_tuned(const vxrt_config* cfg, const vxrt_tuning* tuning, size_t ntuning, vxrt_ctx** out) try {
+    if (!cfg || !out || (ntuning != 0 && !tuning)) { set_error("null argument"); return VXRT_E_INVALID; }
     *out = nullptr;
     if (cfg->width == 0 || cfg->height == 0 || cfg->width > 65536 || cfg->height > 65536) { set_error("bad frame size"); return VXRT_E_INVALID; }
     if (cfg->max_bounces < 1 || cfg->max_bounces > 16) { set_error("max_bounces must be 1..16"); return VXRT_E_INVALID; }
@@ -296,20 +395,15 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) try {
     }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipStreamCreate"));
     if (hipEventCreateWithFlags(&c->halo_event, hipEventDisableTiming) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipEventCreate"));
-    if (const char* v = getenv("VXRT_SKY_CULL")) c->sky_cull = atoi(v) != 0;   // A/B and tests
-    if (const char* v = getenv("VXRT_HALO_ROWS")) c->halo_min_rows = uint32_t(atoi(v) < 0 ? 0 : atoi(v));
     c->inflight = cfg->frames_in_flight == 0 ? 1 : int(cfg->frames_in_flight);
-    if (const char* v = getenv("VXRT_INFLIGHT")) c->inflight = atoi(v);
     // vxrt_config.tracer: 0 auto, 1 monolithic, 2 wavefront, 3 ray queues, 4 monolithic head + compacted tail (internally
     // 0, 2, 3, 4).  Measured on MI355X with frames in flight (menger 1080p 4 bounces / monu10 4K 8 bounces, ms per frame):
     // tracer 1: 0.219 / 0.52-1.53, tracer 3: 0.275 / 0.82-1.10, tracer 4: 0.175 / 0.54-0.94 -> auto = 4 whenever a path
     // can have a second hit, with one more compaction at path segment 3 from 6 bounces on.
     if (cfg->tracer > 5) { set_error("tracer must be 0..5"); return fail(VXRT_E_INVALID); }
     c->trace_variant = cfg->tracer == 0 ? 4 : (cfg->tracer == 1 ? 0 : int(cfg->tracer));
-    c->auto_tracer = cfg->tracer == 0 && getenv("VXRT_TRACE_VARIANT") == nullptr;
+    c->auto_tracer = cfg->tracer == 0;
     c->tail_split = cfg->max_bounces >= 6 ? 0x8u : 0u;
-    if (const char* v = getenv("VXRT_TRACE_VARIANT")) c->trace_variant = atoi(v);  // A/B override for benchmarks and tests
-    if (c->trace_variant != 2 && c->trace_variant != 3 && c->trace_variant != 4 && c->trace_variant != 5) c->trace_variant = 0;
 #if !VXRT_VARIANTS
     if (c->trace_variant == 2 || c->trace_variant == 3 || c->trace_variant == 5) {
         set_error("tracers 2, 3 and 5 are not in this build of libvxrt (compile with -DVXRT_VARIANTS=1: scripts/test_variants.sh)");
@@ -317,27 +411,14 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) try {
     }
 #endif
     if (c->trace_variant >= 4 && cfg->max_bounces < 2) c->trace_variant = 0;  // no tail to compact
-    if (const char* v = getenv("VXRT_PATH_BLOCKS")) c->path_blocks = atoi(v);
-    if (const char* v = getenv("VXRT_TAIL_FROM")) c->tail_from = atoi(v);
+    // The library reads NO environment variable: what an experiment or a test wants different from the defaults arrives here, as
+    // (option, value) pairs (vxrt_create_tuned), or later through vxrt_set_option.
+    for (size_t i = 0; i < ntuning; i++)
+        if ((rc = apply_option(c, tuning[i].option, tuning[i].value, true)) != VXRT_OK) return fail(rc);
     if (c->tail_from < 0 || c->tail_from >= int(cfg->max_bounces)) c->tail_from = 1;
-    if (const char* v = getenv("VXRT_TAIL_SPLIT")) c->tail_split = unsigned(strtoul(v, nullptr, 0));
-    if (const char* v = getenv("VXRT_TAIL_CAPACITY")) c->tail_capacity_override = atoi(v);
-    if (const char* v = getenv("VXRT_WIDE")) c->scene_format = atoi(v) == 1 ? 1 : 0;   // A/B and tests: 1 = the wide records
-#if !VXRT_VARIANTS
-    if (c->scene_format == 1) {
-        set_error("the wide scene records are not in this build of libvxrt (compile with -DVXRT_VARIANTS=1)");
-        return fail(VXRT_E_INVALID);
-    }
-#endif
-    if (const char* v = getenv("VXRT_SHADE_BLOCKS")) c->shade_blocks = atoi(v);
-    if (const char* v = getenv("VXRT_RAYS_PER_WAVE")) c->rays_per_wave = unsigned(atoi(v));
     c->shade_blocks = (c->shade_blocks < 8 ? 8 : (c->shade_blocks > 2048 ? 2048 : c->shade_blocks) + 7) / 8 * 8;
-    if (const char* v = getenv("VXRT_TRACE_BLOCKS")) c->trace_blocks = atoi(v);
-    if (const char* v = getenv("VXRT_FRAME_LANES")) c->frame_lanes = atoi(v);
-    if (const char* v = getenv("VXRT_SPREAD")) c->spread_override = atoi(v);
     if (c->inflight < 1 || c->inflight > 16) { set_error("frames_in_flight must be 1..16"); return fail(VXRT_E_INVALID); }
     c->batch = cfg->frames_per_launch == 0 ? 1 : int(cfg->frames_per_launch);
-    if (const char* v = getenv("VXRT_BATCH")) c->batch = atoi(v);
     if (c->batch < 1 || c->batch > kMaxBatch) { set_error("frames_per_launch must be 1..32"); return fail(VXRT_E_INVALID); }
     c->trace_streams.assign(size_t(c->inflight), nullptr);
     if (c->inflight == 1) {
@@ -360,8 +441,6 @@ int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out) try {
     }
     if (hipMalloc(reinterpret_cast<void**>(&c->d_rays), kRaySlots * 64) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipMalloc counter"));
     if (hipMemsetAsync(c->d_rays, 0, kRaySlots * 64, c->stream) != hipSuccess) return fail(hip_fail(hipGetLastError(), "memset counter"));
-    if (const char* v = getenv("VXRT_TILE_ORDER")) c->use_tile_order = atoi(v);
-    if (const char* v = getenv("VXRT_TRACE_SPLIT")) c->trace_split = unsigned(strtoul(v, nullptr, 0));
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(hip_fail(hipGetLastError(), "sync"));
     *out = c;
     return VXRT_OK;
@@ -432,42 +511,7 @@ int vxrt_set_denoise(vxrt_ctx* c, const vxrt_denoise* d) try {
 int vxrt_set_option(vxrt_ctx* c, vxrt_option option, uint32_t value) try {
     if (!valid_ctx(c)) return VXRT_E_INVALID;
     HIP_TRY(hipSetDevice(c->cfg.device));
-    switch (option) {
-        case VXRT_OPT_DENOISE_MODE:
-            if (value > 3) { set_error("denoise mode must be 0 (exact) or 1 (tolerant), + 2 for the generic kernel"); return VXRT_E_INVALID; }
-            c->denoise_mode = int(value);
-            return VXRT_OK;
-        case VXRT_OPT_SCENE_FORMAT:
-            if (value > 1) { set_error("scene format must be 0 (8-byte records) or 1 (wide records)"); return VXRT_E_INVALID; }
-#if !VXRT_VARIANTS
-            if (value == 1) { set_error("the wide scene records are not in this build of libvxrt (compile with -DVXRT_VARIANTS=1)"); return VXRT_E_INVALID; }
-#endif
-            if (value == 1 && c->has_scene && c->d_wide == nullptr) {
-                set_error("the wide records are built when a scene is set: choose the format before vxrt_set_voxels / vxrt_set_menger");
-                return VXRT_E_INVALID;
-            }
-            c->scene_format = int(value);
-            return VXRT_OK;
-        case VXRT_OPT_TAIL_CAPACITY:
-            if (c->trace_variant < 4) return VXRT_OK;   // the other tracers' queues are sized for the worst case
-            c->tail_capacity_override = int(value > 0x7fffffffu ? 0x7fffffffu : value);
-            return resize_tail_queues(c, value == 0 ? (c->shard_capacity_max / 8u < 4096u ? 4096u : c->shard_capacity_max / 8u) : value);
-        case VXRT_OPT_SKY_CULL:
-            if (value > 1) { set_error("sky cull must be 0 or 1"); return VXRT_E_INVALID; }
-            c->sky_cull = int(value);
-            return VXRT_OK;
-        case VXRT_OPT_FRAME_LANES:
-            if (value > 1) { set_error("frame lanes must be 0 or 1"); return VXRT_E_INVALID; }
-            c->frame_lanes = int(value);
-            return VXRT_OK;
-        case VXRT_OPT_HALO_ROWS:
-            if (value > 4096) { set_error("halo rows must be 0..4096"); return VXRT_E_INVALID; }
-            c->halo_min_rows = value;
-            return VXRT_OK;
-        default:
-            set_error("unknown option");
-            return VXRT_E_INVALID;
-    }
+    return apply_option(c, option, value, false);
 } VXRT_CATCH
 
 int vxrt_reset_history(vxrt_ctx* c) try {

@@ -221,7 +221,7 @@ int vxrt_set_menger(vxrt_ctx* c, uint32_t level, uint32_t clip, const uint8_t mr
     uint32_t depth = 0;
     // On the device when the scene fits its dense sweep (side <= 2048: 1.15 GB of scratch) and only the 8-byte records are wanted:
     // the 2048^3 scene in a fraction of a second instead of ~9 s of host threads + a 5.6 GB upload.  VXRT_HOST_BUILD=1: the host builder.
-    if (menger_device_build_supported(level, clip) && c->scene_format != 1 && getenv("VXRT_HOST_BUILD") == nullptr) {
+    if (menger_device_build_supported(level, clip) && c->scene_format != 1 && c->host_scene_build == 0) {
         HIP_TRY(hipSetDevice(c->cfg.device));
         if (int rc = sync_all(c)) return rc;
         SvoRecord* svo = nullptr;

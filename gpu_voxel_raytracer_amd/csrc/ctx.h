@@ -182,7 +182,8 @@ struct vxrt_ctx {
     int last_schedule = 0;
     int use_tile_order = 1;
     int trace_blocks = 2048;
-    int spread_override = -1;     // VXRT_SPREAD (tests, experiments): see launch_tile_order
+    int spread_override = -1;     // VXRT_OPT_TILE_SPREAD (tests, experiments): see launch_tile_order
+    int host_scene_build = 0;     // VXRT_OPT_HOST_SCENE_BUILD: vxrt_set_menger builds on the host even where the device builder could
     unsigned wave_slots = 5120;   // waves of trace_kernel the device holds at once: CUs x 4 SIMDs x 5 (vxrt_create)
     int frame_lanes = 1;   // trace_kernel may put 8 frames of a pixel row into a wave (TraceArgs::frame_lanes; VXRT_OPT_FRAME_LANES)
     uint32_t frame_lane_launches = 0;
@@ -216,6 +217,7 @@ bool use_wide(const vxrt_ctx* c);
 bool scene_box(const SvoRecord* recs, size_t count, uint32_t depth, const float root_center[3], float root_size, float box_min[3], float box_max[3]);
 // ---- api_trace.hip
 int resize_tail_queues(vxrt_ctx* c, unsigned want);
+int apply_option(vxrt_ctx* c, uint32_t option, uint32_t value, bool at_create);   // api_context.hip
 int grow_tail_queues(vxrt_ctx* c, size_t lane);
 void update_bindings(vxrt_ctx* c);
 void frame_constants(const vxrt_ctx* c, TraceArgs& a);

@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(uint32_t* block_hist, un
         const unsigned long long T = all_cost * waves_x_launches / (wave_slots ? wave_slots : 1u);
         unsigned spread = T > 2u * longest ? unsigned((T - 2u * longest) * 256u / T) : 0u;
         if (spread_override >= 0) spread = unsigned(spread_override);
-        block_hist[kSortBins * kSortBlocks + 1u] = spread;
+        block_hist[kSortBins * kSortBlocks + 1u] = spread > 256u ? 256u : spread;     // spread_position needs <= 256 (k <= nl / nh)
     }
     __syncthreads();
     for (unsigned k = wave * 32u; k < wave * 32u + 32u; k++)

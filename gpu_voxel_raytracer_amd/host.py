@@ -110,6 +110,48 @@ class Stats(C.Structure):
 
 
 OPT_DENOISE_MODE, OPT_TAIL_CAPACITY, OPT_SCENE_FORMAT, OPT_HALO_ROWS, OPT_SKY_CULL, OPT_FRAME_LANES = 1, 2, 3, 4, 5, 6
+(OPT_TILE_ORDER, OPT_TILE_SPREAD, OPT_TRACE_BLOCKS, OPT_TAIL_FROM, OPT_TAIL_SPLIT, OPT_HOST_SCENE_BUILD, OPT_TRACER_OVERRIDE,
+ OPT_TRACE_SPLIT, OPT_PATH_BLOCKS, OPT_SHADE_BLOCKS, OPT_RAYS_PER_WAVE) = range(7, 18)
+TILE_SPREAD_AUTO = 0xffffffff
+
+
+class Tuning(C.Structure):
+    """vxrt_tuning: an (option, value) pair for vxrt_create_tuned."""
+    _fields_ = [("option", C.c_uint32), ("value", C.c_uint32)]
+
+
+# The library reads no environment variable.  The A/B scripts and the parity tests of the scheduling variants, which used to steer
+# it through VXRT_* variables, say what they want through Context(tuning=...) — or, to keep their command lines, switch this
+# translation on (enable_env_knobs(): tests/conftest.py; VXRT_ENV_KNOBS=1: scripts/*.sh): environment name -> create-time option.
+ENV_KNOBS = {"VXRT_SKY_CULL": OPT_SKY_CULL, "VXRT_HALO_ROWS": OPT_HALO_ROWS, "VXRT_TRACE_VARIANT": OPT_TRACER_OVERRIDE,
+             "VXRT_PATH_BLOCKS": OPT_PATH_BLOCKS, "VXRT_TAIL_FROM": OPT_TAIL_FROM, "VXRT_TAIL_SPLIT": OPT_TAIL_SPLIT,
+             "VXRT_TAIL_CAPACITY": OPT_TAIL_CAPACITY, "VXRT_WIDE": OPT_SCENE_FORMAT, "VXRT_SHADE_BLOCKS": OPT_SHADE_BLOCKS,
+             "VXRT_RAYS_PER_WAVE": OPT_RAYS_PER_WAVE, "VXRT_TRACE_BLOCKS": OPT_TRACE_BLOCKS, "VXRT_FRAME_LANES": OPT_FRAME_LANES,
+             "VXRT_SPREAD": OPT_TILE_SPREAD, "VXRT_TILE_ORDER": OPT_TILE_ORDER, "VXRT_TRACE_SPLIT": OPT_TRACE_SPLIT,
+             "VXRT_HOST_BUILD": OPT_HOST_SCENE_BUILD}
+_env_knobs_enabled = os.environ.get("VXRT_ENV_KNOBS") == "1"      # the explicit opt-in of the A/B scripts (scripts/*.sh)
+
+
+def enable_env_knobs(on=True):
+    """Tests and A/B scripts: let Context() translate the VXRT_* variables of ENV_KNOBS (and VXRT_INFLIGHT / VXRT_BATCH) into
+    vxrt_create_tuned options.  Off by default: a host process does not inherit behaviour from its environment."""
+    global _env_knobs_enabled
+    _env_knobs_enabled = bool(on)
+
+
+def tuning_from_env(environ=None):
+    """[(option, value)] for the VXRT_* variables set in `environ`."""
+    environ = os.environ if environ is None else environ
+    out = []
+    for name, opt in ENV_KNOBS.items():
+        v = environ.get(name)
+        if v is None or v == "":
+            continue
+        n = int(v, 0)
+        if opt == OPT_TILE_SPREAD and n < 0:
+            n = TILE_SPREAD_AUTO
+        out.append((opt, max(n, 0) & 0xffffffff))
+    return out
 
 
 class HaloInfo(C.Structure):
@@ -307,8 +349,15 @@ class Context:
     """
 
     def __init__(self, width, height, device=0, max_bounces=3, noise=None, noise_seed=DEFAULT_NOISE_SEED, rank=0,
-                 nranks=1, band_rows=16, frames_in_flight=1, tracer=0, frames_per_launch=1):
+                 nranks=1, band_rows=16, frames_in_flight=1, tracer=0, frames_per_launch=1, tuning=None):
+        """tuning: [(OPT_*, value)] applied by vxrt_create_tuned before anything is allocated (scheduling options for experiments
+        and tests; the image never depends on them)."""
         self._h = C.c_void_p()
+        tuning = list(tuning or [])
+        if _env_knobs_enabled:
+            tuning = tuning_from_env() + tuning
+            frames_in_flight = int(os.environ.get("VXRT_INFLIGHT", frames_in_flight))
+            frames_per_launch = int(os.environ.get("VXRT_BATCH", frames_per_launch))
         self.width, self.height = int(width), int(height)
         self.camera = Camera()
         cfg = Config(self.width, self.height, int(device), int(max_bounces), int(noise_seed), None, int(rank),
@@ -319,7 +368,8 @@ class Context:
             if keep.size != NOISE_LEN:
                 raise ValueError("noise table must hold 512*128*128 floats")
             cfg.noise = keep.ctypes.data
-        _check(lib().vxrt_create(C.byref(cfg), C.byref(self._h)), "vxrt_create")
+        pairs = (Tuning * max(len(tuning), 1))(*[Tuning(int(o), int(v)) for o, v in tuning])
+        _check(lib().vxrt_create_tuned(C.byref(cfg), pairs, C.c_size_t(len(tuning)), C.byref(self._h)), "vxrt_create_tuned")
         self.uniforms = Uniforms.default()
         self.temporal_uniforms = TemporalUniforms.default()
         self.denoise_uniforms = DenoiseUniforms.default()

@@ -195,14 +195,38 @@ typedef struct vxrt_stats {
  *                          8 (4) frames (vxrt_render_path), gives each wave one row (two rows) of 8 pixels in 8 (4) consecutive frames
  *                          instead of an 8 x 8 tile of one frame — the same per-pixel operations, more coherent waves (a pixel's primary
  *                          ray is the same in every frame).  0: always one frame per wave.  vxrt_stats.frame_lane_launches counts the
- *                          former.  Not used for scenes beyond the Infinity Cache (measured slower there).                            */
+ *                          former.  Not used for scenes beyond the Infinity Cache (measured slower there).
+ *
+ * Scheduling options for experiments and tests (same image whatever they say; the library reads NO environment variable — this is
+ * the only way in).  "create": accepted by vxrt_create_tuned only, because a launch in flight must not see them change or because
+ * they size what the context allocates.
+ *   VXRT_OPT_TILE_ORDER    1 (default): the tiles of a trace launch start longest first (csrc/trace.hip); 0: raster order.
+ *   VXRT_OPT_TILE_SPREAD   how far the tiles that walk are spread between the sky tiles of a launch: 0 .. 256 = that many 256ths of
+ *                          the launch, VXRT_TILE_SPREAD_AUTO (default) = decided on the device from the cost histogram.
+ *   VXRT_OPT_TRACE_BLOCKS  blocks of the compacted tail's launches (default 2048).
+ *   VXRT_OPT_TAIL_FROM     create: the hit at which a path moves from trace_kernel to the compacted tail (default 1 = the second hit).
+ *   VXRT_OPT_TAIL_SPLIT    create: bit k = the tail compacts once more at path segment k (default: 0x8 from 6 bounces on).
+ *   VXRT_OPT_HOST_SCENE_BUILD  1: vxrt_set_menger builds the scene on the host also where the device builder could (cross-check).
+ *   VXRT_OPT_TRACER_OVERRIDE   create: the internal schedule past vxrt_config.tracer's automatic choice: 0 all-in-one kernel, 4 head +
+ *                          compacted tail; 2 / 3 / 5 (-DVXRT_VARIANTS=1 builds) wavefront, ray queues, path kernel.
+ *   VXRT_OPT_TRACE_SPLIT / PATH_BLOCKS / SHADE_BLOCKS / RAYS_PER_WAVE   create: launch shapes of tracers 2, 3 and 5.                    */
 typedef enum vxrt_option { VXRT_OPT_DENOISE_MODE = 1, VXRT_OPT_TAIL_CAPACITY = 2, VXRT_OPT_SCENE_FORMAT = 3, VXRT_OPT_HALO_ROWS = 4,
-                           VXRT_OPT_SKY_CULL = 5, VXRT_OPT_FRAME_LANES = 6 } vxrt_option;
+                           VXRT_OPT_SKY_CULL = 5, VXRT_OPT_FRAME_LANES = 6, VXRT_OPT_TILE_ORDER = 7, VXRT_OPT_TILE_SPREAD = 8,
+                           VXRT_OPT_TRACE_BLOCKS = 9, VXRT_OPT_TAIL_FROM = 10, VXRT_OPT_TAIL_SPLIT = 11, VXRT_OPT_HOST_SCENE_BUILD = 12,
+                           VXRT_OPT_TRACER_OVERRIDE = 13, VXRT_OPT_TRACE_SPLIT = 14, VXRT_OPT_PATH_BLOCKS = 15, VXRT_OPT_SHADE_BLOCKS = 16,
+                           VXRT_OPT_RAYS_PER_WAVE = 17 } vxrt_option;
+#define VXRT_TILE_SPREAD_AUTO 0xffffffffu
 int vxrt_set_option(vxrt_ctx* ctx, vxrt_option option, uint32_t value);
+/* An (option, value) pair for vxrt_create_tuned. */
+typedef struct vxrt_tuning { uint32_t option; uint32_t value; } vxrt_tuning;
 
 /* ---- context: replaces Context::new / create_bindings / resize (src/context.rs:595-660, 936-1016,
  *      1430-1461).  resize drops the temporal history like the reference (:1440-1448). -------------- */
 int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out);
+/* vxrt_create with `count` options applied before anything is allocated (vxrt_create = none).  The reference has no counterpart: its
+ * tuning is compile-time constants in the shaders; this is where an A/B script or a test says what it wants instead of the process
+ * environment. */
+int vxrt_create_tuned(const vxrt_config* cfg, const vxrt_tuning* tuning, size_t count, vxrt_ctx** out);
 int vxrt_destroy(vxrt_ctx* ctx);
 int vxrt_resize(vxrt_ctx* ctx, uint32_t width, uint32_t height);
 

@@ -1,4 +1,5 @@
 #!/bin/bash
+export VXRT_ENV_KNOBS=1   # host.py translates the VXRT_* knobs below into vxrt_create_tuned options (the library reads no environment)
 # usage: scripts/ab_bench.sh "<label>:<env assignments>" ...   -- bench.py (no CPU baseline) once per arm, alternating twice
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 for rep in 1 2; do

@@ -1,5 +1,6 @@
 """Config-3 trace stage (monu10 4K, 8 bounces), throughput with 4 frames in flight, per tracer variant."""
 import sys, os, time
+os.environ.setdefault("VXRT_ENV_KNOBS", "1")   # host.py: translate the VXRT_* knobs into create-time options
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gpu_voxel_raytracer_amd import Context, Camera, TRACE, scenes
 W, H, B = 3840, 2160, 8

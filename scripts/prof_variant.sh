@@ -1,4 +1,5 @@
 #!/bin/bash
+export VXRT_ENV_KNOBS=1   # host.py translates the VXRT_* knobs below into vxrt_create_tuned options (the library reads no environment)
 # usage: scripts/prof_variant.sh <tag> [ENV=VAL ...] -- per-kernel average times (us) of bench.py --inflight 1 under rocprofv3
 tag=$1; shift
 export TMPDIR=/tmp

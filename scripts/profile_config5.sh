@@ -1,4 +1,5 @@
 #!/bin/bash
+export VXRT_ENV_KNOBS=1   # host.py translates the VXRT_* knobs below into vxrt_create_tuned options (the library reads no environment)
 # usage (GPU box, repo root): scripts/profile_config5.sh <tag>
 # BASELINE config 5's scene (2048^3 procedural Menger, 5.6 GB) at 3840x2160, 8 bounces, one frame at a time (scripts/exp_config5.py),
 # with the 8-byte scene records (VXRT_WIDE=0) and the wide ones (VXRT_WIDE=1): kernel durations, HBM fetch bytes, L2 hit rate and

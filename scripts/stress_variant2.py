@@ -1,5 +1,6 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("VXRT_ENV_KNOBS", "1")   # host.py: translate the VXRT_* knobs into create-time options
 os.environ.update(VXRT_TRACE_VARIANT="2", VXRT_TRACE_SPLIT="0xff", VXRT_TRACE_BLOCKS="64")
 import numpy as np
 from gpu_voxel_raytracer_amd import Context, Camera, TRACE, scenes

@@ -1,4 +1,5 @@
 #!/bin/bash
+export VXRT_ENV_KNOBS=1   # host.py translates the VXRT_* knobs below into vxrt_create_tuned options (the library reads no environment)
 # A/B of trace variants on the GPU box: VXRT_TRACE_VARIANT (0 monolithic, 2 wavefront), launch split mask, grid size.
 for view in bench close; do
   echo "== view $view"

@@ -1,4 +1,5 @@
 #!/bin/bash
+export VXRT_ENV_KNOBS=1   # host.py translates the VXRT_* knobs below into vxrt_create_tuned options (the library reads no environment)
 # rebuild libvxrt with different register budgets for the bounce kernel and bench each (GPU box)
 for w in 4 5 6 8; do
   VXRT_HIPCC_FLAGS="-DVXRT_BOUNCE_WAVES=$w" python gpu_voxel_raytracer_amd/_build.py -f > /dev/null 2>&1

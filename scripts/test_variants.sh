@@ -1,4 +1,5 @@
 #!/bin/bash
+export VXRT_ENV_KNOBS=1   # host.py translates the VXRT_* knobs below into vxrt_create_tuned options (the library reads no environment)
 # usage: scripts/test_variants.sh      (here: builds; on the GPU box: gpurun -- 'scripts/test_variants.sh run')
 # The compile-time variants of the walk that are NOT in the default library stay bit-exact: this builds each
 # of them as gpu_voxel_raytracer_amd/libvxrt_<tag>.so (hipcc cross-compiles without a GPU) and, with `run`, puts the trace, scene

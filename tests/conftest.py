@@ -14,6 +14,10 @@ REFERENCE = "/root/reference"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the parity tests of the scheduling variants name them by the VXRT_* variables the A/B scripts use; the library reads no
+    # environment, the host layer translates them into vxrt_create_tuned options when asked to (host.enable_env_knobs)
+    from gpu_voxel_raytracer_amd import host
+    host.enable_env_knobs()
 
 
 @pytest.fixture(scope="session")

@@ -20,7 +20,7 @@ def test_every_declared_symbol_is_exported(H):
     lib = H.lib()
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.vxrt_abi_version() == 4
+    assert lib.vxrt_abi_version() == 5
     assert lib.vxrt_status_string(-13) == b"unexpected end of file"
 
 
@@ -78,3 +78,27 @@ def test_cpp_header_compiles_and_links():
     assert os.path.exists(tool)
     out = subprocess.run([tool], capture_output=True, text=True)
     assert out.returncode == 2 and "usage:" in out.stderr
+
+
+def test_the_library_reads_no_environment():
+    """A host process must not inherit behaviour from its environment: the product library neither imports getenv nor holds the name of
+    a tuning variable (the A/B knobs arrive through vxrt_create_tuned / vxrt_set_option; host.py translates VXRT_* variables for the
+    tests and scripts that ask it to)."""
+    from gpu_voxel_raytracer_amd import _build
+    und = subprocess.run(["nm", "-D", "--undefined-only", _build.LIB], capture_output=True, text=True).stdout
+    assert "getenv" not in und
+    blob = open(_build.LIB, "rb").read()
+    from gpu_voxel_raytracer_amd import host
+    for name in list(host.ENV_KNOBS) + ["VXRT_INFLIGHT", "VXRT_BATCH"]:
+        assert name.encode() + b"\0" not in blob, name
+    for src in os.listdir(os.path.join(ROOT, "gpu_voxel_raytracer_amd", "csrc")):
+        if not src.endswith((".hip", ".h", ".cpp")):
+            continue
+        assert "getenv" not in open(os.path.join(ROOT, "gpu_voxel_raytracer_amd", "csrc", src), errors="replace").read(), src
+
+
+def test_create_tuned_validates_its_options(H):
+    lib = H.lib()
+    cfg = H.Config(64, 64, 0, 3, 1, None, 0, 1, 16, 1, 0, 1)
+    h = ctypes.c_void_p()
+    assert lib.vxrt_create_tuned(ctypes.byref(cfg), None, ctypes.c_size_t(2), ctypes.byref(h)) == H.E_INVALID
