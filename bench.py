@@ -47,7 +47,7 @@ WIDTH, HEIGHT, BOUNCES, SCENE = 1920, 1080, 4, "menger"
 # structure beats against the 128-row period).  (A denoise radius > 0 needs 16-row bands; the default benchmark is the trace stage.)
 BAND_ROWS = 8
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_DIRS = ("r03", "r02", "r01")   # newest first: where the rocprofv3 summaries of the default command are kept
+PROFILE_DIRS = ("r04", "r03", "r02", "r01")   # newest first: where the rocprofv3 summaries of the default command are kept
 
 
 def algorithmic_bytes(pixels, bounces, scene_bytes):
@@ -69,7 +69,65 @@ def recorded_profile():
     return None, None
 
 
-def cpu_baseline(pos, mrgb, cam, target_seconds=float(os.environ.get("VXRT_BENCH_CPU_SECONDS", "12"))):
+def recorded_json(name):
+    """profiles/rNN/<name>, newest round first -> (parsed, path) or (None, None).  RECORDED values: counters need profiler passes of
+    their own and are not measurements of this run (profiles/README.md says which script and schedule made each file)."""
+    for d in PROFILE_DIRS:
+        path = os.path.join(ROOT, "profiles", d, name)
+        try:
+            return json.load(open(path)), f"profiles/{d}/{name}"
+        except (OSError, ValueError):
+            continue
+    return None, None
+
+
+def measure_config3(Context, Camera, ALL, TIMED, scenes, device, shown=12):
+    """BASELINE configs[2] on this GPU, whole frame loop: vox/monu10.vox 3840x2160, 4 samples per pixel per displayed frame
+    (vxrt_render_spp), 8 bounces, temporal + denoise at radius 2 and radius 8 (exact mode, bit-identical to the oracle).  Per
+    displayed frame: wall ms, per-stage ms from HIP events (the stages overlap the next frame's trace launch, so they do not add up),
+    Gray/s, and the fraction of the HBM roofline the SURVEY 8d byte model amounts to: (48 + 16) spp + 16 + 80 + 64 B/px."""
+    w, h, spp, bounces = 3840, 2160, 4, 8
+    pos, mrgb, size = scenes.load_scene("monu10")
+    out = {"workload": f"vox/monu10.vox {w}x{h}, {spp} spp, {bounces} bounces, temporal + denoise (BASELINE configs[2]); bench camera; "
+                       f"{spp} frames per trace launch x 2 launches in flight; {shown} displayed frames after 3 of warm-up"}
+    post, post_path = recorded_json("post_stages_summary.json")
+    with Context(w, h, device=device, max_bounces=bounces, frames_in_flight=2, frames_per_launch=spp) as ctx:
+        ctx.recreate_octree(pos, mrgb)
+        ctx.camera = Camera(*scenes.bench_camera(size))
+        alg = ((48 + 16) * spp + 16 + 80 + 64) * w * h
+        for radius in (2, 8):
+            ctx.denoise_uniforms.radius = radius
+            for _ in range(3):
+                ctx.render_spp(ALL, spp)
+            ctx.sync()
+            ctx.reset_stats()
+            t0 = time.perf_counter()
+            for _ in range(shown):
+                ctx.render_spp(ALL | TIMED, spp)
+            ctx.sync()
+            dt = (time.perf_counter() - t0) / shown
+            st = ctx.stats()
+            r = {"ms_per_displayed_frame": round(dt * 1e3, 4), "gray_per_s": round(st.rays / shown / dt / 1e9, 2),
+                 "rays_per_pixel_per_sample": round(st.rays / shown / spp / (w * h), 4),
+                 "stage_ms": {"trace": round(st.trace_ms / shown, 4), "temporal": round(st.temporal_ms / shown, 4), "denoise": round(st.denoise_ms / shown, 4)},
+                 "roofline": {"bound": "hbm", "algorithmic_bytes_per_displayed_frame": alg, "achieved": round(alg / dt / 1e9, 1), "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": round(alg / dt / 1e9 / HBM_PEAK_GBS, 4)}}
+            if radius == 8 and post is not None:
+                try:    # VALU issue of denoise_pair_kernel: wave-instructions (RECORDED) x 2 cycles on 1024 SIMDs at 2.4 GHz / this run's stage time
+                    k = post["kernels"]["denoise r=8 exact"]
+                    issue_ms = k["sq_insts_valu_per_launch"] * 2 / (1024 * 2.4e9) * 1e3
+                    r["denoise_valu"] = {"kernel": "denoise_pair_kernel<exact, 8>", "valu_wave_instr_per_launch": int(k["sq_insts_valu_per_launch"]),
+                                         "lane_instr_per_tap": k["valu_lane_instr_per_tap"], "issue_ms": round(issue_ms, 3),
+                                         "issue_slot_frac": round(issue_ms / (st.denoise_ms / shown), 3),
+                                         "source": f"instruction count RECORDED in {post_path} (rocprofv3 --pmc SQ_INSTS_VALU pass of scripts/profile_post.sh), "
+                                                   f"divided by this run's HIP-event time of the stage"}
+                except (KeyError, ZeroDivisionError, TypeError):
+                    pass
+            out[f"radius_{radius}"] = r
+    return out
+
+
+def cpu_baseline(pos, mrgb, cam, target_seconds=float(os.environ.get("VXRT_BENCH_CPU_SECONDS", "8"))):
     """The CPU oracle (restatement of shaders/voxels.comp, oracle/oshaders.cpp) timed on this host's cores on
     whole frames of the same workload: a reported baseline, not the target."""
     from oracle import oracle as O
@@ -396,6 +454,8 @@ def trace_bench(args):
         frames_timed += st.timed_frames
         local_px = st.pixels // max(args.steps, 1)
     scene_bytes = st.scene_bytes
+    # primary rays the sky cull answers without a walk (counted in `rays`: each is one cast_bounded_ray of the shader), all ranks
+    culled = reduce_sum(dist, torch, red_dev, [ctx.culled_pixels()])[0]
     rccl = world_info(dist, torch, world, rank, device, backend)
 
     if rank == 0:
@@ -456,6 +516,7 @@ def trace_bench(args):
                        "parallelism": f"screen bands x{world} ({BAND_ROWS}-row interleave, scene replicated)",
                        "launches_in_flight": args.inflight, "frames_per_launch": args.batch,
                        "rays_per_frame": rays // args.steps, "rays_per_pixel": round(rays / args.steps / (WIDTH * HEIGHT), 4),
+                       "rays_walked_per_frame": rays // args.steps - culled, "primary_rays_answered_by_the_sky_cull_per_frame": culled,
                        "mpixels_per_s": round(WIDTH * HEIGHT * args.steps / elapsed / 1e6, 1)},
             "timing": {"blocks": blocks, "steps_per_block": args.steps, "reported": "median block",
                        "block_ms": {"min": round(min(times) * 1e3, 4), "median": round(elapsed * 1e3, 4), "max": round(max(times) * 1e3, 4)},
@@ -480,13 +541,39 @@ def trace_bench(args):
             if default_cfg and not args.no_config5:
                 try:
                     c5cam = scenes.config5_cameras()["outside"]
-                    extra["config5_outside_view"] = dict(
+                    c5 = dict(
                         measure_view(Context, Camera, TRACE, None, None, c5cam, device, 8, 1, 1, width=3840, height=2160, frames=24, blocks=5,
                                      setup=lambda ctx: ctx.set_menger(*scenes.CONFIG5)),
                         workload="BASELINE configs[4]'s scene (procedural Menger level 7 clipped to 2048^3, 5.6 GB: HBM-resident) at 3840x2160, "
                                  "8 bounces, one frame per launch, view from outside; one GPU's share is a band set of the 7680x4320 frame")
+                    # the one HBM-relevant config: what it writes (48 B/px) + what its scene gathers fetched from HBM (RECORDED counters)
+                    rec, rec_path = recorded_json("config5_formats_summary.json")
+                    try:
+                        o = rec["formats"]["8-byte records"]["outside"]
+                        fetch = float(o["fetch_size_kb"]) * 1024.0
+                        written = 48.0 * 3840 * 2160
+                        sec = c5["ms_per_frame"] * 1e-3
+                        c5["roofline"] = {"bound": "hbm", "kernel": "trace_kernel (all-in-one, 6 waves per SIMD)", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "bytes_written_per_frame": int(written), "bytes_fetched_per_frame_recorded": int(fetch),
+                                          "achieved_raw": round((written + fetch) / sec / 1e9, 1), "frac_raw": round((written + fetch) / sec / 1e9 / HBM_PEAK_GBS, 4),
+                                          "achieved_read_doubled": round((written + 2 * fetch) / sec / 1e9, 1),
+                                          "frac_read_doubled": round((written + 2 * fetch) / sec / 1e9 / HBM_PEAK_GBS, 4),
+                                          "fetch_over_written": round(fetch / written, 2), "l2_hit_rate_recorded": o.get("l2_hit_rate"),
+                                          "lane_utilisation_recorded": o.get("lane_utilisation"),
+                                          "source": f"FETCH_SIZE RECORDED in {rec_path} (rocprofv3 --pmc pass of scripts/profile_config5.sh, same scene, view "
+                                                    f"and frame size, {o.get('avg_ms')} ms per frame there) over this run's frame time; read-doubled = the "
+                                                    f"guide's gfx950 correction of the read side"}
+                    except (KeyError, TypeError, ValueError, ZeroDivisionError):
+                        pass
+                    extra["config5_outside_view"] = c5
                 except Exception as e:  # noqa: BLE001 — an extra must never cost the headline line
                     extra["config5_outside_view"] = {"error": repr(e)}
+            if default_cfg and not args.no_config3:
+                try:
+                    from gpu_voxel_raytracer_amd import ALL
+                    extra["config3_pipeline"] = measure_config3(Context, Camera, ALL, TIMED, scenes, device)
+                except Exception as e:  # noqa: BLE001
+                    extra["config3_pipeline"] = {"error": repr(e)}
             out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pos, mrgb, cam)
@@ -621,6 +708,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (latency, close view, config 5's scene)")
     ap.add_argument("--no-config5", action="store_true", help="skip the extra that builds the 5.6 GB procedural scene")
+    ap.add_argument("--no-config3", action="store_true", help="skip the extra that times BASELINE configs[2]'s frame loop at 4K")
     ap.add_argument("--pipeline", action="store_true", help="time the whole frame loop with the denoise halo exchange (BASELINE configs[3])")
     ap.add_argument("--radius", type=int, default=8, help="--pipeline: denoise radius")
     ap.add_argument("--band-rows", type=int, default=0, help="--pipeline: rows per band (default: >= 8 radius, a multiple of 16)")

@@ -141,7 +141,28 @@ def build_tool(force=False):
     return TOOL
 
 
+MULTI_TOOL = os.path.join(HERE, "vxrt_multi")
+MULTI_TOOL_SRC = os.path.join(os.path.dirname(HERE), "tools", "vxrt_multi.cpp")
+
+
+def build_multi_tool(force=False):
+    """The multi-GPU C++ host (tools/vxrt_multi.cpp): one thread per rank over include/vxrt.hpp, the halo over RCCL.  Host code only:
+    g++ against the HIP runtime API and librccl of /opt/rocm (-D__HIP_PLATFORM_AMD__ is what hip_runtime_api.h asks a host
+    compiler for)."""
+    build()
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    hdr = os.path.join(os.path.dirname(HERE), "include", "vxrt.hpp")
+    if not force and os.path.exists(MULTI_TOOL) and os.path.getmtime(MULTI_TOOL) >= max(os.path.getmtime(MULTI_TOOL_SRC), os.path.getmtime(LIB),
+                                                                                       os.path.getmtime(hdr)):
+        return MULTI_TOOL
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"),
+                           MULTI_TOOL_SRC, "-o", MULTI_TOOL, "-L" + HERE, "-lvxrt", "-L" + os.path.join(rocm, "lib"), "-lrccl", "-lamdhip64",
+                           "-pthread", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(rocm, "lib")])
+    return MULTI_TOOL
+
+
 if __name__ == "__main__":
     import sys
     build(force="-f" in sys.argv, verbose=True)
     build_tool(force="-f" in sys.argv)
+    build_multi_tool(force="-f" in sys.argv)

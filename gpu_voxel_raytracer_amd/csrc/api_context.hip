@@ -293,7 +293,7 @@ int apply_option(vxrt_ctx* c, uint32_t option, uint32_t value, bool at_create) {
             return VXRT_OK;
         case VXRT_OPT_TRACER_OVERRIDE:  // the internal tracer number, past vxrt_config.tracer's auto rule (A/B runs of the variants)
             if (!create_only()) return VXRT_E_INVALID;
-            if (value != 0 && value != 4 && !needs_variants("tracers 2, 3 and 5 are not in this build of libvxrt (compile with -DVXRT_VARIANTS=1: scripts/test_variants.sh)")) return VXRT_E_INVALID;
+            if ((value == 2 || value == 3 || value == 5) && !needs_variants("tracers 2, 3 and 5 are not in this build of libvxrt (compile with -DVXRT_VARIANTS=1: scripts/test_variants.sh)")) return VXRT_E_INVALID;
             c->trace_variant = (value == 2 || value == 3 || value == 4 || value == 5) ? int(value) : 0;
             if (c->trace_variant >= 4 && c->cfg.max_bounces < 2) c->trace_variant = 0;
             c->auto_tracer = false;

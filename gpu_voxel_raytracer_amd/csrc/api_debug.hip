@@ -153,6 +153,35 @@ int vxrt_debug_path_log(vxrt_ctx* c, int32_t x, int32_t y, float* log, int32_t* 
     return VXRT_OK;
 } VXRT_CATCH
 
+// Diagnostics: of this rank's pixels, how many primary rays of the NEXT frame (the camera as set) the sky cull decides without walking
+// the octree (0 with VXRT_OPT_SKY_CULL off).  Those rays are counted in vxrt_stats.rays — a ray is one cast_bounded_ray invocation
+// of the shader, and the cull is an implementation of it for rays that provably miss — so rays - frames x this = the rays that
+// walked.  Nothing is rendered and no context state changes.
+int vxrt_debug_culled_pixels(vxrt_ctx* c, uint64_t* count) try {
+    if (!valid_ctx(c) || !count) { set_error("null argument"); return VXRT_E_INVALID; }
+    if (!c->has_scene) { set_error("no scene set"); return VXRT_E_NOSCENE; }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = vxrt_sync(c)) return rc;
+    const Cam keep_cam = c->cam, keep_old = c->old_cam;
+    const vxrt_uniforms keep_u = c->uniforms;
+    update_bindings(c);
+    TraceArgs a{};
+    frame_constants(c, a);
+    a.cam = c->cam;
+    a.batch = 1;
+    set_cull(c, a, &a.cam, 1);
+    c->cam = keep_cam; c->old_cam = keep_old; c->uniforms = keep_u;
+    ScratchBuffer b;
+    HIP_TRY(b.alloc(sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(b.as<unsigned long long>(), 0, sizeof(unsigned long long), c->stream));
+    HIP_TRY(launch_count_culled(a, b.as<unsigned long long>(), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    unsigned long long n = 0;
+    HIP_TRY(hipMemcpy(&n, b.as<unsigned long long>(), sizeof n, hipMemcpyDeviceToHost));
+    *count = n;
+    return VXRT_OK;
+} VXRT_CATCH
+
 // device-vs-host bit equality probe of include/vxrt_detmath.h (test hook; host arrays in and out)
 int vxrt_detmath_probe(int32_t device, int32_t fn, const float* x, const float* y, float* out, size_t n) try {
     if (!x || !y || !out) { set_error("null argument"); return VXRT_E_INVALID; }

@@ -110,6 +110,28 @@ void frame_constants(const vxrt_ctx* c, TraceArgs& a) {
     a.sun_size = u.sun_size; a.sun_strength = u.sun_strength; a.emit_strength = u.emit_strength; a.specularity = u.specularity;
 }
 
+// Sky cull: the scene's box grown by a margin m that dwarfs every rounding error of the walk and of the test itself.  The walk
+// visits a cell only if the ray passes within ~2^-21 (|origin| + root_size) of it (its plane times are fl(fl(p - o) * inv): two
+// roundings of quantities no larger than that); m = 0.01 + 2^-16 (max |origin| + 2 root_size) is at least 32 times as much.
+void set_cull(const vxrt_ctx* c, TraceArgs& a, const Cam* cams, uint32_t g) {
+    a.cull = 0;
+    if (c->sky_cull && c->box_valid) {
+        float far = 0.0f;
+        bool sane = true;
+        for (uint32_t k = 0; k < g; k++)
+            for (int i = 0; i < 3; i++) {
+                const float v = fabsf(cams[k].o[i]);
+                sane = sane && v < 1e6f && std::isfinite(cams[k].r[i]) && std::isfinite(cams[k].u[i]) && std::isfinite(cams[k].f[i]);   // NaN fails v < 1e6
+                far = v > far ? v : far;
+            }
+        if (sane) {
+            const float m = 0.01f + ldexpf(far + 2.0f * c->root_size, -16);
+            for (int i = 0; i < 3; i++) { a.cull_min[i] = c->box_min[i] - m; a.cull_max[i] = c->box_max[i] + m; }
+            a.cull = 1;
+        }
+    }
+}
+
 // The trace stage of the next g frames (parameters at rest) as ONE launch of the tracer: g ring slots, frame numbers
 // frame_number+1 .. +g.  g > 1 only with the trace_kernel-based tracers (1, 4, 5).  slots[k] = ring slot of frame k.
 // path: optional g camera poses (position, direction), one per frame; null = the camera stays where it is.  cams / olds
@@ -179,25 +201,7 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
         }
         if (!(worst <= 16.0f)) a.frame_lanes = 0;
     }
-    // Sky cull: the scene's box grown by a margin m that dwarfs every rounding error of the walk and of the test itself.  The walk
-    // visits a cell only if the ray passes within ~2^-21 (|origin| + root_size) of it (its plane times are fl(fl(p - o) * inv): two
-    // roundings of quantities no larger than that); m = 0.01 + 2^-16 (max |origin| + 2 root_size) is at least 32 times as much.
-    a.cull = 0;
-    if (c->sky_cull && c->box_valid) {
-        float far = 0.0f;
-        bool sane = true;
-        for (uint32_t k = 0; k < g; k++)
-            for (int i = 0; i < 3; i++) {
-                const float v = fabsf(cams[k].o[i]);
-                sane = sane && v < 1e6f && std::isfinite(cams[k].r[i]) && std::isfinite(cams[k].u[i]) && std::isfinite(cams[k].f[i]);   // NaN fails v < 1e6
-                far = v > far ? v : far;
-            }
-        if (sane) {
-            const float m = 0.01f + ldexpf(far + 2.0f * c->root_size, -16);
-            for (int i = 0; i < 3; i++) { a.cull_min[i] = c->box_min[i] - m; a.cull_max[i] = c->box_max[i] + m; }
-            a.cull = 1;
-        }
-    }
+    set_cull(c, a, cams, g);
     a.ray_counter = c->d_rays;
     a.tile_order = (c->use_tile_order && sched.valid) ? sched.order : nullptr;
     a.tile_cost = c->use_tile_order ? sched.cost : nullptr;

@@ -218,6 +218,7 @@ bool scene_box(const SvoRecord* recs, size_t count, uint32_t depth, const float 
 // ---- api_trace.hip
 int resize_tail_queues(vxrt_ctx* c, unsigned want);
 int apply_option(vxrt_ctx* c, uint32_t option, uint32_t value, bool at_create);   // api_context.hip
+void set_cull(const vxrt_ctx* c, TraceArgs& a, const Cam* cams, uint32_t g);       // api_trace.hip
 int grow_tail_queues(vxrt_ctx* c, size_t lane);
 void update_bindings(vxrt_ctx* c);
 void frame_constants(const vxrt_ctx* c, TraceArgs& a);

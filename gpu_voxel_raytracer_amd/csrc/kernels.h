@@ -184,6 +184,7 @@ struct RayQueue {
 hipError_t launch_trace(const TraceArgs& a, bool wide, bool hbm_scene, hipStream_t s);
 // test hook: the walk (cast_ray) for caller-given rays; out = 8 floats per ray (hit, time, bits(leaf word), normal, 0, 0)
 hipError_t launch_path_log(const TraceArgs& a, bool wide, int x, int y, float* log, hipStream_t s);
+hipError_t launch_count_culled(const TraceArgs& a, unsigned long long* count, hipStream_t s);   // diagnostics: pixels the sky cull decides
 hipError_t launch_cast_probe(const TraceArgs& a, bool wide, const float* origins, const float* dirs, float* out, unsigned n, hipStream_t s);
 unsigned trace_tile_count(int width, int local_rows);  // blocks per frame of trace_kernel = entries of a tile schedule
 void trace_tile_dims(int* w, int* h);                  // pixels per block  // monolithic: one pixel per lane, all bounces

@@ -510,6 +510,28 @@ hipError_t launch_path_log(const TraceArgs& a, bool wide, int x, int y, float* l
     return hipGetLastError();
 }
 
+// Diagnostics (vxrt_debug_culled_pixels): how many of this rank's pixels the sky cull decides without a walk for the camera a.cam —
+// the same test on the same ray as trace_kernel's, one lane per pixel, one atomic per wave.
+__global__ __launch_bounds__(256) void count_culled_kernel(TraceArgs a, unsigned long long* count) {
+    const int x = int(blockIdx.x * 64u + (threadIdx.x & 63u)), lrow = int(blockIdx.y * 4u + (threadIdx.x >> 6));
+    bool culled = false;
+    if (x < a.band.width && lrow < a.band.local_rows) {
+        const int lband = lrow / a.band.band_rows;
+        const int y = (lband * a.band.nranks + a.band.rank) * a.band.band_rows + (lrow - lband * a.band.band_rows);
+        const f3 o = ld3(a.cam.o);
+        const f3 d = norm3((float(x) * ld3(a.cam.r) - float(y) * ld3(a.cam.u)) + ld3(a.cam.f));  // voxels.comp:299-303
+        culled = y < a.band.height && primary_miss_is_certain(a, o, d);
+    }
+    const unsigned long long m = __ballot(culled);
+    if ((threadIdx.x & 63u) == 0u && m != 0ull) atomicAdd(count, (unsigned long long)__popcll(m));
+}
+
+hipError_t launch_count_culled(const TraceArgs& a, unsigned long long* count, hipStream_t s) {
+    if (a.band.local_rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(count_culled_kernel, dim3(unsigned(a.band.width + 63) / 64u, unsigned(a.band.local_rows + 3) / 4u), dim3(256), 0, s, a, count);
+    return hipGetLastError();
+}
+
 // tiles (= blocks per frame) of trace_kernel: the unit of the longest-tile-first schedule
 unsigned trace_tile_count(int width, int local_rows) {
     return unsigned((width + kTileW - 1) / kTileW) * unsigned((local_rows + kTileH - 1) / kTileH);

@@ -498,6 +498,13 @@ class Context:
         """vxrt_render without re-pushing parameters (multi-GPU: DENOISE after the halo exchange)."""
         _check(lib().vxrt_render(self._h, C.c_uint32(flags)), "vxrt_render")
 
+    def culled_pixels(self):
+        """vxrt_debug_culled_pixels: primary rays of the next frame (camera as set) that the sky cull decides without a walk."""
+        n = C.c_uint64(0)
+        self.update_bindings()
+        _check(lib().vxrt_debug_culled_pixels(self._h, C.byref(n)), "vxrt_debug_culled_pixels")
+        return int(n.value)
+
     def set_option(self, option, value):
         """vxrt_set_option: OPT_DENOISE_MODE (0 exact, 1 tolerant), OPT_TAIL_CAPACITY (records per queue shard; 0 = automatic)."""
         _check(lib().vxrt_set_option(self._h, C.c_int(option), C.c_uint32(value)), "vxrt_set_option")

@@ -403,6 +403,11 @@ int vxrt_debug_tile_costs(vxrt_ctx* ctx, uint32_t* out, size_t n);
  * be null; n = the tile count.  VXRT_E_INVALID before a stream's first sort. */
 int vxrt_debug_tile_order(vxrt_ctx* ctx, uint32_t* order, uint32_t* cost, size_t n, uint32_t* walking_tiles, uint32_t* spread_256);
 
+/* Diagnostics: of this rank's pixels, how many primary rays of the next frame (camera as set) VXRT_OPT_SKY_CULL decides by its box
+ * test instead of walking the octree.  They are counted in vxrt_stats.rays (each is one cast_bounded_ray of voxels.comp:134-247,
+ * answered without a walk); for a camera at rest, rays per frame minus this = the rays that walked. */
+int vxrt_debug_culled_pixels(vxrt_ctx* ctx, uint64_t* count);
+
 const char* vxrt_status_string(int status);
 const char* vxrt_last_error(void);               /* thread-local detail of the last failing call */
 uint32_t vxrt_abi_version(void);

@@ -122,11 +122,11 @@ class Context {
     DenoiseUniforms denoise_uniforms;
 
     Context(uint32_t width, uint32_t height, uint32_t max_bounces = 3, int device = 0, uint32_t frames_in_flight = 1,
-            uint32_t rank = 0, uint32_t nranks = 1, uint32_t frames_per_launch = 1)
+            uint32_t rank = 0, uint32_t nranks = 1, uint32_t frames_per_launch = 1, uint32_t band_rows = 16)
         : width_(width), height_(height) {
         vxrt_config cfg{};
         cfg.width = width; cfg.height = height; cfg.device = device; cfg.max_bounces = max_bounces;
-        cfg.noise_seed = 0x5EED0001u; cfg.noise = nullptr; cfg.rank = rank; cfg.nranks = nranks; cfg.band_rows = 16;
+        cfg.noise_seed = 0x5EED0001u; cfg.noise = nullptr; cfg.rank = rank; cfg.nranks = nranks; cfg.band_rows = band_rows;
         cfg.frames_in_flight = frames_in_flight; cfg.tracer = 0; cfg.frames_per_launch = frames_per_launch;
         check(vxrt_create(&cfg, &ctx_), "vxrt_create");
     }

@@ -102,3 +102,19 @@ def test_create_tuned_validates_its_options(H):
     cfg = H.Config(64, 64, 0, 3, 1, None, 0, 1, 16, 1, 0, 1)
     h = ctypes.c_void_p()
     assert lib.vxrt_create_tuned(ctypes.byref(cfg), None, ctypes.c_size_t(2), ctypes.byref(h)) == H.E_INVALID
+
+
+def test_multi_gpu_cpp_host_compiles_and_links():
+    """tools/vxrt_multi.cpp — the RCCL host a Rust host would mirror: builds with g++ against libvxrt.so,
+    the HIP runtime API and librccl, and every halo entry point it needs is in the C ABI (no torch, no Python)."""
+    from gpu_voxel_raytracer_amd import _build
+    tool = _build.build_multi_tool(force=True)
+    assert os.path.exists(tool)
+    out = subprocess.run([tool], capture_output=True, text=True)
+    assert out.returncode == 2 and "usage:" in out.stderr and "--transport rccl|copy" in out.stderr
+    ldd = subprocess.run(["ldd", tool], capture_output=True, text=True).stdout
+    assert "librccl" in ldd and "libvxrt" in ldd and "torch" not in ldd and "python" not in ldd
+    und = subprocess.run(["nm", "-D", "--undefined-only", tool], capture_output=True, text=True).stdout
+    for sym in ("ncclCommInitAll", "ncclSend", "ncclRecv", "ncclGroupStart", "ncclGroupEnd", "vxrt_halo_pack", "vxrt_halo_unpack",
+                "vxrt_stream_wait_context", "vxrt_context_wait_stream"):
+        assert sym in und, sym

@@ -165,3 +165,47 @@ def test_halo_rows_sized_from_the_camera_path_keep_every_motion_exact():
     assert d["rest"]["halo_rows_chosen"] == [2, 2, 2]
     assert max(d["slow"]["halo_rows_chosen"]) <= 8
     assert d["fast"]["halo_rows_chosen"][0] >= 19 and d["fast"]["halo_rows_chosen"][1] == 2
+
+
+def run_multi(args, timeout=600):
+    from gpu_voxel_raytracer_amd import _build
+    tool = _build.build_multi_tool()
+    out = subprocess.run([tool] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    return out, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.parametrize("ranks,radius,spp,band", [(2, 8, 1, 64), (3, 3, 2, 48), (4, 0, 1, 16), (2, 2, 1, 16)])
+def test_cpp_multi_rank_host_stitches_the_single_context_frame(tmp_path, ranks, radius, spp, band):
+    """tools/vxrt_multi.cpp: the multi-rank frame loop in C++ over the C ABI, one host thread per rank — vxrt_render(TRACE | TEMPORAL),
+    vxrt_halo_pack, vxrt_stream_wait_context, the four transfers, DENOISE_INTERIOR, vxrt_context_wait_stream, vxrt_halo_unpack,
+    DENOISE_EDGE — here with its copy transport (hipMemcpyPeerAsync in place of ncclSend / ncclRecv: RCCL refuses two ranks on one
+    device), several ranks on this box's one GPU.  --check renders the same frames in one context: bit-identical, rays equal."""
+    out, d = run_multi(["menger:4", 512, 288, 4, 3, radius, tmp_path / "m.ppm", "--ranks", ranks, "--transport", "copy", "--band", band,
+                        "--spp", spp, "--check"])
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-500:]
+    assert d["ranks"] == ranks and d["transport"] == "copy" and d["checked"] and d["differing_values"] == 0 and d["rays_equal"]
+    assert d["halo_bytes_per_rank_per_frame"] > 0 and d["ms_per_frame"] > 0
+    assert os.path.getsize(tmp_path / "m.ppm") > 512 * 288 * 3
+
+
+def test_cpp_multi_rank_host_over_rccl_world_of_one(tmp_path):
+    """The same program over its RCCL transport with the one rank this box's GPU allows: ncclCommInitAll, a frame loop that sends
+    nothing, the frame equal to the single context's."""
+    out, d = run_multi(["menger:3", 256, 160, 3, 3, 2, tmp_path / "m.ppm", "--ranks", 1, "--transport", "rccl", "--check"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert d["transport"] == "rccl" and d["rccl_version"] > 0 and d["differing_values"] == 0 and d["rays_equal"]
+    bad, _ = run_multi(["menger:3", 64, 64, 1, 3, 0, tmp_path / "n.ppm", "--ranks", gpu_count() + 1, "--transport", "rccl"])
+    assert bad.returncode == 1 and "one device per rank" in bad.stderr
+
+
+@needs_two_gpus
+@pytest.mark.parametrize("radius,spp", [(8, 1), (0, 1), (3, 4)])
+def test_ranks_over_rccl_cpp_host(tmp_path, radius, spp):
+    """tools/vxrt_multi.cpp with ncclSend / ncclRecv between as many GPUs as the box has (at most 8): stitched frame bit-identical to
+    one context's."""
+    n = min(gpu_count(), 8)
+    out, d = run_multi(["menger:4", 1280, 720, 4, 4, radius, tmp_path / "m.ppm", "--ranks", n, "--transport", "rccl", "--spp", spp, "--check"])
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-500:]
+    assert d["ranks"] == n and d["transport"] == "rccl" and d["differing_values"] == 0 and d["rays_equal"]
+    assert len(set(d["devices"])) == n

@@ -295,6 +295,19 @@ def test_bench_contract_line():
     assert d["metric"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 48 and d["warmup"] == 8 and d["vs_baseline"] is None
     assert d["value"] > 1000.0 and abs(d["value"] * d["ms_per_step"] * 1e3 - d["config"]["rays_per_frame"]) < 0.01 * d["config"]["rays_per_frame"]
     assert "menger" in d["config"]["workload"] and "model" not in d["config"]
+    cfg = d["config"]      # the rays that walked the octree beside the rays counted (the sky cull answers the rest of the primary rays)
+    assert cfg["rays_walked_per_frame"] + cfg["primary_rays_answered_by_the_sky_cull_per_frame"] == cfg["rays_per_frame"]
+    assert 0 < cfg["primary_rays_answered_by_the_sky_cull_per_frame"] < 1920 * 1080 and cfg["rays_walked_per_frame"] > 1000000
+    c3 = d["extra"]["config3_pipeline"]          # BASELINE configs[2]: the whole frame loop at 4K, radius 2 and 8
+    for key in ("radius_2", "radius_8"):
+        e = c3[key]
+        assert e["ms_per_displayed_frame"] > 0 and e["gray_per_s"] > 1 and e["stage_ms"]["trace"] > 0 and e["stage_ms"]["denoise"] > 0
+        assert abs(e["roofline"]["frac"] - e["roofline"]["achieved"] / 8000.0) < 1e-3
+        assert e["roofline"]["algorithmic_bytes_per_displayed_frame"] == ((48 + 16) * 4 + 16 + 80 + 64) * 3840 * 2160
+    assert c3["radius_8"]["ms_per_displayed_frame"] > c3["radius_2"]["ms_per_displayed_frame"]
+    assert 0.3 < c3["radius_8"]["denoise_valu"]["issue_slot_frac"] < 1.0 and "RECORDED" in c3["radius_8"]["denoise_valu"]["source"]
+    c5 = d["extra"]["config5_outside_view"]["roofline"]
+    assert c5["bound"] == "hbm" and c5["frac_raw"] < c5["frac_read_doubled"] < 1.0 and "RECORDED" in c5["source"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and "valu" in r["limited_by"] and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
