@@ -291,6 +291,10 @@ int apply_option(vxrt_ctx* c, uint32_t option, uint32_t value, bool at_create) {
             if (value > 1) { set_error("host scene build must be 0 or 1"); return VXRT_E_INVALID; }
             c->host_scene_build = int(value);
             return VXRT_OK;
+        case VXRT_OPT_NODE_ORDER:       // read when a scene is set
+            if (value > 1) { set_error("node order must be 0 (breadth-first) or 1 (treelets at the bottom)"); return VXRT_E_INVALID; }
+            c->node_order = int(value);
+            return VXRT_OK;
         case VXRT_OPT_TRACER_OVERRIDE:  // the internal tracer number, past vxrt_config.tracer's auto rule (A/B runs of the variants)
             if (!create_only()) return VXRT_E_INVALID;
             if ((value == 2 || value == 3 || value == 5) && !needs_variants("tracers 2, 3 and 5 are not in this build of libvxrt (compile with -DVXRT_VARIANTS=1: scripts/test_variants.sh)")) return VXRT_E_INVALID;
@@ -594,6 +598,7 @@ int vxrt_get_stats(vxrt_ctx* c, vxrt_stats* out) try {
     out->noise_bytes = kNoiseCount * sizeof(float);
     out->local_rows = uint32_t(c->band.local_rows);
     out->octree_depth = c->depth;
+    out->node_order = uint32_t(c->node_order_applied);
     out->octree_nodes = c->svo_count;
     for (size_t lane = 0; lane < c->queues.size(); lane++)   // fold in what the last launches wanted (the GPU is idle here)
         if (c->trace_variant >= 4) { if (int rc = grow_tail_queues(c, lane)) return rc; }

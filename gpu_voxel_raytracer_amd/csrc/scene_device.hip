@@ -171,6 +171,48 @@ __global__ __launch_bounds__(kScanBlock) void emit_level_kernel(const uint32_t* 
     }
 }
 
+// ---- node order (VXRT_OPT_NODE_ORDER 1): depth-first TREELETS at the bottom of the tree -------------------------------------------
+// The builders emit the records breadth-first: level after level, each level in the order of its parents (a Morton order), the
+// children of a node contiguous.  A descent through the last three node levels then reads three far-apart arrays.  Node indices
+// never reach an output and the walk only ever forms `base + popcount(...)`, so the order is free as long as the children of a node
+// stay contiguous: here every node of level depth - 2 is followed directly by its <= 8 children and their <= 64 children (the leaf
+// parents) — 1 + c + g records, <= 584 bytes — and only `base` values change (the leaf words keep their order).
+//   old: [.. level A = depth-2 ..][.. level B = depth-1 ..][.. level C = depth ..]      fa / fb / fc: where the levels start
+//   new: [A_0 | its B's | their C's][A_1 | ...] ...        in the same range [fa, n)
+// position of treelet t: fa + t + (B nodes before its first child) + (C nodes before its first grandchild) — both read off the old
+// records' bases, which are exclusive scans already.
+__device__ __forceinline__ uint32_t treelet_position(const SvoRecord* old, uint32_t fa, uint32_t fb, uint32_t fc, uint32_t t) {
+    const uint32_t kfirst = old[fa + t].base - fb;              // index of its first child within level B
+    const uint32_t gfirst = old[fb + kfirst].base - fc;         // index of its first grandchild within level C
+    return fa + t + kfirst + gfirst;
+}
+
+__global__ __launch_bounds__(256) void treelet_scatter_kernel(const SvoRecord* old, SvoRecord* out, uint32_t fa, uint32_t fb, uint32_t fc) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= fb - fa) return;
+    const SvoRecord a = old[fa + t];
+    const uint32_t ca = uint32_t(__popc(a.masks & 0xffu));
+    const uint32_t kfirst = a.base - fb;
+    const uint32_t pos = treelet_position(old, fa, fb, fc, t);
+    out[pos] = SvoRecord{a.masks, pos + 1u};
+    uint32_t g = pos + 1u + ca;                                   // where the next child's children go
+    for (uint32_t j = 0; j < ca; j++) {
+        const SvoRecord b = old[fb + kfirst + j];
+        const uint32_t cb = uint32_t(__popc(b.masks & 0xffu));
+        out[pos + 1u + j] = SvoRecord{b.masks, g};
+        for (uint32_t i = 0; i < cb; i++) out[g + i] = old[b.base + i];     // leaf parents: {leaf mask << 8, first leaf word}, unchanged
+        g += cb;
+    }
+}
+
+// the parents of the treelet roots (level depth - 3, [fp, fa)): their bases follow the roots
+__global__ __launch_bounds__(256) void treelet_parents_kernel(const SvoRecord* old, SvoRecord* out, uint32_t fp, uint32_t fa, uint32_t fb, uint32_t fc) {
+    const uint32_t p = fp + blockIdx.x * 256u + threadIdx.x;
+    if (p >= fa) return;
+    const SvoRecord r = old[p];
+    out[p] = SvoRecord{r.masks, treelet_position(old, fa, fb, fc, r.base - fa)};
+}
+
 struct DevBuf {
     void* p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -284,6 +326,25 @@ int build_menger_svo_device(uint32_t level, uint32_t clip, const uint8_t mrgb[4]
     *d_leaves = leaves.as<int32_t>(); leaves.p = nullptr;
     *svo_count = nodes;
     *leaf_count = nleaves ? nleaves : 1;
+    return VXRT_OK;
+}
+
+// Reorders the last three node levels of a breadth-first record array into depth-first treelets (see above).  level_first[l]: index
+// of the first record of node level l (0 .. depth; level 0 is the root), n: records in all.  *d_svo is replaced (the old array freed).
+int reorder_bottom_treelets(SvoRecord** d_svo, size_t n, const std::vector<size_t>& level_first, uint32_t depth, hipStream_t stream) {
+    if (depth < 4 || level_first.size() < size_t(depth) + 1 || n >= (size_t(1) << 32)) { set_error("treelets: the tree is too shallow"); return VXRT_E_INVALID; }
+    const uint32_t fp = uint32_t(level_first[depth - 3]), fa = uint32_t(level_first[depth - 2]), fb = uint32_t(level_first[depth - 1]), fc = uint32_t(level_first[depth]);
+    if (!(fp < fa && fa < fb && fb < fc && fc < n)) { set_error("treelets: level starts out of order"); return VXRT_E_INVALID; }
+    DevBuf out;
+    DEV_TRY(out.alloc(n * sizeof(SvoRecord)));
+    DEV_TRY(hipMemcpyAsync(out.p, *d_svo, size_t(fp) * sizeof(SvoRecord), hipMemcpyDeviceToDevice, stream));     // levels 0 .. depth-4 as they are
+    hipLaunchKernelGGL(treelet_parents_kernel, dim3((fa - fp + 255u) / 256u), dim3(256), 0, stream, *d_svo, out.as<SvoRecord>(), fp, fa, fb, fc);
+    hipLaunchKernelGGL(treelet_scatter_kernel, dim3((fb - fa + 255u) / 256u), dim3(256), 0, stream, *d_svo, out.as<SvoRecord>(), fa, fb, fc);
+    DEV_TRY(hipGetLastError());
+    DEV_TRY(hipStreamSynchronize(stream));
+    (void)hipFree(*d_svo);
+    *d_svo = out.as<SvoRecord>();
+    out.p = nullptr;
     return VXRT_OK;
 }
 

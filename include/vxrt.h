@@ -155,7 +155,7 @@ typedef struct vxrt_stats {
     uint64_t octree_nodes;
     uint64_t wide_nodes;      /* records of the scene's two-levels-per-record form (16 bytes each); 0 unless VXRT_OPT_SCENE_FORMAT 1 */
     uint32_t scene_format;    /* which of the two the default tracer walks right now: 0 8-byte records, 1 wide records      */
-    uint32_t reserved0;
+    uint32_t node_order;      /* 1: the scene in place has its bottom levels as treelets (VXRT_OPT_NODE_ORDER)            */
     uint64_t queue_bytes;     /* device bytes of the tracer's path queues (sized by need for tracers 4 / 5)             */
     uint64_t queue_overflow_paths; /* paths that found their queue shard full and were followed by the head kernel
                                  instead (same image; the queues grow before the stream's next launch)               */
@@ -207,6 +207,11 @@ typedef struct vxrt_stats {
  *   VXRT_OPT_TAIL_FROM     create: the hit at which a path moves from trace_kernel to the compacted tail (default 1 = the second hit).
  *   VXRT_OPT_TAIL_SPLIT    create: bit k = the tail compacts once more at path segment k (default: 0x8 from 6 bounces on).
  *   VXRT_OPT_HOST_SCENE_BUILD  1: vxrt_set_menger builds the scene on the host also where the device builder could (cross-check).
+ *   VXRT_OPT_NODE_ORDER    the order of the scene's 8-byte records in memory, chosen before the scene is set: 0 (default) breadth-first,
+ *                          level after level; 1: for trees of depth >= 10 the last three node levels as depth-first treelets — a node of
+ *                          level depth - 2 followed by its children and theirs (<= 584 bytes), so that the end of a descent stays in
+ *                          one neighbourhood of memory (BASELINE config 5's scene lives in HBM).  Node indices never reach an output:
+ *                          same image.  vxrt_stats.node_order reads 1 when the scene in place was reordered.
  *   VXRT_OPT_TRACER_OVERRIDE   create: the internal schedule past vxrt_config.tracer's automatic choice: 0 all-in-one kernel, 4 head +
  *                          compacted tail; 2 / 3 / 5 (-DVXRT_VARIANTS=1 builds) wavefront, ray queues, path kernel.
  *   VXRT_OPT_TRACE_SPLIT / PATH_BLOCKS / SHADE_BLOCKS / RAYS_PER_WAVE   create: launch shapes of tracers 2, 3 and 5.                    */
@@ -214,7 +219,7 @@ typedef enum vxrt_option { VXRT_OPT_DENOISE_MODE = 1, VXRT_OPT_TAIL_CAPACITY = 2
                            VXRT_OPT_SKY_CULL = 5, VXRT_OPT_FRAME_LANES = 6, VXRT_OPT_TILE_ORDER = 7, VXRT_OPT_TILE_SPREAD = 8,
                            VXRT_OPT_TRACE_BLOCKS = 9, VXRT_OPT_TAIL_FROM = 10, VXRT_OPT_TAIL_SPLIT = 11, VXRT_OPT_HOST_SCENE_BUILD = 12,
                            VXRT_OPT_TRACER_OVERRIDE = 13, VXRT_OPT_TRACE_SPLIT = 14, VXRT_OPT_PATH_BLOCKS = 15, VXRT_OPT_SHADE_BLOCKS = 16,
-                           VXRT_OPT_RAYS_PER_WAVE = 17 } vxrt_option;
+                           VXRT_OPT_RAYS_PER_WAVE = 17, VXRT_OPT_NODE_ORDER = 18 } vxrt_option;
 #define VXRT_TILE_SPREAD_AUTO 0xffffffffu
 int vxrt_set_option(vxrt_ctx* ctx, vxrt_option option, uint32_t value);
 /* An (option, value) pair for vxrt_create_tuned. */

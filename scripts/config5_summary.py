@@ -42,16 +42,18 @@ def mean(xs):
 
 out = {"workload": "scripts/exp_config5.py 2048: level-7 Menger clipped to 2048^3 (261 140 230 nodes, 5.58 GiB as 8-byte records + leaf words), "
                    "3840x2160, 8 bounces, all-in-one trace_kernel, one frame per launch", "formats": {}}
-for wide, label in ((0, "8-byte records"), (1, "wide records (two levels per 16-byte record)")):
+# the variants of a run: `prefix=label` arguments (scripts/profile_config5_order.sh), default the two scene formats of profile_config5.sh
+variants = [a.split("=", 1) for a in sys.argv[2:]] or [("w0", "8-byte records"), ("w1", "wide records (two levels per 16-byte record)")]
+for pre, label in variants:
     entry = {}
     try:
-        entry["reported_by_the_run"] = [l.strip() for l in open(f"{base}/w{wide}_stats.txt") if "ms/frame" in l or "built in" in l]
+        entry["reported_by_the_run"] = [l.strip() for l in open(f"{base}/{pre}_stats.txt") if "ms/frame" in l or "built in" in l]
     except OSError:
         pass
-    st = views(per_launch(f"w{wide}_stats"))
-    fe = views(per_launch(f"w{wide}_fetch", True))
-    tc = views(per_launch(f"w{wide}_tcc", True))
-    sq = views(per_launch(f"w{wide}_sq", True))
+    st = views(per_launch(f"{pre}_stats"))
+    fe = views(per_launch(f"{pre}_fetch", True))
+    tc = views(per_launch(f"{pre}_tcc", True))
+    sq = views(per_launch(f"{pre}_sq", True))
     for v in ("outside", "tunnel"):
         e = {}
         if st[v]:
