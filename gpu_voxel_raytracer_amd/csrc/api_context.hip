@@ -9,13 +9,15 @@ size_t image_bytes(const vxrt_ctx* c) { return size_t(c->band.local_rows) * c->b
 
 int count_local_rows(const BandMap& b) {
     int rows = 0;
-    for (int y0 = 0, band = 0; y0 < b.height; y0 += b.band_rows, band++)
-        if (band % b.nranks == b.rank) rows += (y0 + b.band_rows <= b.height) ? b.band_rows : b.height - y0;
+    for (int gb = b.rank; gb < band_count(b); gb += b.nranks) {
+        const int y0 = band_first_row(b, gb), n = band_nominal_rows(b, gb);
+        rows += (y0 + n <= b.height) ? n : b.height - y0;
+    }
     return rows;
 }
 
 int local_band_count(const BandMap& b) {
-    int bands = (b.height + b.band_rows - 1) / b.band_rows;
+    const int bands = band_count(b);
     return bands <= b.rank ? 0 : (bands - b.rank + b.nranks - 1) / b.nranks;
 }
 
@@ -162,6 +164,12 @@ int set_band(vxrt_ctx* c, uint32_t width, uint32_t height) {
     b.rank = int(cfg.rank);
     b.band_rows = cfg.band_rows == 0 ? 16 : int(cfg.band_rows);
     if (b.nranks == 1) b.rank = 0;
+    // whole rounds of nranks bands at band_rows rows, then one round of shorter bands over what is left (kernels.h: BandMap)
+    const int tile = b.band_rows % 16 == 0 ? 16 : 8;
+    b.full_bands = (b.height / (b.nranks * b.band_rows)) * b.nranks;
+    b.tail_y0 = b.full_bands * b.band_rows;
+    const int rest = b.height - b.tail_y0;                                  // < nranks * band_rows
+    b.tail_rows = rest == 0 ? b.band_rows : ((rest + b.nranks - 1) / b.nranks + tile - 1) / tile * tile;
     b.local_rows = count_local_rows(b);
     c->band = b;
     return VXRT_OK;
@@ -292,7 +300,7 @@ int apply_option(vxrt_ctx* c, uint32_t option, uint32_t value, bool at_create) {
             c->host_scene_build = int(value);
             return VXRT_OK;
         case VXRT_OPT_NODE_ORDER:       // read when a scene is set
-            if (value > 1) { set_error("node order must be 0 (breadth-first) or 1 (treelets at the bottom)"); return VXRT_E_INVALID; }
+            if (value != 0 && value != 2 && value != 3) { set_error("node order must be 0 (breadth-first), 2 or 3 (treelets of the last 2 / 3 node levels)"); return VXRT_E_INVALID; }
             c->node_order = int(value);
             return VXRT_OK;
         case VXRT_OPT_TRACER_OVERRIDE:  // the internal tracer number, past vxrt_config.tracer's auto rule (A/B runs of the variants)
@@ -563,7 +571,7 @@ int vxrt_local_rows(const vxrt_ctx* c, uint32_t* count, uint32_t* rows) try {
     const BandMap& b = c->band;
     uint32_t n = 0;
     for (int y = 0; y < b.height; y++)
-        if ((y / b.band_rows) % b.nranks == b.rank) {
+        if (band_of_row(b, y) % b.nranks == b.rank) {
             if (rows) rows[n] = uint32_t(y);
             n++;
         }

@@ -15,8 +15,7 @@ namespace vxrt {
 
 namespace {
 int max_bands(const BandMap& b) {
-    int bands = (b.height + b.band_rows - 1) / b.band_rows;
-    return (bands + b.nranks - 1) / b.nranks;
+    return (band_count(b) + b.nranks - 1) / b.nranks;
 }
 
 // the layout of an exchange with `rows` rows per band edge
@@ -32,7 +31,9 @@ HaloView view_for(const vxrt_ctx* c, uint32_t rows) {
 uint32_t halo_rows_wanted(const vxrt_ctx* c) {
     if (c->band.nranks < 2) return 0;
     uint32_t rows = c->denoise.radius > c->halo_min_rows ? c->denoise.radius : c->halo_min_rows;
-    return rows > uint32_t(c->band.band_rows) ? uint32_t(c->band.band_rows) : rows;
+    // at most a band: a neighbour's rows beyond that belong to a third rank.  The tail round's bands may be lower than band_rows.
+    const uint32_t lowest = uint32_t(c->band.tail_y0 < c->band.height ? c->band.tail_rows : c->band.band_rows);
+    return rows > lowest ? lowest : rows;
 }
 
 void free_halo(vxrt_ctx* c) {
@@ -57,10 +58,10 @@ int build_tile_rows(vxrt_ctx* c) {
     if (tile_rows == 0 || tile_rows > 65535 || b.band_rows % 16 != 0) return VXRT_OK;   // 8-row bands: no denoise window (check_render)
     std::vector<uint16_t> interior, edge;
     for (int t = 0; t < tile_rows; t++) {
-        const int lrow0 = t * 16, lband = lrow0 / b.band_rows;
-        const int band_y0 = (lband * b.nranks + b.rank) * b.band_rows;
-        const int band_end = band_y0 + b.band_rows < b.height ? band_y0 + b.band_rows : b.height;
-        const int y0 = band_y0 + (lrow0 - lband * b.band_rows), y1 = y0 + 16 < band_end ? y0 + 16 : band_end;   // the tile's rows [y0, y1)
+        const int lrow0 = t * 16, lband = local_band_of(b, lrow0), gb = lband * b.nranks + b.rank;
+        const int band_y0 = band_first_row(b, gb);
+        const int band_end = band_y0 + band_nominal_rows(b, gb) < b.height ? band_y0 + band_nominal_rows(b, gb) : b.height;
+        const int y0 = band_y0 + (lrow0 - local_band_first_row(b, lband)), y1 = y0 + 16 < band_end ? y0 + 16 : band_end;   // the tile's rows [y0, y1)
         const bool above = b.nranks > 1 && y0 == band_y0 && band_y0 > 0;
         const bool below = b.nranks > 1 && y1 == band_end && band_end < b.height;
         (above || below ? edge : interior).push_back(uint16_t(t));

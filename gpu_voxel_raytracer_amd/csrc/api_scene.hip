@@ -11,7 +11,7 @@ namespace vxrt {
 int build_menger_svo(uint32_t level, uint32_t clip, const uint8_t mrgb[4], uint32_t emissive_period, std::vector<SvoRecord>* recs,
                      std::vector<int32_t>* leaves, uint32_t* depth_out);
 bool menger_device_build_supported(uint32_t level, uint32_t clip);
-int reorder_bottom_treelets(SvoRecord** d_svo, size_t n, const std::vector<size_t>& level_first, uint32_t depth, hipStream_t stream);
+int reorder_bottom_treelets(SvoRecord** d_svo, size_t n, const std::vector<size_t>& level_first, uint32_t depth, int levels, hipStream_t stream);
 int build_menger_svo_device(uint32_t level, uint32_t clip, const uint8_t mrgb[4], uint32_t emissive_period, hipStream_t stream,
                             SvoRecord** d_svo, size_t* svo_count, int32_t** d_leaves, size_t* leaf_count, uint32_t* depth_out, SvoRecord* root);
 }
@@ -129,13 +129,13 @@ bool scene_box(const SvoRecord* recs, size_t count, uint32_t depth, const float 
     return true;
 }
 
-// VXRT_OPT_NODE_ORDER 1: the last three node levels of the (breadth-first) records just built become depth-first treelets
-// (scene_device.hip: reorder_bottom_treelets).  Only for trees of depth >= 10: the sky cull's box reads levels 0 .. 7 as a prefix of
-// the records, and a shallow tree is cache-resident anyway.  The level starts are found by following the first node of every level
+// VXRT_OPT_NODE_ORDER 2 / 3: the last two / three node levels of the (breadth-first) records just built become depth-first treelets
+// (scene_device.hip: reorder_bottom_treelets); trees of depth >= 4.  (The sky cull's box was made from the breadth-first records
+// before this runs.)  The level starts are found by following the first node of every level
 // (in a breadth-first array the first child of a level's first node opens the next level; every inner node has a child).
 int apply_node_order(vxrt_ctx* c) {
     c->node_order_applied = 0;
-    if (c->node_order != 1 || c->depth < 10u || c->d_svo == nullptr || c->svo_count < 2) return VXRT_OK;
+    if ((c->node_order != 2 && c->node_order != 3) || c->depth < 4u || c->d_svo == nullptr || c->svo_count < 2) return VXRT_OK;
     std::vector<size_t> first(size_t(c->depth) + 1, 0);
     SvoRecord r = c->root_rec;
     for (uint32_t l = 1; l <= c->depth; l++) {
@@ -143,8 +143,8 @@ int apply_node_order(vxrt_ctx* c) {
         first[l] = r.base;
         HIP_TRY(hipMemcpy(&r, c->d_svo + r.base, sizeof r, hipMemcpyDeviceToHost));
     }
-    if (int rc = reorder_bottom_treelets(&c->d_svo, c->svo_count, first, c->depth, c->stream)) return rc;
-    c->node_order_applied = 1;
+    if (int rc = reorder_bottom_treelets(&c->d_svo, c->svo_count, first, c->depth, c->node_order, c->stream)) return rc;
+    c->node_order_applied = c->node_order;
     return VXRT_OK;
 }
 

@@ -183,7 +183,7 @@ struct vxrt_ctx {
     int use_tile_order = 1;
     int trace_blocks = 2048;
     int spread_override = -1;     // VXRT_OPT_TILE_SPREAD (tests, experiments): see launch_tile_order
-    int node_order = 0;           // VXRT_OPT_NODE_ORDER: 1 = depth-first treelets at the bottom of deep trees (scene_device.hip)
+    int node_order = 0;           // VXRT_OPT_NODE_ORDER: 2 / 3 = depth-first treelets of the last 2 / 3 node levels (scene_device.hip)
     int node_order_applied = 0;   // ... and whether the scene in place was reordered (vxrt_stats.node_order)
     int host_scene_build = 0;     // VXRT_OPT_HOST_SCENE_BUILD: vxrt_set_menger builds on the host even where the device builder could
     unsigned wave_slots = 5120;   // waves of trace_kernel the device holds at once: CUs x 4 SIMDs x 5 (vxrt_create)

@@ -20,16 +20,17 @@ __global__ __launch_bounds__(256) void halo_pack_kernel(const HaloPackArgs a) {
     if (x >= a.band.width) return;
     const BandMap& b = a.band;
     const int gb = lb * b.nranks + b.rank;
-    const int y0 = gb * b.band_rows;
-    const int rows_here = (y0 + b.band_rows <= b.height) ? b.band_rows : b.height - y0;
+    const int y0 = band_first_row(b, gb), nominal = band_nominal_rows(b, gb);
+    if (y0 >= b.height) return;
+    const int rows_here = (y0 + nominal <= b.height) ? nominal : b.height - y0;
     int lrow, slot;
     if (side == 0) {   // my top rows are the rows below band gb - 1 (the previous rank's local band (gb - 1) / nranks)
         if (gb < 1 || k >= rows_here) return;
-        lrow = lb * b.band_rows + k;
+        lrow = local_band_first_row(b, lb) + k;
         slot = (gb - 1) / b.nranks;
     } else {           // my bottom rows are the rows above band gb + 1 (the next rank's local band (gb + 1) / nranks)
-        if (rows_here != b.band_rows || (gb + 1) * b.band_rows >= b.height) return;
-        lrow = lb * b.band_rows + (b.band_rows - a.rows) + k;
+        if (rows_here != nominal || y0 + nominal >= b.height) return;
+        lrow = local_band_first_row(b, lb) + (nominal - a.rows) + k;
         slot = (gb + 1) / b.nranks;
     }
     const size_t p = size_t(lrow) * b.width + x;

@@ -23,28 +23,17 @@ __device__ __forceinline__ HaloRow halo_row(const HaloView& h, int width, int si
     return r;
 }
 
-// frame row -> local row of this context, or -1 when another rank owns it
-__device__ __forceinline__ int local_row(const BandMap& b, int y) {
-    int band = y / b.band_rows;
-    if (band % b.nranks != b.rank) return -1;
-    return (band / b.nranks) * b.band_rows + (y - band * b.band_rows);
-}
-__device__ __forceinline__ int frame_row(const BandMap& b, int lrow) {
-    int lband = lrow / b.band_rows;
-    return (lband * b.nranks + b.rank) * b.band_rows + (lrow - lband * b.band_rows);
-}
-
 // Frame row y, which this rank does not own, in its halo: false when the halo does not hold it (further than h.rows rows from
 // every band of this rank, or no halo at all).
 __device__ __forceinline__ bool halo_find(const BandMap& b, const HaloView& h, int y, HaloRow& out) {
     if (h.base == nullptr) return false;
-    const int band = y / b.band_rows, off = y - band * b.band_rows;
+    const int band = band_of_row(b, y), off = y - band_first_row(b, band), nominal = band_nominal_rows(b, band);
     if (band >= 1 && (band - 1) % b.nranks == b.rank && off < h.rows) {               // just below one of this rank's bands
         out = halo_row(h, b.width, 1, (band - 1) / b.nranks, off);
         return true;
     }
-    if ((band + 1) % b.nranks == b.rank && off >= b.band_rows - h.rows) {             // just above one
-        out = halo_row(h, b.width, 0, (band + 1) / b.nranks, off - (b.band_rows - h.rows));
+    if ((band + 1) % b.nranks == b.rank && off >= nominal - h.rows) {                 // just above one
+        out = halo_row(h, b.width, 0, (band + 1) / b.nranks, off - (nominal - h.rows));
         return true;
     }
     return false;

@@ -47,9 +47,36 @@ struct Cam {  // first 64 bytes of Uniforms, without padding
     float o[3], r[3], u[3], f[3];
 };
 
-struct BandMap {  // which rows of the frame this context owns (vxrt_config.rank/nranks/band_rows)
+// Which rows of the frame this context owns (vxrt_config.rank / nranks / band_rows).  The rows are dealt to the ranks in interleaved
+// bands, band gb -> rank gb % nranks.  Whole ROUNDS of nranks bands are band_rows rows high (`full_bands` bands, rows [0, tail_y0));
+// what is left below them — fewer than nranks * band_rows rows — is ONE more round of bands `tail_rows` rows high, the smallest
+// multiple of the tile height (16 rows when band_rows is a multiple of 16, else 8) that covers the rest in nranks bands.  So every
+// rank's row count is within one tile row of height / nranks (round 4; until then the last round's bands were band_rows high too and
+// the first ranks of that round owned up to a band more than the others: 288 against 240 rows at 2160 rows / 8 ranks / 48-row bands).
+struct BandMap {
     int width, height, local_rows, band_rows, rank, nranks;
+    int full_bands;   // bands of band_rows rows (a multiple of nranks)
+    int tail_y0;      // = full_bands * band_rows: where the tail round starts (== height: there is none)
+    int tail_rows;    // height of the tail round's bands: <= band_rows, a multiple of the tile height
 };
+#define VX_BAND_FN __host__ __device__ __forceinline__
+VX_BAND_FN int band_of_row(const BandMap& b, int y) { return y < b.tail_y0 ? y / b.band_rows : b.full_bands + (y - b.tail_y0) / b.tail_rows; }
+VX_BAND_FN int band_first_row(const BandMap& b, int gb) { return gb < b.full_bands ? gb * b.band_rows : b.tail_y0 + (gb - b.full_bands) * b.tail_rows; }
+VX_BAND_FN int band_nominal_rows(const BandMap& b, int gb) { return gb < b.full_bands ? b.band_rows : b.tail_rows; }    // before the frame's edge clips it
+VX_BAND_FN int band_count(const BandMap& b) { return b.full_bands + (b.height - b.tail_y0 + b.tail_rows - 1) / b.tail_rows; }
+// local band lb of a rank (its lb-th band): the first local row; and the local band a local row lies in
+VX_BAND_FN int local_band_first_row(const BandMap& b, int lb) { const int r = b.full_bands / b.nranks; return lb < r ? lb * b.band_rows : r * b.band_rows; }
+VX_BAND_FN int local_band_of(const BandMap& b, int lrow) { const int r = b.full_bands / b.nranks; return lrow < r * b.band_rows ? lrow / b.band_rows : r; }
+// frame row -> local row of this context, or -1 when another rank owns it; and back
+VX_BAND_FN int local_row(const BandMap& b, int y) {
+    const int gb = band_of_row(b, y);
+    if (gb % b.nranks != b.rank) return -1;
+    return local_band_first_row(b, gb / b.nranks) + (y - band_first_row(b, gb));
+}
+VX_BAND_FN int frame_row(const BandMap& b, int lrow) {
+    const int lb = local_band_of(b, lrow);
+    return band_first_row(b, lb * b.nranks + b.rank) + (lrow - local_band_first_row(b, lb));
+}
 
 // A queue of 64-byte path records in 64 shards (trace_common.h: PathRec, queue_append).
 struct PathQueue {

@@ -172,8 +172,9 @@ __global__ __launch_bounds__(256) void denoise_generic_kernel(const DenoiseArgs 
     const int tile_row = a.tile_rows != nullptr ? int(a.tile_rows[blockIdx.y]) : int(blockIdx.y);
     const int lrow0 = tile_row * 16;  // band_rows is a multiple of 16: a tile never straddles two bands
     const int y0 = frame_row(a.band, lrow0) - r;
-    const int lband = lrow0 / a.band.band_rows;
-    const int band_y0 = (lband * a.band.nranks + a.band.rank) * a.band.band_rows;  // first frame row of the band
+    const int lband = local_band_of(a.band, lrow0);
+    const int band_y0 = band_first_row(a.band, lband * a.band.nranks + a.band.rank);   // first frame row of the band
+    const int band_rows_here = band_nominal_rows(a.band, lband * a.band.nranks + a.band.rank);
 
     for (int i = threadIdx.x; i < taps * taps; i += 256) wdist[i] = a.wdist[i];   // denoise.comp:79, made by launch_denoise
     for (int i = threadIdx.x; i < tw * tw; i += 256) {
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void denoise_generic_kernel(const DenoiseArgs 
             } else if (a.halo.base != nullptr) {
                 // a row of a neighbouring rank: side 0 = the rows above the band, side 1 = the rows below it
                 const int side = gy < band_y0 ? 0 : 1;
-                const int k = side == 0 ? gy - (band_y0 - a.halo.rows) : gy - (band_y0 + a.band.band_rows);
+                const int k = side == 0 ? gy - (band_y0 - a.halo.rows) : gy - (band_y0 + band_rows_here);
                 const HaloRow row = halo_row(a.halo, a.band.width, side, lband, k);
                 const float4 ha = row.a[gx], hb = row.b[gx];
                 c = make_float4(ha.x, ha.y, ha.z, 0.0f);

@@ -171,46 +171,61 @@ __global__ __launch_bounds__(kScanBlock) void emit_level_kernel(const uint32_t* 
     }
 }
 
-// ---- node order (VXRT_OPT_NODE_ORDER 1): depth-first TREELETS at the bottom of the tree -------------------------------------------
+// ---- node order (VXRT_OPT_NODE_ORDER): depth-first TREELETS at the bottom of the tree ---------------------------------------------
 // The builders emit the records breadth-first: level after level, each level in the order of its parents (a Morton order), the
-// children of a node contiguous.  A descent through the last three node levels then reads three far-apart arrays.  Node indices
-// never reach an output and the walk only ever forms `base + popcount(...)`, so the order is free as long as the children of a node
-// stay contiguous: here every node of level depth - 2 is followed directly by its <= 8 children and their <= 64 children (the leaf
-// parents) — 1 + c + g records, <= 584 bytes — and only `base` values change (the leaf words keep their order).
-//   old: [.. level A = depth-2 ..][.. level B = depth-1 ..][.. level C = depth ..]      fa / fb / fc: where the levels start
-//   new: [A_0 | its B's | their C's][A_1 | ...] ...        in the same range [fa, n)
-// position of treelet t: fa + t + (B nodes before its first child) + (C nodes before its first grandchild) — both read off the old
-// records' bases, which are exclusive scans already.
-__device__ __forceinline__ uint32_t treelet_position(const SvoRecord* old, uint32_t fa, uint32_t fb, uint32_t fc, uint32_t t) {
-    const uint32_t kfirst = old[fa + t].base - fb;              // index of its first child within level B
-    const uint32_t gfirst = old[fb + kfirst].base - fc;         // index of its first grandchild within level C
-    return fa + t + kfirst + gfirst;
-}
-
-__global__ __launch_bounds__(256) void treelet_scatter_kernel(const SvoRecord* old, SvoRecord* out, uint32_t fa, uint32_t fb, uint32_t fc) {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= fb - fa) return;
-    const SvoRecord a = old[fa + t];
-    const uint32_t ca = uint32_t(__popc(a.masks & 0xffu));
-    const uint32_t kfirst = a.base - fb;
-    const uint32_t pos = treelet_position(old, fa, fb, fc, t);
-    out[pos] = SvoRecord{a.masks, pos + 1u};
-    uint32_t g = pos + 1u + ca;                                   // where the next child's children go
-    for (uint32_t j = 0; j < ca; j++) {
-        const SvoRecord b = old[fb + kfirst + j];
-        const uint32_t cb = uint32_t(__popc(b.masks & 0xffu));
-        out[pos + 1u + j] = SvoRecord{b.masks, g};
-        for (uint32_t i = 0; i < cb; i++) out[g + i] = old[b.base + i];     // leaf parents: {leaf mask << 8, first leaf word}, unchanged
-        g += cb;
+// children of a node contiguous.  A descent through the last node levels then reads one far-apart array per level.  Node indices
+// never reach an output and the walk only ever forms `base + popcount(...)`, so the order is free as long as THE CHILDREN OF A NODE
+// STAY CONTIGUOUS.  A treelet therefore hangs below a node p of level depth - K (K = 2 or 3; p itself stays where it is, only its
+// base changes): p's children as one block, then, child by child, that child's children as a block followed by their children's
+// blocks — K levels, <= 8 + 64 (+ 512) records, all of p's descendants in one run of memory:
+//   old: [.. level depth-K+1 ..] ... [.. level depth ..]                 one array per level (first[l]: where level l starts)
+//   new: [treelet of p_0][treelet of p_1] ...                              in the same range [first[depth-K+1], n), p in level order
+// Where p's treelet starts: every earlier p's descendants come before it, level by level — the index of p's first descendant within
+// each level, read off the old bases (they are exclusive scans already).  The leaf words keep their order.
+template <int K>
+__global__ __launch_bounds__(256) void treelet_kernel(const SvoRecord* old, SvoRecord* out, uint32_t fp, uint32_t fa, uint32_t fb, uint32_t fc) {
+    // K = 3: p in [fp, fa), levels A = [fa, fb), B = [fb, fc), C = [fc, n).   K = 2: p in [fa, fb) (passed as fp = fa), levels B, C.
+    const uint32_t pi = fp + blockIdx.x * 256u + threadIdx.x;
+    if (pi >= fa && K == 3) return;
+    if (K == 2 && pi >= fb) return;
+    const SvoRecord p = old[pi];
+    if (K == 3) {
+        const uint32_t a0 = p.base - fa;                                  // p's first child within level A
+        const uint32_t b0 = old[fa + a0].base - fb;                       // ... its first descendant within level B
+        const uint32_t c0 = old[fb + b0].base - fc;                       // ... and within level C
+        const uint32_t pos0 = fa + a0 + b0 + c0;
+        const uint32_t na = uint32_t(__popc(p.masks & 0xffu));
+        out[pi] = SvoRecord{p.masks, pos0};
+        uint32_t cursor = pos0 + na;
+        for (uint32_t j = 0; j < na; j++) {
+            const SvoRecord ra = old[fa + a0 + j];
+            const uint32_t nb = uint32_t(__popc(ra.masks & 0xffu));
+            out[pos0 + j] = SvoRecord{ra.masks, cursor};
+            const uint32_t bpos = cursor;
+            cursor += nb;
+            for (uint32_t i = 0; i < nb; i++) {
+                const SvoRecord rb = old[ra.base + i];
+                const uint32_t nc = uint32_t(__popc(rb.masks & 0xffu));
+                out[bpos + i] = SvoRecord{rb.masks, cursor};
+                for (uint32_t c = 0; c < nc; c++) out[cursor + c] = old[rb.base + c];   // leaf parents: {leaf mask << 8, first leaf word}
+                cursor += nc;
+            }
+        }
+    } else {
+        const uint32_t b0 = p.base - fb;
+        const uint32_t c0 = old[fb + b0].base - fc;
+        const uint32_t pos0 = fb + b0 + c0;
+        const uint32_t nb = uint32_t(__popc(p.masks & 0xffu));
+        out[pi] = SvoRecord{p.masks, pos0};
+        uint32_t cursor = pos0 + nb;
+        for (uint32_t i = 0; i < nb; i++) {
+            const SvoRecord rb = old[fb + b0 + i];
+            const uint32_t nc = uint32_t(__popc(rb.masks & 0xffu));
+            out[pos0 + i] = SvoRecord{rb.masks, cursor};
+            for (uint32_t c = 0; c < nc; c++) out[cursor + c] = old[rb.base + c];
+            cursor += nc;
+        }
     }
-}
-
-// the parents of the treelet roots (level depth - 3, [fp, fa)): their bases follow the roots
-__global__ __launch_bounds__(256) void treelet_parents_kernel(const SvoRecord* old, SvoRecord* out, uint32_t fp, uint32_t fa, uint32_t fb, uint32_t fc) {
-    const uint32_t p = fp + blockIdx.x * 256u + threadIdx.x;
-    if (p >= fa) return;
-    const SvoRecord r = old[p];
-    out[p] = SvoRecord{r.masks, treelet_position(old, fa, fb, fc, r.base - fa)};
 }
 
 struct DevBuf {
@@ -329,17 +344,23 @@ int build_menger_svo_device(uint32_t level, uint32_t clip, const uint8_t mrgb[4]
     return VXRT_OK;
 }
 
-// Reorders the last three node levels of a breadth-first record array into depth-first treelets (see above).  level_first[l]: index
-// of the first record of node level l (0 .. depth; level 0 is the root), n: records in all.  *d_svo is replaced (the old array freed).
-int reorder_bottom_treelets(SvoRecord** d_svo, size_t n, const std::vector<size_t>& level_first, uint32_t depth, hipStream_t stream) {
-    if (depth < 4 || level_first.size() < size_t(depth) + 1 || n >= (size_t(1) << 32)) { set_error("treelets: the tree is too shallow"); return VXRT_E_INVALID; }
+// Reorders the last `levels` (2 or 3) node levels of a breadth-first record array into depth-first treelets (see above).
+// level_first[l]: index of the first record of node level l (0 .. depth; level 0 is the root), n: records in all.  *d_svo is replaced.
+int reorder_bottom_treelets(SvoRecord** d_svo, size_t n, const std::vector<size_t>& level_first, uint32_t depth, int levels, hipStream_t stream) {
+    if ((levels != 2 && levels != 3) || depth < 4 || level_first.size() < size_t(depth) + 1 || n >= (size_t(1) << 32)) {
+        set_error("treelets: 2 or 3 levels of a tree at least 4 levels deep");
+        return VXRT_E_INVALID;
+    }
     const uint32_t fp = uint32_t(level_first[depth - 3]), fa = uint32_t(level_first[depth - 2]), fb = uint32_t(level_first[depth - 1]), fc = uint32_t(level_first[depth]);
     if (!(fp < fa && fa < fb && fb < fc && fc < n)) { set_error("treelets: level starts out of order"); return VXRT_E_INVALID; }
     DevBuf out;
     DEV_TRY(out.alloc(n * sizeof(SvoRecord)));
-    DEV_TRY(hipMemcpyAsync(out.p, *d_svo, size_t(fp) * sizeof(SvoRecord), hipMemcpyDeviceToDevice, stream));     // levels 0 .. depth-4 as they are
-    hipLaunchKernelGGL(treelet_parents_kernel, dim3((fa - fp + 255u) / 256u), dim3(256), 0, stream, *d_svo, out.as<SvoRecord>(), fp, fa, fb, fc);
-    hipLaunchKernelGGL(treelet_scatter_kernel, dim3((fb - fa + 255u) / 256u), dim3(256), 0, stream, *d_svo, out.as<SvoRecord>(), fa, fb, fc);
+    const uint32_t keep = levels == 3 ? fp : fa;        // the levels above the treelets' parents: as they are
+    DEV_TRY(hipMemcpyAsync(out.p, *d_svo, size_t(keep) * sizeof(SvoRecord), hipMemcpyDeviceToDevice, stream));
+    if (levels == 3)
+        hipLaunchKernelGGL(treelet_kernel<3>, dim3((fa - fp + 255u) / 256u), dim3(256), 0, stream, *d_svo, out.as<SvoRecord>(), fp, fa, fb, fc);
+    else
+        hipLaunchKernelGGL(treelet_kernel<2>, dim3((fb - fa + 255u) / 256u), dim3(256), 0, stream, *d_svo, out.as<SvoRecord>(), fa, fa, fb, fc);
     DEV_TRY(hipGetLastError());
     DEV_TRY(hipStreamSynchronize(stream));
     (void)hipFree(*d_svo);

@@ -119,8 +119,7 @@ __global__ __launch_bounds__(kTB, kWaves) void trace_kernel(const TraceArgs a) {
     const unsigned tile = a.tile_order ? a.tile_order[ord] : ord;
     const int x = int(tile % tiles_x) * kTileW + (wave & 1) * 8 + (lane & 7);
     const int lrow = int(tile / tiles_x) * kTileH + (wave >> 1) * 8 + int(row_in_tile);
-    const int lband = lrow / a.band.band_rows;
-    const int y = (lband * a.band.nranks + a.band.rank) * a.band.band_rows + (lrow - lband * a.band.band_rows);
+    const int y = frame_row(a.band, lrow);
     const bool active = x < a.band.width && lrow < a.band.local_rows && y < a.band.height && fb < batch;
     const unsigned cam_index = fb;   // per lane when kF > 1: the frames of a wave may have cameras of their own (vxrt_render_path)
 
@@ -516,8 +515,7 @@ __global__ __launch_bounds__(256) void count_culled_kernel(TraceArgs a, unsigned
     const int x = int(blockIdx.x * 64u + (threadIdx.x & 63u)), lrow = int(blockIdx.y * 4u + (threadIdx.x >> 6));
     bool culled = false;
     if (x < a.band.width && lrow < a.band.local_rows) {
-        const int lband = lrow / a.band.band_rows;
-        const int y = (lband * a.band.nranks + a.band.rank) * a.band.band_rows + (lrow - lband * a.band.band_rows);
+        const int y = frame_row(a.band, lrow);
         const f3 o = ld3(a.cam.o);
         const f3 d = norm3((float(x) * ld3(a.cam.r) - float(y) * ld3(a.cam.u)) + ld3(a.cam.f));  // voxels.comp:299-303
         culled = y < a.band.height && primary_miss_is_certain(a, o, d);

@@ -31,8 +31,7 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const TraceArgs a, cons
     zero_counts(zero, tid);
     const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
     const int lrow = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const int lband = lrow / a.band.band_rows;
-    const int y = (lband * a.band.nranks + a.band.rank) * a.band.band_rows + (lrow - lband * a.band.band_rows);
+    const int y = frame_row(a.band, lrow);
     const bool active = x < a.band.width && lrow < a.band.local_rows && y < a.band.height;
 
     bool keep = false;

@@ -27,9 +27,10 @@ def band_rows_for(radius, height=None, nranks=None, minimum=16):
     """Band height for the frame loop with a denoise window of `radius` (a multiple of 16: the denoise tiles; 16 without a window).
     Without a frame size: >= 8 radius, so that the halo is at most a quarter of the rows a rank owns.  With
     `height` and `nranks`: the candidate between 48 rows (three rows of tiles: one of them needs no neighbour, so the exchange has
-    work to hide behind) and 8 radius that leaves the busiest rank the fewest rows — bands are dealt whole, and e.g. 2160 rows in
-    64-row bands over 8 ranks give two ranks 320 rows and the others 256 (+ 18 % on the slowest), in 48-row bands 288 and 240;
-    ties go to the taller band (less halo)."""
+    work to hide behind) and 8 radius that leaves the busiest rank the fewest rows; ties go to the taller band (less halo).  Since
+    the last round of bands is dealt in shorter bands (BandLayout: every rank within one tile row of height / nranks) the candidates
+    differ by a tile row at most, and the tall band usually wins: 64 rows at radius 8 for 2160 rows on 8 ranks (272 rows on the
+    busiest rank, 270 would be even; round 3's whole-band deal: 288 with 48-row bands, 320 with 64)."""
     if radius <= 0:
         return minimum
     tall = max(minimum, (8 * radius + 15) // 16 * 16)
@@ -37,18 +38,18 @@ def band_rows_for(radius, height=None, nranks=None, minimum=16):
         return tall
     best = None
     for band in range(max(48, (4 * radius + 15) // 16 * 16), max(tall, 48) + 1, 16):
-        bands = (height + band - 1) // band
-        most = 0
-        for rank in range(nranks):
-            rows = sum(min(band, height - b * band) for b in range(rank, bands, nranks))
-            most = max(most, rows)
+        layout = BandLayout(1, height, nranks, band)
+        most = max(len(layout.rows(rank)) for rank in range(nranks))
         if best is None or most <= best[0]:
             best = (most, band)
     return best[1]
 
 
 class BandLayout:
-    """Row ownership and halo message layout; mirrors BandMap and csrc/api_halo.hip / csrc/halo_view.h."""
+    """Row ownership and halo message layout; mirrors BandMap (csrc/kernels.h) and csrc/api_halo.hip / csrc/halo_view.h.
+    Band gb -> rank gb % nranks.  Whole rounds of nranks bands are band_rows rows high (`full_bands` of them, rows [0, tail_y0));
+    what is left is one more round of bands `tail_rows` high — the smallest multiple of the tile height (16, or 8 for 8-row bands)
+    that covers the rest in nranks bands — so every rank owns within one tile row of height / nranks rows."""
 
     def __init__(self, width, height, nranks, band_rows=16, radius=None):
         # the library's rule (vxrt_create / check_render): bands are multiples of the tracer's 8-row tiles;
@@ -58,14 +59,38 @@ class BandLayout:
         if band_rows % 16 and (radius is None or radius > 0):
             raise ValueError("band_rows must be a multiple of 16 for a denoise radius > 0 (pass radius=0 for 8-row bands)")
         self.width, self.height, self.nranks, self.band_rows = width, height, nranks, band_rows
-        self.bands = (height + band_rows - 1) // band_rows
+        tile = 16 if band_rows % 16 == 0 else 8
+        self.full_bands = (height // (nranks * band_rows)) * nranks
+        self.tail_y0 = self.full_bands * band_rows
+        rest = height - self.tail_y0
+        self.tail_rows = band_rows if rest == 0 else ((rest + nranks - 1) // nranks + tile - 1) // tile * tile
+        self.bands = self.full_bands + (rest + self.tail_rows - 1) // self.tail_rows
+
+    def band_of_row(self, y):
+        return y // self.band_rows if y < self.tail_y0 else self.full_bands + (y - self.tail_y0) // self.tail_rows
+
+    def band_first_row(self, gb):
+        return gb * self.band_rows if gb < self.full_bands else self.tail_y0 + (gb - self.full_bands) * self.tail_rows
+
+    def band_nominal_rows(self, gb):
+        return self.band_rows if gb < self.full_bands else self.tail_rows
+
+    def band_rows_here(self, gb):
+        """Rows of band gb inside the frame."""
+        return min(self.band_nominal_rows(gb), self.height - self.band_first_row(gb))
+
+    def local_band_first_row(self, lb):
+        """First LOCAL row of a rank's lb-th band."""
+        r = self.full_bands // self.nranks
+        return lb * self.band_rows if lb < r else r * self.band_rows
 
     def owner(self, y):
-        return (y // self.band_rows) % self.nranks
+        return self.band_of_row(y) % self.nranks
 
     def rows(self, rank):
         y = np.arange(self.height)
-        return y[(y // self.band_rows) % self.nranks == rank]
+        band = np.where(y < self.tail_y0, y // self.band_rows, self.full_bands + (y - self.tail_y0) // self.tail_rows)
+        return y[band % self.nranks == rank]
 
     def local_bands(self, rank):
         return list(range(rank, self.bands, self.nranks))
@@ -74,8 +99,11 @@ class BandLayout:
         return (self.bands + self.nranks - 1) // self.nranks
 
     def halo_rows(self, radius, min_rows=1):
-        """Rows per band edge an exchange carries (vxrt_halo_info.rows)."""
-        return 0 if self.nranks < 2 else min(self.band_rows, max(radius, min_rows))
+        """Rows per band edge an exchange carries (vxrt_halo_info.rows): at most the lowest band."""
+        if self.nranks < 2:
+            return 0
+        lowest = self.tail_rows if self.tail_y0 < self.height else self.band_rows
+        return min(lowest, max(radius, min_rows))
 
     def plane(self, rows):
         """float4 per A / B plane of a message."""
@@ -101,11 +129,10 @@ class BandLayout:
         """Pixels this rank SENDS per exchange (both neighbours)."""
         n = 0
         for gb in self.local_bands(rank):
-            y0 = gb * self.band_rows
-            here = min(self.band_rows, self.height - y0)
+            y0, here, nominal = self.band_first_row(gb), self.band_rows_here(gb), self.band_nominal_rows(gb)
             if gb >= 1:
                 n += min(rows, here)
-            if here == self.band_rows and (gb + 1) * self.band_rows < self.height:
+            if here == nominal and y0 + nominal < self.height:
                 n += rows
         return n * self.width
 
@@ -113,17 +140,17 @@ class BandLayout:
         """(interior, edge): the rank's rows of 16x16 denoise tiles (index = local row // 16) whose window stays inside the rank's own
         rows, and those that read rows of a neighbour — a band's first tile row when a band lies above it, its last when one lies
         below (csrc/api_halo.hip: build_tile_rows)."""
-        interior, edge, t = [], [], 0
+        interior, edge = [], []
         if self.band_rows % 16:
             return interior, edge
-        for gb in self.local_bands(rank):
-            y0 = gb * self.band_rows
-            end = min(y0 + self.band_rows, self.height)
+        for lb, gb in enumerate(self.local_bands(rank)):
+            y0 = self.band_first_row(gb)
+            end = y0 + self.band_rows_here(gb)
+            t = self.local_band_first_row(lb) // 16
             for ty in range(y0, end, 16):
                 above = self.nranks > 1 and ty == y0 and y0 > 0
                 below = self.nranks > 1 and min(ty + 16, end) == end and end < self.height
                 (edge if above or below else interior).append(t + (ty - y0) // 16)
-            t += self.band_rows // 16
         return interior, edge
 
     def neighbours(self, rank):

@@ -94,7 +94,12 @@ typedef struct vxrt_config {
     const float* noise;       /* optional 512*128*128 floats in [0,1) (layout of shaders/voxels.comp:65-71) */
     uint32_t rank, nranks;    /* this context renders the row bands b with b % nranks == rank ...       */
     uint32_t band_rows;       /* ... where band b = rows [b*band_rows, (b+1)*band_rows); 0 -> 16.  A multiple of 8;
-                               * of 16 if the denoise stage runs with radius > 0 (its tiles are 16 rows).   */
+                               * of 16 if the denoise stage runs with radius > 0 (its tiles are 16 rows).
+                               * That holds for the whole ROUNDS of nranks bands; the rows left below them (fewer
+                               * than nranks * band_rows) are dealt as one more round of lower bands — the smallest
+                               * multiple of the tile height (16, or 8 for 8-row bands) that covers them in nranks
+                               * bands — so that every rank owns within one tile row of height / nranks rows.
+                               * vxrt_local_rows lists a context's rows; distributed.BandLayout states the rule.     */
                               /* nranks = 0 or 1 -> the whole frame                                     */
     uint32_t frames_in_flight;/* 0/1: every stage of a frame runs in submission order on one stream (the
                                  reference's single queue).  F = 2..16: the TRACE stage of up to F consecutive
@@ -155,7 +160,7 @@ typedef struct vxrt_stats {
     uint64_t octree_nodes;
     uint64_t wide_nodes;      /* records of the scene's two-levels-per-record form (16 bytes each); 0 unless VXRT_OPT_SCENE_FORMAT 1 */
     uint32_t scene_format;    /* which of the two the default tracer walks right now: 0 8-byte records, 1 wide records      */
-    uint32_t node_order;      /* 1: the scene in place has its bottom levels as treelets (VXRT_OPT_NODE_ORDER)            */
+    uint32_t node_order;      /* 2 / 3: the scene in place has its last 2 / 3 node levels as treelets (VXRT_OPT_NODE_ORDER)  */
     uint64_t queue_bytes;     /* device bytes of the tracer's path queues (sized by need for tracers 4 / 5)             */
     uint64_t queue_overflow_paths; /* paths that found their queue shard full and were followed by the head kernel
                                  instead (same image; the queues grow before the stream's next launch)               */
@@ -208,10 +213,11 @@ typedef struct vxrt_stats {
  *   VXRT_OPT_TAIL_SPLIT    create: bit k = the tail compacts once more at path segment k (default: 0x8 from 6 bounces on).
  *   VXRT_OPT_HOST_SCENE_BUILD  1: vxrt_set_menger builds the scene on the host also where the device builder could (cross-check).
  *   VXRT_OPT_NODE_ORDER    the order of the scene's 8-byte records in memory, chosen before the scene is set: 0 (default) breadth-first,
- *                          level after level; 1: for trees of depth >= 10 the last three node levels as depth-first treelets — a node of
- *                          level depth - 2 followed by its children and theirs (<= 584 bytes), so that the end of a descent stays in
- *                          one neighbourhood of memory (BASELINE config 5's scene lives in HBM).  Node indices never reach an output:
- *                          same image.  vxrt_stats.node_order reads 1 when the scene in place was reordered.
+ *                          level after level; 2 / 3: the last two / three node levels as depth-first treelets — below every node of
+ *                          level depth - 2 / depth - 3 its children as one block, then child by child their children's blocks
+ *                          (<= 576 bytes / <= 4.6 KB) — so that the end of a descent stays in one neighbourhood of memory (BASELINE
+ *                          config 5's scene lives in HBM).  Node indices never reach an output and the children of a node stay
+ *                          contiguous: same image, same walk code.  vxrt_stats.node_order reads what the scene in place has.
  *   VXRT_OPT_TRACER_OVERRIDE   create: the internal schedule past vxrt_config.tracer's automatic choice: 0 all-in-one kernel, 4 head +
  *                          compacted tail; 2 / 3 / 5 (-DVXRT_VARIANTS=1 builds) wavefront, ray queues, path kernel.
  *   VXRT_OPT_TRACE_SPLIT / PATH_BLOCKS / SHADE_BLOCKS / RAYS_PER_WAVE   create: launch shapes of tracers 2, 3 and 5.                    */

@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/c5_$tag
 mkdir -p $O
 cd /tmp
-for order in 0 1; do
+for order in 0 2 3; do
   export VXRT_NODE_ORDER=$order
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/o${order}_stats -- python3 $R/scripts/exp_config5.py 2048 > $O/o${order}_stats.txt 2> $O/o${order}_stats.err
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/o${order}_fetch -- python3 $R/scripts/exp_config5.py 2048 > $O/o${order}_fetch.txt 2> $O/o${order}_fetch.err
@@ -20,6 +20,6 @@ for order in 0 1; do
 done
 unset VXRT_NODE_ORDER
 cd $R
-python3 scripts/config5_summary.py $tag "o0=breadth-first records" "o1=treelets of the last three node levels" > $O/summary_stdout.txt
+python3 scripts/config5_summary.py $tag "o0=breadth-first records" "o2=treelets of the last two node levels" "o3=treelets of the last three node levels" > $O/summary_stdout.txt
 # keep the csv volume small: the merged-back directory is capped
 find $O -name "*.csv" -size +2M -delete

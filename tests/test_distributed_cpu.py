@@ -53,14 +53,15 @@ class OracleBandContext:
             C[slot, k] = accum[lrow, :, 3]
         vp, vn = self._view(to_prev), self._view(to_next)
         for lb, gb in enumerate(L.local_bands(self.rank)):
-            y0 = gb * L.band_rows
-            nrows = min(L.band_rows, L.height - y0)
+            y0, nominal = L.band_first_row(gb), L.band_nominal_rows(gb)
+            nrows = L.band_rows_here(gb)
+            l0 = L.local_band_first_row(lb)
             if gb >= 1:
                 for k in range(min(H, nrows)):
-                    put(vp, (gb - 1) // L.nranks, k, lb * L.band_rows + k)
-            if nrows == L.band_rows and (gb + 1) * L.band_rows < L.height:
+                    put(vp, (gb - 1) // L.nranks, k, l0 + k)
+            if nrows == nominal and y0 + nominal < L.height:
                 for k in range(H):
-                    put(vn, (gb + 1) // L.nranks, k, lb * L.band_rows + L.band_rows - H + k)
+                    put(vn, (gb + 1) // L.nranks, k, l0 + nominal - H + k)
 
     def halo_unpack(self, from_prev, from_next):
         self.log.append("unpack")
@@ -78,25 +79,26 @@ class OracleBandContext:
         du = O.Denoise.default()
         du.radius = r
         for lb, gb in enumerate(L.local_bands(self.rank)):
-            y0 = gb * L.band_rows
-            nrows = min(L.band_rows, L.height - y0)
+            y0, nominal = L.band_first_row(gb), L.band_nominal_rows(gb)
+            nrows = L.band_rows_here(gb)
+            l0 = L.local_band_first_row(lb)
             top, bot = max(y0 - r, 0), min(y0 + nrows + r, L.height)
             strip = [np.zeros((L.height, L.width, 4), np.float32) for _ in range(3)]   # full-frame canvas
             for im in range(3):
-                strip[im][y0:y0 + nrows] = self.imgs[im][lb * L.band_rows: lb * L.band_rows + nrows]
+                strip[im][y0:y0 + nrows] = self.imgs[im][l0: l0 + nrows]
             if flags != D.DENOISE_INTERIOR:     # the interior launch runs BEFORE the unpack: it must not need the halo
                 for side, ys in ((0, range(top, y0)), (1, range(y0 + nrows, bot))):
                     A, B, C = self.halo[side]
                     for y in ys:
-                        k = y - (y0 - H) if side == 0 else y - (y0 + L.band_rows)
+                        k = y - (y0 - H) if side == 0 else y - (y0 + nominal)
                         strip[0][y, :, :3] = A[lb, k, :, :3]; strip[0][y, :, 3] = C[lb, k]
                         strip[1][y, :, :3] = B[lb, k, :, :3]; strip[1][y, :, 3] = A[lb, k, :, 3]
                         strip[2][y, :, 3] = (B[lb, k, :, 3].view(np.int32) << 24).view(np.float32)   # only the material id is read
             den = O.denoise(strip[0], strip[1], strip[2], self.cam16, du, nthreads=2)
             for t in range(nrows // 16 + (1 if nrows % 16 else 0)):
-                if lb * (L.band_rows // 16) + t in chosen:
+                if l0 // 16 + t in chosen:
                     lo, hi = t * 16, min(t * 16 + 16, nrows)
-                    self.denoised[lb * L.band_rows + lo: lb * L.band_rows + hi] = den[y0 + lo:y0 + hi]
+                    self.denoised[l0 + lo: l0 + hi] = den[y0 + lo:y0 + hi]
 
 
 def _worker(rank, world, port, w, h, radius, band, overlap, q):
@@ -124,7 +126,8 @@ def _worker(rank, world, port, w, h, radius, band, overlap, q):
         mine = layout.rows(rank)
         color = np.zeros((h, w, 4), np.float32); nd = np.zeros_like(color); alb = np.zeros_like(color)
         for gb in layout.local_bands(rank):
-            y0, y1 = gb * band, min(gb * band + band, h)
+            y0 = layout.band_first_row(gb)
+            y1 = y0 + layout.band_rows_here(gb)
             c, n_, a, _ = O.trace(octree, noise, u, w, h, 3, crop=(0, y0, w, y1), nthreads=2)
             color[y0:y1], nd[y0:y1], alb[y0:y1] = c, n_, a
         accum = O.temporal(color, nd, np.zeros_like(color), np.zeros_like(nd), cam16, cam16, O.Temporal.default(), False, nthreads=2)
@@ -192,12 +195,35 @@ def test_band_layout_row_rule_is_the_librarys():
     D.BandLayout(1920, 1080, 8, 32, radius=8)
     # band height for the frame loop: >= 8 r without a frame size; with one, the candidate in [48, 8 r] that leaves the busiest rank fewest rows
     assert D.band_rows_for(0) == 16 and D.band_rows_for(2) == 16 and D.band_rows_for(8) == 64 and D.band_rows_for(3) == 32
-    assert D.band_rows_for(8, 2160, 8) == 48 and D.band_rows_for(8, 2160, 2) == 64 and D.band_rows_for(8, 2160, 1) == 64
+    assert D.band_rows_for(8, 2160, 8) == 64 and D.band_rows_for(8, 2160, 2) == 64 and D.band_rows_for(8, 2160, 1) == 64
     for radius, h, n in ((8, 2160, 8), (8, 2160, 4), (8, 1080, 8), (4, 2160, 3), (1, 720, 2)):
         band = D.band_rows_for(radius, h, n)
         assert band % 16 == 0 and 48 <= band <= max(64, 8 * radius)
         most = max(len(D.BandLayout(w := 64, h, n, band).rows(r)) for r in range(n))
         assert all(most <= max(len(D.BandLayout(w, h, n, other).rows(r)) for r in range(n)) for other in range(48, max(64, 8 * radius) + 1, 16))
+        assert most - h / n < 16 + 1e-9                      # within one tile row of an even deal (round 3 dealt whole bands: up to a band more)
+
+
+def test_band_layout_deals_the_last_round_in_shorter_bands():
+    """Whole rounds of nranks bands at band_rows rows, then one round of bands just high enough (a multiple of the tile height) to cover
+    the rest: every rank within one tile row of height / nranks, every row owned once, local rows in frame order, bands tile-aligned."""
+    from gpu_voxel_raytracer_amd import distributed as D
+    for h, n, band in ((2160, 8, 48), (2160, 8, 64), (2160, 4, 64), (2160, 3, 48), (200, 2, 16), (1080, 8, 8), (1080, 5, 32), (50, 2, 16), (4320, 8, 64), (37, 3, 16)):
+        L = D.BandLayout(7, h, n, band, radius=0 if band % 16 else None)
+        tile = 16 if band % 16 == 0 else 8
+        rows = [L.rows(r) for r in range(n)]
+        assert sorted(np.concatenate(rows).tolist()) == list(range(h))
+        counts = [len(r) for r in rows]
+        assert max(counts) - h / n < tile and L.tail_rows % tile == 0 and L.tail_rows <= band and L.full_bands % n == 0
+        for r in range(n):
+            assert (np.diff(rows[r]) > 0).all()
+            for lb, gb in enumerate(L.local_bands(r)):
+                y0 = L.band_first_row(gb)
+                assert L.owner(y0) == r and L.band_of_row(y0) == gb and L.band_of_row(y0 + L.band_rows_here(gb) - 1) == gb
+                assert L.local_band_first_row(lb) % tile == 0 and rows[r][L.local_band_first_row(lb)] == y0
+    L = D.BandLayout(7, 2160, 8, 48)
+    assert (L.full_bands, L.tail_y0, L.tail_rows, L.bands) == (40, 1920, 32, 48)
+    assert [len(L.rows(r)) for r in range(8)] == [272] * 7 + [256]
 
 
 def _bench(args, env):

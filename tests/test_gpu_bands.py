@@ -22,7 +22,10 @@ def hip():
 
 @pytest.mark.parametrize("nranks,w,h,radius,band,split", [(2, 128, 80, 3, 16, False), (3, 96, 100, 8, 16, True), (4, 160, 72, 1, 16, False),
                                                           (8, 64, 200, 8, 16, False), (5, 80, 40, 2, 16, True), (2, 100, 300, 8, 64, True),
-                                                          (3, 64, 250, 4, 32, True), (2, 72, 130, 8, 48, False)])
+                                                          (3, 64, 250, 4, 32, True), (2, 72, 130, 8, 48, False),
+                                                          # the last round in shorter bands (kernels.h: BandMap): 3 tail bands of 32 rows below one
+                                                          # round of 48-row bands; two 16-row tail bands for four ranks (two of them get none)
+                                                          (3, 64, 240, 8, 48, True), (4, 96, 224, 4, 48, False), (8, 64, 432, 8, 48, True)])
 def test_bands_and_halo_equal_single_context(H, scenes, noise, nranks, w, h, radius, band, split):
     """split: the denoise stage in two launches around the exchange (DENOISE_INTERIOR before the unpack, DENOISE_EDGE after)."""
     from gpu_voxel_raytracer_amd import ALL, DENOISE, DENOISE_EDGE, DENOISE_INTERIOR, TEMPORAL, TRACE, Camera, Context
@@ -45,6 +48,9 @@ def test_bands_and_halo_equal_single_context(H, scenes, noise, nranks, w, h, rad
             rows = [c.local_rows() for c in ctxs]
             assert sorted(np.concatenate(rows).tolist()) == list(range(h))          # a partition of the frame
             layout = BandLayout(w, h, nranks, band)
+            for r in range(nranks):                                                # ... the one distributed.BandLayout states,
+                assert np.array_equal(rows[r], layout.rows(r))
+            assert max(len(x) for x in rows) - h / nranks < 16                      # every rank within a tile row of an even share
             for r, c in enumerate(ctxs):      # the message layout and the tile split as distributed.py states them
                 info = c.halo_info()
                 interior, edge = layout.tile_rows(r)

@@ -57,14 +57,15 @@ def test_config3_full_size_pipeline(O, H, scenes, noise):
 
 def test_config4_eight_ranks_with_halo_at_4k(O, H, scenes, noise):
     """BASELINE configs[3] as this build defines it (BASELINE names no bounce count): castle at 3840x2160, 4 spp,
-    8 bounces, temporal + denoise r = 8 on 8 ranks, 48-row interleaved bands (distributed.band_rows_for: between 48 rows and 8 r, the
-    height that leaves the busiest rank fewest rows — 288 of 2160 instead of 320 with 64-row bands), the denoise stage split around
-    the halo exchange."""
+    8 bounces, temporal + denoise r = 8 on 8 ranks, 64-row interleaved bands (distributed.band_rows_for: 8 r; since round 4 the last
+    round of bands is dealt in shorter ones — here 7 bands of 16 rows below 32 of 64 — so the busiest rank owns 272 of 2160 rows,
+    270 being even; round 3's whole-band deal gave it 288 with 48-row bands and 320 with 64), the denoise stage split around the
+    halo exchange."""
     from gpu_voxel_raytracer_amd import ALL, DENOISE_EDGE, DENOISE_INTERIOR, TEMPORAL, TRACE, Camera, Context
     from gpu_voxel_raytracer_amd.distributed import band_rows_for
     w, h, bounces, radius, nranks = 3840, 2160, 8, 8, 8
     band = band_rows_for(radius, h, nranks)
-    assert band == 48 and band_rows_for(radius) == 64
+    assert band == 64 and band_rows_for(radius) == 64
     pos, mrgb, size = scenes.load_scene("castle")
     cam = Camera(*scenes.close_camera(size))
     cam_tuple = scenes.close_camera(size)
@@ -83,10 +84,10 @@ def test_config4_eight_ranks_with_halo_at_4k(O, H, scenes, noise):
                 setup(c)
             rows = [c.local_rows() for c in ctxs]
             info = ctxs[0].halo_info()
-            # 45 bands of 48 rows over 8 ranks: 6 slots x 8 rows x 3840 px x 36 B = 6.6 MB per message, two messages per rank and frame
-            assert (info.rows, info.slots) == (8, 6) and info.message_bytes <= 6 * 8 * 3840 * 36 + 256 and 2 * info.message_bytes <= 15e6
-            assert info.edge_tile_rows >= info.interior_tile_rows > 0            # one of a band's three tile rows needs no neighbour
-            assert max(len(r) for r in rows) == 288
+            # 32 bands of 64 rows + 7 of 16 over 8 ranks: 5 slots x 8 rows x 3840 px x 36 B = 5.5 MB per message, two per rank and frame
+            assert (info.rows, info.slots) == (8, 5) and info.message_bytes <= 5 * 8 * 3840 * 36 + 256 and 2 * info.message_bytes <= 12e6
+            assert info.interior_tile_rows >= info.edge_tile_rows - 1 > 0        # two of a 64-row band's four tile rows need no neighbour
+            assert [len(r) for r in rows] == [272] * 7 + [256]
             for frame in range(2):
                 single.render_spp(ALL, 4)
                 for c in ctxs:
@@ -113,7 +114,7 @@ def test_config4_eight_ranks_with_halo_at_4k(O, H, scenes, noise):
                     got[rr] = c.read(img)
                 assert_bits_equal(got, want, f"config 4 image {img}, 8 ranks at 4K")
             assert sum(c.stats().rays for c in ctxs) == single.stats().rays
-            assert max(len(r) for r in rows) - min(len(r) for r in rows) <= band
+            assert max(len(r) for r in rows) - min(len(r) for r in rows) <= 16
             # and the frame the ranks agree on is the oracle's: the second displayed frame's 4-sample mean (frames 5..8), first hit
             # and accumulated colour on three 16-row strips that straddle band edges of different ranks
             octree = O.create_octree(pos, mrgb)

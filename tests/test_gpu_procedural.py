@@ -123,42 +123,50 @@ def _levels(svo, depth):
     return out
 
 
-def test_treelet_node_order_is_the_same_tree_and_the_same_image(H, O, noise):
-    """VXRT_OPT_NODE_ORDER 1 (csrc/scene_device.hip: reorder_bottom_treelets): the records of the last three node levels as depth-first
-    treelets.  Same tree — followed from the root, every level holds the same masks in the same order and the leaf parents the same
-    leaf-word bases — every node of level depth - 2 is directly followed by its whole subtree, the device-built and the host-built scene
-    are still byte-identical, and the frames (colour, normal / depth, leaf words, ray count) are bit-equal to the breadth-first order's.
-    A voxel-list scene of depth 10 goes the same way (vxrt_set_voxels -> the host builder -> the same device pass)."""
+@pytest.mark.parametrize("order", [2, 3])
+def test_treelet_node_order_is_the_same_tree_and_the_same_image(H, O, noise, order):
+    """VXRT_OPT_NODE_ORDER 2 / 3 (csrc/scene_device.hip: reorder_bottom_treelets): the records of the last two / three node levels as
+    depth-first treelets.  Same tree — followed from the root, every level holds the same masks in the same order and the leaf parents
+    the same leaf-word bases — all descendants of a node of level depth - order lie in one run of memory right where its base points,
+    the device-built and the host-built scene are still byte-identical, and the frames (colour, normal / depth, leaf words, ray count)
+    are bit-equal to the breadth-first order's.  A voxel-list scene of depth 10 goes the same way (vxrt_set_voxels -> the host builder
+    -> the same device pass)."""
     from gpu_voxel_raytracer_amd import TRACE, Camera, Context
     from gpu_voxel_raytracer_amd.host import OPT_HOST_SCENE_BUILD, OPT_NODE_ORDER
     level, clip, period, mrgb = 6, 0, 997, (0, 150, 170, 120)     # 729^3: depth 10
     f32 = np.float32
     cam = (np.array([-300, 500, -420], f32), np.array([0.9, -0.6, 1.2], f32), 1.0)
     got = {}
-    for order, host_build in ((0, 0), (1, 0), (1, 1)):
-        with Context(320, 192, max_bounces=4, noise=noise, tuning=[(OPT_NODE_ORDER, order), (OPT_HOST_SCENE_BUILD, host_build)]) as ctx:
+    for o, host_build in ((0, 0), (order, 0), (order, 1)):
+        with Context(320, 192, max_bounces=4, noise=noise, tuning=[(OPT_NODE_ORDER, o), (OPT_HOST_SCENE_BUILD, host_build)]) as ctx:
             ctx.set_menger(level, clip, mrgb, period)
             ctx.camera = Camera(*cam)
             ctx.render(TRACE)
             st = ctx.stats()
-            assert st.node_order == order and st.octree_depth == 10
-            got[(order, host_build)] = (ctx.read_scene(), [ctx.read(i) for i in range(3)], st.rays)
+            assert st.node_order == o and st.octree_depth == 10
+            got[(o, host_build)] = (ctx.read_scene(), [ctx.read(i) for i in range(3)], st.rays)
     (svo0, lw0), img0, rays0 = got[(0, 0)]
-    (svo1, lw1), img1, rays1 = got[(1, 0)]
-    (svo1h, lw1h), _, _ = got[(1, 1)]
+    (svo1, lw1), img1, rays1 = got[(order, 0)]
+    (svo1h, lw1h), _, _ = got[(order, 1)]
     assert np.array_equal(svo1, svo1h) and np.array_equal(lw1, lw1h)                    # device builder == host builder, reordered alike
     assert np.array_equal(lw0, lw1) and svo0.shape == svo1.shape and not np.array_equal(svo0, svo1)
     a, b = _levels(svo0, 10), _levels(svo1, 10)
     for level_no, ((ia, ma), (ib, mb)) in enumerate(zip(a, b)):
         assert np.array_equal(ma, mb), level_no
     assert np.array_equal(svo0[a[10][0], 1], svo1[b[10][0], 1])                          # leaf parents: the same first leaf word
-    assert np.array_equal(a[7][0], b[7][0])                                             # levels 0 .. 7 did not move
-    roots = b[8][0]                                                                      # level depth - 2: each followed by its subtree
-    assert (svo1[roots, 1] == roots + 1).all()
-    sizes = np.diff(np.append(roots, len(svo1)))
-    assert sizes.max() <= 73 and (np.sort(roots) == roots).all()
-    kids = b[9][0]                                                                       # a child's children start right after its siblings' ...
-    assert ((svo1[kids, 1] > kids) & (svo1[kids, 1] <= kids + 72)).all()
+    top = 10 - order                                                                     # the treelets' parents: they and everything above stay put
+    assert np.array_equal(a[top][0], b[top][0])
+    # every record below `top` belongs to exactly one treelet, and a parent's treelet is the run [base, next parent's base)
+    parents = b[top][0]
+    starts = svo1[parents, 1].astype(np.int64)
+    assert (np.diff(starts) > 0).all() and starts[0] == a[top + 1][0][0]
+    sizes = np.diff(np.append(starts, len(svo1)))
+    assert sizes.max() <= (8 + 64 + 512 if order == 3 else 8 + 64)
+    below = np.sort(np.concatenate([b[l][0] for l in range(top + 1, 11)]))
+    assert np.array_equal(below, np.arange(starts[0], len(svo1)))
+    for l in range(top + 1, 11):                                                         # each level's nodes fall into their own ancestor's run
+        owner = np.searchsorted(starts, b[l][0], side="right") - 1
+        assert (np.diff(owner) >= 0).all()
     for x, y, name in zip(img0, img1, ("colour", "normal / depth", "albedo / leaf word")):
         assert_bits_equal(x, y, name)
     assert rays0 == rays1 and (img0[1][..., 3] >= 0).mean() > 0.2
@@ -168,12 +176,12 @@ def test_treelet_node_order_is_the_same_tree_and_the_same_image(H, O, noise):
     m = rng.integers(0, 256, (len(pos), 4)).astype(np.uint8)
     cam = (np.array([150, 260, 120], f32), np.array([0.4, -0.3, 0.6], f32), 1.1)
     frames = []
-    for order in (0, 1):
-        with Context(256, 160, max_bounces=3, noise=noise, tuning=[(OPT_NODE_ORDER, order)]) as ctx:
+    for o in (0, order):
+        with Context(256, 160, max_bounces=3, noise=noise, tuning=[(OPT_NODE_ORDER, o)]) as ctx:
             ctx.recreate_octree(pos, m)
             ctx.camera = Camera(*cam)
             ctx.render(TRACE)
-            assert ctx.stats().node_order == order
+            assert ctx.stats().node_order == o
             frames.append(([ctx.read(i) for i in range(3)], ctx.stats().rays))
     for x, y in zip(frames[0][0], frames[1][0]):
         assert_bits_equal(x, y, "voxel-list scene")
