@@ -160,8 +160,6 @@ int vxrt_render(vxrt_ctx* c, uint32_t flags) try {
     return VXRT_OK;
 } VXRT_CATCH
 
-// `count` frames with the parameters at rest.  With vxrt_config.frames_per_launch = B > 1 the trace stage of up to B
-// consecutive frames is one launch (see trace_frames); temporal / denoise then run per frame, in frame order.
 // `count` frames; frame k through camera pose k of `path_pos` / `path_dir` (null: the camera at rest), one launch per `batch` frames
 static int render_sequence(vxrt_ctx* c, uint32_t flags, uint32_t count, const float (*path_pos)[3], const float (*path_dir)[3]) {
     const bool timed = (flags & VXRT_TIMED) != 0;

@@ -671,7 +671,6 @@ inline size_t caster_lds_bytes(const TraceArgs& a, bool wide, int threads) {
 __device__ __forceinline__ void zero_counts(unsigned* counts, int tid) {
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid < int(kShards)) {
         counts[tid * kCountStride] = 0u;
-        if (tid == 0) counts[1] = 0u;   // the chunk cursor of a consumer that hands chunks out dynamically (trace_tail.hip)
     }
 }
 
