@@ -308,6 +308,16 @@ __device__ __forceinline__ int walkf_step(WalkF& w, const SceneView& sc, uint2* 
         if (too_far | leaf) return too_far ? kWalkMiss : kWalkLeaf;
     }
 
+#ifndef VXRT_EARLY_FETCH
+#define VXRT_EARLY_FETCH 0   // experiment: ask for the child's record before the sibling search, so that the search runs under the load
+#endif
+#if VXRT_EARLY_FETCH
+    uint2 early = make_uint2(0u, 0u);
+    if ((w.rec.masks & bit) != 0u) {
+        early = *reinterpret_cast<const uint2*>(sc.svo + (w.rec.base + __popc(w.rec.masks & (bit - 1u))));
+        asm volatile("" ::: "memory");   // the load is issued here (nothing that touches memory moves across), waited for where it is used
+    }
+#endif
     const f3 tm = (w.center - w.o) * w.inv;                  // voxels.comp:191
     const uint32_t directional = w.octant ^ w.dir_mask;
     const bool far_x = (directional & 4u) != 0u, far_y = (directional & 2u) != 0u, far_z = (directional & 1u) != 0u;
@@ -318,6 +328,9 @@ __device__ __forceinline__ int walkf_step(WalkF& w, const SceneView& sc, uint2* 
     const uint32_t transition = (mx == next_time) ? 4u : ((my == next_time) ? 2u : 1u);
     const bool has_next = next_time <= w.exit && (directional & transition) == 0u;
     const bool is_child = (w.rec.masks & bit) != 0u;         // value > 0
+#if VXRT_EARLY_FETCH
+    (void)is_child;
+#endif
 
     if (is_child || !has_next) {
         uint2 raw;
@@ -326,7 +339,11 @@ __device__ __forceinline__ int walkf_step(WalkF& w, const SceneView& sc, uint2* 
                 stack[w.lvl * kStackStride] = make_uint2(w.rec.masks | (w.octant ^ transition) << 16, w.rec.base);
                 w.has_next_mask |= 1u << w.lvl;
             }
+#if VXRT_EARLY_FETCH
+            raw = early;
+#else
             raw = *reinterpret_cast<const uint2*>(sc.svo + (w.rec.base + __popc(w.rec.masks & (bit - 1u))));
+#endif
             w.ix = (w.ix << 1) | ((w.octant >> 2) & 1u);
             w.iy = (w.iy << 1) | ((w.octant >> 1) & 1u);
             w.iz = (w.iz << 1) | (w.octant & 1u);
