@@ -69,11 +69,13 @@ VX_BAND_FN int local_band_first_row(const BandMap& b, int lb) { const int r = b.
 VX_BAND_FN int local_band_of(const BandMap& b, int lrow) { const int r = b.full_bands / b.nranks; return lrow < r * b.band_rows ? lrow / b.band_rows : r; }
 // frame row -> local row of this context, or -1 when another rank owns it; and back
 VX_BAND_FN int local_row(const BandMap& b, int y) {
+    if (b.nranks == 1) return y;               // one context: the identity (a uniform branch past two integer divisions)
     const int gb = band_of_row(b, y);
     if (gb % b.nranks != b.rank) return -1;
     return local_band_first_row(b, gb / b.nranks) + (y - band_first_row(b, gb));
 }
 VX_BAND_FN int frame_row(const BandMap& b, int lrow) {
+    if (b.nranks == 1) return lrow;
     const int lb = local_band_of(b, lrow);
     return band_first_row(b, lb * b.nranks + b.rank) + (lrow - local_band_first_row(b, lb));
 }
