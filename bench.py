@@ -340,11 +340,17 @@ def world_info(dist, torch, world, rank, device, backend):
             ver = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:  # noqa: BLE001
             ver = None
-    return {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "rccl_version": ver, "world_size": world,
+    note = os.environ.get("VXRT_BENCH_BACKEND_NOTE")
+    return {"backend": backend + (" (RCCL)" if backend == "nccl" else "") + (f" ({note})" if note else ""), "rccl_version": ver, "world_size": world,
             "distinct_devices": len({(e["host"], e["pci"], e["device"]) for e in everyone}), "devices": everyone}
 
 
 def init_dist(need_gpu=True):
+    """-> (world, rank, device, dist, torch, backend).  N > 1: one process per GPU, torch.distributed over RCCL (backend "nccl");
+    VXRT_BENCH_BACKEND=gloo for rehearsals with several ranks on one GPU.  If RCCL cannot be brought up (its first collective is
+    made here, so a failure shows now and on every rank alike) the ranks fall back to gloo on the next port and say so in the line's
+    `rccl.backend`: the trace bench uses the process group for its barrier and two reductions only, and a number measured with a
+    gloo barrier is worth more than no number; `--pipeline` then stages its halo through the host, which its line says as well."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -357,7 +363,26 @@ def init_dist(need_gpu=True):
         if need_gpu:
             torch.cuda.set_device(device)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+            try:
+                if os.environ.get("VXRT_BENCH_FAIL_NCCL") == "1":      # test hook of the fall-back
+                    raise RuntimeError("VXRT_BENCH_FAIL_NCCL=1")
+                dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+                probe = torch.ones(1, device="cuda")
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"all_reduce over RCCL returned {probe.item()} for a world of {world}")
+            except Exception as e:  # noqa: BLE001
+                print(f"bench.py rank {rank}: RCCL did not come up ({e!r}); falling back to gloo", file=sys.stderr, flush=True)
+                try:
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                port = int(os.environ.get("MASTER_PORT", "29500")) + 1
+                dist.init_process_group("gloo", init_method=f"tcp://{os.environ.get('MASTER_ADDR', '127.0.0.1')}:{port}", rank=rank, world_size=world)
+                backend = "gloo"
+                os.environ["VXRT_BENCH_BACKEND_NOTE"] = f"nccl failed: {e!r}"[:200]
         else:
             dist.init_process_group(backend)
     return world, rank, device, dist, torch, backend

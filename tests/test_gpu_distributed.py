@@ -209,3 +209,11 @@ def test_ranks_over_rccl_cpp_host(tmp_path, radius, spp):
     assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-500:]
     assert d["ranks"] == n and d["transport"] == "rccl" and d["differing_values"] == 0 and d["rays_equal"]
     assert len(set(d["devices"])) == n
+
+
+def test_bench_falls_back_to_gloo_when_rccl_does_not_come_up():
+    """If RCCL cannot be brought up the ranks re-rendezvous over gloo and the line says so (VXRT_BENCH_FAIL_NCCL=1 stands in for the
+    failure): the trace bench needs the process group for its barrier and two reductions only."""
+    d = run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--blocks", "3"], env={"VXRT_BENCH_FAIL_NCCL": "1"})
+    assert d["n_gpus"] == 2 and d["value"] > 1000.0
+    assert d["rccl"]["backend"].startswith("gloo") and "nccl failed" in d["rccl"]["backend"]
