@@ -217,3 +217,12 @@ def test_bench_falls_back_to_gloo_when_rccl_does_not_come_up():
     d = run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--blocks", "3"], env={"VXRT_BENCH_FAIL_NCCL": "1"})
     assert d["n_gpus"] == 2 and d["value"] > 1000.0
     assert d["rccl"]["backend"].startswith("gloo") and "nccl failed" in d["rccl"]["backend"]
+
+
+@pytest.mark.skipif(gpu_count() != 1, reason="needs exactly one GPU: two ranks on it make RCCL refuse (duplicate GPU)")
+def test_bench_survives_a_real_rccl_failure():
+    """Two ranks on this box's one GPU over the default backend: ncclCommInitRank fails on both ("Duplicate GPU detected"), the ranks
+    re-rendezvous over gloo on the next port and the line still comes, saying what happened."""
+    d = run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--blocks", "3"], env={"VXRT_BENCH_SPAWN_TIMEOUT": "300"})
+    assert d["n_gpus"] == 2 and d["value"] > 1000.0
+    assert d["rccl"]["backend"].startswith("gloo") and "nccl failed" in d["rccl"]["backend"]
