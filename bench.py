@@ -127,6 +127,76 @@ def measure_config3(Context, Camera, ALL, TIMED, scenes, device, shown=12):
     return out
 
 
+def measure_config4_rank(Context, Camera, flags, scenes, device, rank=0, nranks=8, shown=12):
+    """BASELINE configs[3] seen from ONE of its 8 ranks, alone on this GPU: vox/castle.vox 3840x2160, 4 spp, 8 bounces, temporal +
+    denoise r = 8, the rank's whole loop — trace + temporal, halo pack, denoise of the interior tiles, halo unpack, denoise of the edge
+    tiles — with 64-row bands (distributed.band_rows_for).  No transfer: the two messages it unpacks were packed once, before the timed
+    loop, by contexts of its two neighbour ranks (real rows of the right ranks, one frame old).  What a rank of the 8-GPU job has to do
+    per displayed frame, not a measurement of the job."""
+    import ctypes as C
+    TRACE, TEMPORAL, TIMED, INTERIOR, EDGE = flags
+    from gpu_voxel_raytracer_amd import distributed
+    w, h, spp, bounces, radius = 3840, 2160, 4, 8, 8
+    band = distributed.band_rows_for(radius, h, nranks)
+    pos, mrgb, size = scenes.load_scene("castle")
+    cam = Camera(*scenes.close_camera(size))
+    rt = C.CDLL("libamdhip64.so")
+    rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    rt.hipFree.argtypes = [C.c_void_p]
+    bufs = {}
+
+    def make(r, inflight):
+        ctx = Context(w, h, device=device, max_bounces=bounces, rank=r, nranks=nranks, band_rows=band, frames_in_flight=inflight, frames_per_launch=spp)
+        ctx.recreate_octree(pos, mrgb)
+        ctx.camera = cam
+        ctx.denoise_uniforms.radius = radius
+        n = ctx.halo_bytes()
+        pair = (C.c_void_p(), C.c_void_p())
+        for b in pair:
+            if rt.hipMalloc(C.byref(b), n) != 0:
+                raise RuntimeError("hipMalloc of a halo message failed")
+        bufs[r] = pair
+        return ctx
+
+    try:
+        for r in ((rank - 1) % nranks, (rank + 1) % nranks):        # the neighbours' messages, once
+            with make(r, 1) as nb:
+                nb.render_spp(TRACE | TEMPORAL, spp)
+                nb.halo_export(bufs[r][0].value, bufs[r][1].value)
+        with make(rank, 2) as ctx:
+            from_prev, from_next = bufs[(rank - 1) % nranks][1].value, bufs[(rank + 1) % nranks][0].value
+
+            def frame(extra=0):
+                ctx.render_spp(TRACE | TEMPORAL | extra, spp)
+                ctx.halo_pack(bufs[rank][0].value, bufs[rank][1].value)
+                ctx.render_stage(INTERIOR | extra)
+                ctx.halo_unpack(from_prev, from_next)
+                ctx.render_stage(EDGE | extra)
+            for _ in range(3):
+                frame()
+            ctx.sync()
+            ctx.reset_stats()
+            t0 = time.perf_counter()
+            for _ in range(shown):
+                frame(TIMED)
+            ctx.sync()
+            dt = (time.perf_counter() - t0) / shown
+            st, info = ctx.stats(), ctx.halo_info()
+            return {"workload": f"vox/castle.vox {w}x{h}, {spp} spp, {bounces} bounces, temporal + denoise r={radius} (BASELINE configs[3]): rank {rank} of "
+                                f"{nranks} alone on this GPU, {band}-row bands (the last round lower: {st.local_rows} of {h} rows), its whole loop without "
+                                f"transfer time; {shown} displayed frames after 3 of warm-up",
+                    "ms_per_displayed_frame": round(dt * 1e3, 4), "gray_per_s_this_rank": round(st.rays / shown / dt / 1e9, 2),
+                    "local_rows": int(st.local_rows), "halo_bytes_per_rank_per_frame": 2 * int(info.message_bytes), "halo_rows": int(info.rows),
+                    "interior_tile_rows": int(info.interior_tile_rows), "edge_tile_rows": int(info.edge_tile_rows),
+                    "stage_ms": {"trace": round(st.trace_ms / shown, 4), "temporal": round(st.temporal_ms / shown, 4), "denoise": round(st.denoise_ms / shown, 4),
+                                 "halo_pack": round(st.halo_pack_ms / max(st.halo_exchanges, 1), 5), "halo_unpack": round(st.halo_unpack_ms / max(st.halo_exchanges, 1), 5)}}
+    finally:
+        for pair in bufs.values():
+            for b in pair:
+                if b.value:
+                    rt.hipFree(b)
+
+
 def cpu_baseline(pos, mrgb, cam, target_seconds=float(os.environ.get("VXRT_BENCH_CPU_SECONDS", "8"))):
     """The CPU oracle (restatement of shaders/voxels.comp, oracle/oshaders.cpp) timed on this host's cores on
     whole frames of the same workload: a reported baseline, not the target."""
@@ -599,6 +669,11 @@ def trace_bench(args):
                     extra["config3_pipeline"] = measure_config3(Context, Camera, ALL, TIMED, scenes, device)
                 except Exception as e:  # noqa: BLE001
                     extra["config3_pipeline"] = {"error": repr(e)}
+                try:
+                    from gpu_voxel_raytracer_amd import DENOISE_EDGE, DENOISE_INTERIOR, TEMPORAL
+                    extra["config4_one_rank_of_8"] = measure_config4_rank(Context, Camera, (TRACE, TEMPORAL, TIMED, DENOISE_INTERIOR, DENOISE_EDGE), scenes, device)
+                except Exception as e:  # noqa: BLE001
+                    extra["config4_one_rank_of_8"] = {"error": repr(e)}
             out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pos, mrgb, cam)

@@ -65,8 +65,8 @@ def load_into(ctx, scene, whole_scene=False):
 def run(scene="menger", width=1280, height=720, frames=16, bounces=3, radius=0, moving=False, out=None, device=0,
         frames_in_flight=1, dump_every=0, noise="white", spp=1, whole_scene=False, float_dump=False):
     """Renders `frames` frames; returns the last denoised frame (float32 [h, w, 4]) and the context statistics.
-    float_dump: also write the frame losslessly as <out>.npy (float32 [h, w, 4], linear radiance as denoise.comp stores it) — the
-    lossless counterpart of the 8-bit sRGB PNG (SURVEY.md 8f n1 asks for PNG / EXR; no EXR writer is available here)."""
+    float_dump: also write the frame losslessly as <out>.exr (OpenEXR, 32-bit float, save_exr) and <out>.npy (float32 [h, w, 4]):
+    linear radiance as denoise.comp stores it — the lossless counterparts of the 8-bit sRGB PNG (PNG / EXR)."""
     from . import host
     with Context(width, height, device=device, max_bounces=bounces, frames_in_flight=frames_in_flight,
                  frames_per_launch=min(max(spp, 1), 32) if spp > 1 else min(max(frames, 1), 16)) as ctx:
@@ -99,7 +99,37 @@ def run(scene="menger", width=1280, height=720, frames=16, bounces=3, radius=0, 
         save_png(img, out + ".png")
         if float_dump:
             np.save(out + ".npy", np.ascontiguousarray(img, np.float32))
+            save_exr(img, out + ".exr")
     return img, st
+
+
+def save_exr(img, path):
+    """The frame as an OpenEXR file (SURVEY.md 8f n1 asks for PNG / EXR): linear radiance, 32-bit float channels A, B, G, R, one
+    uncompressed scan line per block, written from the file-layout document of OpenEXR 2 with numpy (no EXR library is in this image).
+    img: float32 [h, w, 4] = (r, g, b, a) as denoise.comp stores it."""
+    import struct
+    img = np.ascontiguousarray(img, np.float32)
+    h, w = img.shape[:2]
+
+    def attr(name, kind, value):
+        return name.encode() + b"\0" + kind.encode() + b"\0" + struct.pack("<i", len(value)) + value
+    chlist = b"".join(c + b"\0" + struct.pack("<iB3xii", 2, 0, 1, 1) for c in (b"A", b"B", b"G", b"R")) + b"\0"   # pixel type 2 = FLOAT
+    window = struct.pack("<4i", 0, 0, w - 1, h - 1)
+    header = (struct.pack("<ii", 20000630, 2) + attr("channels", "chlist", chlist) + attr("compression", "compression", b"\0") +
+              attr("dataWindow", "box2i", window) + attr("displayWindow", "box2i", window) + attr("lineOrder", "lineOrder", b"\0") +
+              attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<2f", 0.0, 0.0)) +
+              attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0")
+    row_bytes = 4 * w * 4
+    first = len(header) + 8 * h
+    offsets = (first + np.arange(h, dtype=np.uint64) * np.uint64(8 + row_bytes)).astype("<u8")
+    planes = np.ascontiguousarray(img[:, :, [3, 2, 1, 0]].transpose(0, 2, 1)).astype("<f4")      # [row][A, B, G, R][x]
+    os.makedirs(os.path.dirname(os.path.abspath(path)) or ".", exist_ok=True)
+    with open(path, "wb") as f:
+        f.write(header)
+        f.write(offsets.tobytes())
+        for y in range(h):
+            f.write(struct.pack("<ii", y, row_bytes))
+            f.write(planes[y].tobytes())
 
 
 def save_png(img, path):
@@ -121,7 +151,7 @@ def main():
     ap.add_argument("--noise", default="white", help="white (seeded stand-in), blue (void-and-cluster, made on the GPU) or an archive")
     ap.add_argument("--spp", type=int, default=1, help="samples per pixel per displayed frame (vxrt_render_spp)")
     ap.add_argument("--whole-scene", action="store_true", help="place every model of a .vox file's scene graph")
-    ap.add_argument("--float-dump", action="store_true", help="also write <out>.npy: the frame as float32 [h, w, 4], lossless")
+    ap.add_argument("--float-dump", action="store_true", help="also write <out>.exr (OpenEXR, float32) and <out>.npy: the frame as linear radiance, lossless")
     ap.add_argument("--out", default="gpurun_out/frame")
     args = ap.parse_args()
     img, st = run(args.scene, args.width, args.height, args.frames, args.bounces, args.radius, args.moving, args.out,

@@ -239,7 +239,10 @@ def test_headless_frame_loop(H, scenes, tmp_path):
     img, st = frame_loop.run("castle", 160, 96, frames=6, bounces=3, radius=1, moving=True, out=out, dump_every=3, float_dump=True)
     assert img.shape == (96, 160, 4) and np.isfinite(img).all() and st.frames == 6
     assert os.path.exists(out + ".png") and os.path.exists(out + "_0003.png") and os.path.exists(out + "_0006.png")
-    assert np.array_equal(np.load(out + ".npy"), img)          # the lossless dump
+    assert np.array_equal(np.load(out + ".npy"), img)          # the lossless dumps
+    from test_host_logic import read_exr_uncompressed
+    planes, _ = read_exr_uncompressed(out + ".exr")
+    assert np.array_equal(np.stack([planes[c] for c in "RGBA"], -1).view(np.uint32), img.view(np.uint32))
     # converged static view is less noisy than a single frame
     one, _ = frame_loop.run("castle", 160, 96, frames=1, bounces=3)
     many, _ = frame_loop.run("castle", 160, 96, frames=24, bounces=3)
@@ -306,6 +309,9 @@ def test_bench_contract_line():
         assert e["roofline"]["algorithmic_bytes_per_displayed_frame"] == ((48 + 16) * 4 + 16 + 80 + 64) * 3840 * 2160
     assert c3["radius_8"]["ms_per_displayed_frame"] > c3["radius_2"]["ms_per_displayed_frame"]
     assert 0.3 < c3["radius_8"]["denoise_valu"]["issue_slot_frac"] < 1.0 and "RECORDED" in c3["radius_8"]["denoise_valu"]["source"]
+    c4 = d["extra"]["config4_one_rank_of_8"]      # BASELINE configs[3]: what one of its 8 ranks does per displayed frame
+    assert c4["local_rows"] == 272 and c4["halo_rows"] == 8 and 10e6 < c4["halo_bytes_per_rank_per_frame"] < 12e6
+    assert 0.2 < c4["ms_per_displayed_frame"] < 5 and c4["stage_ms"]["halo_pack"] > 0 and c4["stage_ms"]["denoise"] > 0
     c5 = d["extra"]["config5_outside_view"]["roofline"]
     assert c5["bound"] == "hbm" and c5["frac_raw"] < c5["frac_read_doubled"] < 1.0 and "RECORDED" in c5["source"]
     r = d["roofline"]

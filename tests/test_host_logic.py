@@ -228,3 +228,60 @@ def test_wide_records_hold_the_voxel_set(H, scenes, case):
     assert [(x, y, z) for x, y, z, _ in got] == sorted(want)
     assert all(want[(x, y, z)] == w for x, y, z, w in got)
     assert len(wide) <= len(svo) and (len(svo) < 16 or 16 * len(wide) < 8 * len(svo))     # fewer bytes than the 8-byte records
+
+
+def read_exr_uncompressed(path):
+    """An independent reader of the subset of OpenEXR that frame_loop.save_exr writes (version 2, scan lines, NO_COMPRESSION, FLOAT
+    channels): walks the attribute list, the offset table and the scan-line blocks -> ({channel: float32 [h, w]}, attributes)."""
+    import struct
+    b = open(path, "rb").read()
+    assert struct.unpack_from("<i", b, 0)[0] == 20000630 and b[:4] == bytes([0x76, 0x2f, 0x31, 0x01])
+    version = struct.unpack_from("<i", b, 4)[0]
+    assert version & 0xff == 2 and version >> 8 == 0                  # no tiles, no long names, no deep data, single part
+    pos, attrs = 8, {}
+    while b[pos] != 0:
+        e = b.index(b"\0", pos); name = b[pos:e].decode(); pos = e + 1
+        e = b.index(b"\0", pos); kind = b[pos:e].decode(); pos = e + 1
+        size = struct.unpack_from("<i", b, pos)[0]; pos += 4
+        attrs[name] = (kind, b[pos:pos + size]); pos += size
+    pos += 1
+    for required in ("channels", "compression", "dataWindow", "displayWindow", "lineOrder", "pixelAspectRatio", "screenWindowCenter", "screenWindowWidth"):
+        assert required in attrs, required
+    assert attrs["compression"] == ("compression", b"\0") and attrs["lineOrder"] == ("lineOrder", b"\0")
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    chans, p, ch = [], 0, attrs["channels"][1]
+    while ch[p] != 0:
+        e = ch.index(b"\0", p); name = ch[p:e].decode(); p = e + 1
+        ptype, plinear, xs, ys = struct.unpack_from("<iB3xii", ch, p); p += 16
+        assert ptype == 2 and xs == 1 and ys == 1
+        chans.append(name)
+    assert chans == sorted(chans)                                      # the file format wants them in alphabetical order
+    offsets = np.frombuffer(b, "<u8", h, pos)
+    out = {c: np.zeros((h, w), np.float32) for c in chans}
+    for row in range(h):
+        o = int(offsets[row])
+        y, size = struct.unpack_from("<ii", b, o)
+        assert y == y0 + row and size == 4 * w * len(chans)
+        data = np.frombuffer(b, "<f4", w * len(chans), o + 8).reshape(len(chans), w)
+        for i, c in enumerate(chans):
+            out[c][row] = data[i]
+    assert int(offsets[-1]) + 8 + 4 * w * len(chans) == len(b)        # nothing after the last block
+    return out, attrs
+
+
+def test_exr_writer_round_trip(tmp_path):
+    """frame_loop.save_exr (PNG / EXR dumps): the file parses as OpenEXR 2 scan lines and gives every float back bit for
+    bit, NaN, infinities and denormals included."""
+    from gpu_voxel_raytracer_amd import frame_loop
+    rng = np.random.default_rng(11)
+    img = rng.standard_normal((37, 53, 4)).astype(np.float32)
+    img[0, 0] = (np.nan, np.inf, -np.inf, 1e-42)
+    img[5, 7] = (0.0, -0.0, 3.4e38, 1.0)
+    path = str(tmp_path / "f.exr")
+    frame_loop.save_exr(img, path)
+    planes, attrs = read_exr_uncompressed(path)
+    assert sorted(planes) == ["A", "B", "G", "R"] and attrs["channels"][0] == "chlist" and attrs["dataWindow"][0] == "box2i"
+    for c, k in (("R", 0), ("G", 1), ("B", 2), ("A", 3)):
+        assert np.array_equal(planes[c].view(np.uint32), img[..., k].view(np.uint32)), c
+    assert os.path.getsize(path) == 8 + sum(len(n) + 1 + len(k) + 1 + 4 + len(v) for n, (k, v) in attrs.items()) + 1 + 37 * 8 + 37 * (8 + 53 * 16)
