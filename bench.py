@@ -182,7 +182,7 @@ def measure_config4_rank(Context, Camera, flags, scenes, device, rank=0, nranks=
             ctx.sync()
             dt = (time.perf_counter() - t0) / shown
             st, info = ctx.stats(), ctx.halo_info()
-            return {"workload": f"vox/castle.vox {w}x{h}, {spp} spp, {bounces} bounces, temporal + denoise r={radius} (BASELINE configs[3]): rank {rank} of "
+            return {"workload": f"vox/castle.vox {w}x{h}, {spp} spp, {bounces} bounces, temporal + denoise r={radius} (BASELINE configs[3]; camera 'close' as in --pipeline): rank {rank} of "
                                 f"{nranks} alone on this GPU, {band}-row bands (the last round lower: {st.local_rows} of {h} rows), its whole loop without "
                                 f"transfer time; {shown} displayed frames after 3 of warm-up",
                     "ms_per_displayed_frame": round(dt * 1e3, 4), "gray_per_s_this_rank": round(st.rays / shown / dt / 1e9, 2),
