@@ -220,6 +220,53 @@ def refill_wave_cost(paths, T, c_small):
     return cost
 
 
+
+def segment_pool(scene="menger", view="bench", bounces=4, w=1920, h=1080, split_round=3, c_step=116.0, c_io=80.0, ks=(1, 2, 3, 5, 8, 16), splits=((), (2,), (1, 2, 3, 4, 5, 6))):
+    """Round 4: what would compacting the tail's live paths at EVERY path segment give — (a) inside a persistent wave that owns K chunks
+    of 64 queued paths and re-packs its own survivors between segments (no launch boundary, no shared queue; c_io wave-instructions per
+    pass for the record store / load), against (b) the shipped tail with a global compaction (a new launch) at the tail segments in
+    `splits`.  Costs in wave-instructions from the oracle's per-ray step counts: c_step per lock-step trip (profiles/r04/walkf_step_isa.md:
+    116 measured), C_SHADE per shading round."""
+    st = steps_for(scene=scene, view=view, w=w, h=h, bounces=bounces)
+    rays = tiles_of(st)[:, :, 1:]
+    paths = rays[rays[:, :, split_round] > 0][:, split_round:].astype(np.int64)      # [n, rounds]: sun, bounce, sun, bounce, ...
+    n, nr = paths.shape
+    nseg = (nr + 1) // 2
+    lane_steps = paths.sum()
+    print(f"{scene} {view}, {bounces} bounces: {n} tail paths, {lane_steps / 1e6:.2f} M lane-steps")
+    for K in ks:
+        tot, trips = 0.0, 0
+        for g0 in range(0, n, K * 64):
+            p = paths[g0:g0 + K * 64]
+            for j in range(nseg):
+                s = p[:, 2 * j]
+                b = p[:, 2 * j + 1] if 2 * j + 1 < nr else np.zeros(len(p), np.int64)
+                a = s > 0 if j > 0 else np.ones(len(p), bool)
+                if not a.any():
+                    break
+                sa, ba = s[a], b[a]
+                for q in range(0, len(sa), 64):
+                    ms, mb = sa[q:q + 64].max(), ba[q:q + 64].max()
+                    tot += (ms + mb) * c_step + C_SHADE + (c_io if K > 1 else 0.0)
+                    trips += ms + mb
+        print(f"   a wave re-packs its own K = {K:2d} chunks at every segment: {tot / 1e6:6.1f} M wave-instr, lane utilisation {lane_steps / (trips * 64):.3f}")
+    for split in splits:
+        tot, trips, cur = 0.0, 0, paths
+        for j in range(nseg):
+            if j in split:
+                cur = cur[cur[:, 2 * j] > 0]
+                tot += len(cur) / 64 * 2 * c_io
+            if len(cur) == 0:
+                break
+            pad = (-len(cur)) % 64
+            P = np.concatenate([cur, np.zeros((pad, nr), np.int64)]).reshape(-1, 64, nr)
+            s = P[:, :, 2 * j]
+            b = P[:, :, 2 * j + 1] if 2 * j + 1 < nr else np.zeros_like(s)
+            tot += (s.max(axis=1) + b.max(axis=1)).sum() * c_step + (s > 0).any(axis=1).sum() * C_SHADE
+            trips += (s.max(axis=1) + b.max(axis=1)).sum()
+        print(f"   shipped tail, global compaction (new launch) at tail segments {list(split)}: {tot / 1e6:6.1f} M, lane utilisation {lane_steps / (trips * 64):.3f}")
+
+
 def steps_frames(frames, view="bench", w=1920, h=1080, bounces=4):
     """orc_trace_steps for `frames` consecutive frame numbers of a camera at rest: [frames, h, w, 17]."""
     pos, mrgb, size = scenes.load_scene("menger")
