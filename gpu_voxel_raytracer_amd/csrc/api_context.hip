@@ -411,11 +411,15 @@ int vxrt_create_tuned(const vxrt_config* cfg, const vxrt_tuning* tuning, size_t 
     // vxrt_config.tracer: 0 auto, 1 monolithic, 2 wavefront, 3 ray queues, 4 monolithic head + compacted tail (internally
     // 0, 2, 3, 4).  Measured on MI355X with frames in flight (menger 1080p 4 bounces / monu10 4K 8 bounces, ms per frame):
     // tracer 1: 0.219 / 0.52-1.53, tracer 3: 0.275 / 0.82-1.10, tracer 4: 0.175 / 0.54-0.94 -> auto = 4 whenever a path
-    // can have a second hit, with one more compaction at path segment 3 from 6 bounces on.
+    // can have a second hit, with further compactions from 6 bounces on (below).
     if (cfg->tracer > 5) { set_error("tracer must be 0..5"); return fail(VXRT_E_INVALID); }
     c->trace_variant = cfg->tracer == 0 ? 4 : (cfg->tracer == 1 ? 0 : int(cfg->tracer));
     c->auto_tracer = cfg->tracer == 0;
-    c->tail_split = cfg->max_bounces >= 6 ? 0x8u : 0u;
+    // From 6 bounces on the tail compacts its live paths again, in launches of their own, at path segments 2, 3 and 5 (round 4; one
+    // compaction at segment 3 until then).  Measured at 3840x2160, 4 spp, 8 bounces (scripts/exp_tail_split.py, ms per displayed frame,
+    // castle close up / monu10 from outside): none 4.21 / 1.21, 0x08 3.53 / 1.13-1.15, 0x14 3.37 / 1.11-1.12, 0x2c 3.31-3.33 / 1.11,
+    // 0x54 3.34-3.36 / 1.11-1.13, every segment (0xfc) 3.30 / 1.15.  At 4 bounces every extra compaction loses.
+    c->tail_split = cfg->max_bounces >= 6 ? 0x2cu : 0u;
 #if !VXRT_VARIANTS
     if (c->trace_variant == 2 || c->trace_variant == 3 || c->trace_variant == 5) {
         set_error("tracers 2, 3 and 5 are not in this build of libvxrt (compile with -DVXRT_VARIANTS=1: scripts/test_variants.sh)");

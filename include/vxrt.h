@@ -210,7 +210,7 @@ typedef struct vxrt_stats {
  *                          the launch, VXRT_TILE_SPREAD_AUTO (default) = decided on the device from the cost histogram.
  *   VXRT_OPT_TRACE_BLOCKS  blocks of the compacted tail's launches (default 2048).
  *   VXRT_OPT_TAIL_FROM     create: the hit at which a path moves from trace_kernel to the compacted tail (default 1 = the second hit).
- *   VXRT_OPT_TAIL_SPLIT    create: bit k = the tail compacts once more at path segment k (default: 0x8 from 6 bounces on).
+ *   VXRT_OPT_TAIL_SPLIT    create: bit k = the tail compacts once more at path segment k (default: 0x2c — segments 2, 3 and 5 — from 6 bounces on).
  *   VXRT_OPT_HOST_SCENE_BUILD  1: vxrt_set_menger builds the scene on the host also where the device builder could (cross-check).
  *   VXRT_OPT_NODE_ORDER    the order of the scene's 8-byte records in memory, chosen before the scene is set: 0 (default) breadth-first,
  *                          level after level; 2 / 3: the last two / three node levels as depth-first treelets — below every node of
