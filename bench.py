@@ -274,9 +274,10 @@ def measure_latency(Context, Camera, TRACE, pos, mrgb, cam, device, bounces, fra
     return statistics.median(times) * 1e3
 
 
-def measure_view(Context, Camera, TRACE, pos, mrgb, cam, device, bounces, inflight, batch, width=WIDTH, height=HEIGHT, frames=480, blocks=7,
+def measure_view(Context, Camera, TRACE, pos, mrgb, cam, device, bounces, inflight, batch, width=None, height=None, frames=480, blocks=7,
                  setup=None):
     """Throughput of the trace stage for another view / scene with the headline's schedule: median of `blocks` blocks of `frames` frames."""
+    width, height = width or WIDTH, height or HEIGHT
     ctx = Context(width, height, device=device, max_bounces=bounces, frames_in_flight=inflight, frames_per_launch=batch)
     if setup is not None:
         setup(ctx)
@@ -563,7 +564,7 @@ def trace_bench(args):
         wall = alg * args.steps / elapsed / 1e9                          # GB/s the block's wall time amounts to
         conc = max(1, min(args.inflight, launches // max(blocks, 1)))
         prof, prof_path = recorded_profile()
-        default_cfg = world == 1 and args.view == "bench" and args.bounces == 4
+        default_cfg = world == 1 and args.view == "bench" and args.bounces == 4 and args.frame == "1080p"
         roof = {
             # what the profile shows: VALU issue, not bandwidth, limits this stage (the `valu` object below).  The HBM
             # figures stay because the path is nominally HBM-bound work (no contraction, no MFMA): achieved = algorithmic bytes of
@@ -633,6 +634,14 @@ def trace_bench(args):
                                                         view_inflight, view_batch),
                                            workload=f"vox/{SCENE}.vox {WIDTH}x{HEIGHT}, {args.bounces} bounces, camera 'close' (geometry fills the frame); "
                                                     f"{view_batch} frames per launch x {view_inflight} launches in flight")
+            if default_cfg and args.frame == "1080p":
+                # north_star asks for 1080p AND 4K frames: the same scene, camera and schedule at 3840x2160 (`--frame 4k` makes it the headline)
+                m4 = measure_view(Context, Camera, TRACE, pos, mrgb, cam, device, args.bounces, view_inflight, view_batch, width=3840, height=2160, frames=240, blocks=5)
+                alg4 = algorithmic_bytes(3840 * 2160, args.bounces, m4["scene_bytes"])
+                m4["roofline"] = {"bound": "hbm", "limited_by": "valu issue", "algorithmic_bytes_per_frame": int(alg4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "achieved": round(alg4 / (m4["ms_per_frame"] * 1e-3) / 1e9, 1), "frac": round(alg4 / (m4["ms_per_frame"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                m4["workload"] = f"vox/{SCENE}.vox 3840x2160, 1 spp, {args.bounces} bounces, trace stage, camera 'bench'; {view_batch} frames per launch x {view_inflight} launches in flight"
+                extra["menger_4k"] = m4
             if default_cfg and not args.no_config5:
                 try:
                     c5cam = scenes.config5_cameras()["outside"]
@@ -820,7 +829,12 @@ def main():
     ap.add_argument("--batch", type=int, default=0,
                     help="consecutive frames per trace launch (vxrt_config.frames_per_launch; default: 16, 32 from 4 ranks on; a short block "
                          "is dealt to the launches in equal parts)")
+    ap.add_argument("--frame", default="1080p", choices=["1080p", "4k"],
+                    help="frame size of the trace bench: 1920x1080 (BASELINE configs[1], the headline) or 3840x2160 (north_star: 'Mrays/s on 1080p / 4K frames')")
     args = ap.parse_args()
+    if args.frame == "4k":
+        global WIDTH, HEIGHT
+        WIDTH, HEIGHT = 3840, 2160
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus, sys.argv[1:])      # does not return
     if os.environ.get("VXRT_BENCH_DRY") == "1":
