@@ -69,6 +69,81 @@ def recorded_profile():
     return None, None
 
 
+SQ_COUNTERS = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"]
+
+
+def live_counters(args):
+    """HBM bytes and SQ instruction counters of THIS invocation's workload and schedule, from three profiler passes run as CHILD
+    processes before this process touches the GPU: `rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py <the same steps /
+    schedule, no extras>` for FETCH_SIZE, WRITE_SIZE and the SQ set, each a pass of its own (counters are never combined with API
+    tracing; the program itself stands after `--`).  The HBM correction is MI355X_MICROARCH.md's: WRITE_SIZE as counted, the read side
+    doubled (gfx950 counts a wide coalesced read at half its bytes; for the 4-16-byte gathers here the truth lies between raw and
+    doubled: both are kept).  Returns (dict, note): dict None when rocprofv3 is missing or a pass fails — the line then falls back
+    to the RECORDED values of profiles/ and says so."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3")
+    if rocprof is None:
+        return None, "rocprofv3 not on PATH"
+    steady = args.steps >= 96
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "96" if steady else str(args.steps), "--warmup", "32" if steady else str(max(args.warmup, 0)),
+             "--blocks", "2" if steady else "12", "--no-cpu-baseline", "--no-extras", "--no-counters", "--bounces", str(args.bounces), "--view", args.view,
+             "--frame", args.frame]
+    if args.inflight:
+        child += ["--inflight", str(args.inflight)]
+    if args.batch:
+        child += ["--batch", str(args.batch)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    per_kernel, lines = {}, {}
+    try:
+        for name, ctrs in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", SQ_COUNTERS)):
+            tmp = tempfile.mkdtemp(prefix=f"vxrt_pmc_{name}_", dir="/tmp")
+            try:
+                out = subprocess.run([rocprof, "--kernel-trace", "--pmc"] + ctrs + ["--output-format", "csv", "-d", tmp, "--"] + child,
+                                     cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
+                js = [l for l in out.stdout.splitlines() if l.startswith("{")]
+                if out.returncode != 0 or not js:
+                    return None, f"the {name} pass failed (status {out.returncode}): {out.stderr[-200:]!r}"
+                lines[name] = json.loads(js[-1])
+                for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                    for r in csv.DictReader(open(f)):
+                        m = re.search(r"(trace_kernel|bounce_kernel)", r["Kernel_Name"])
+                        if m:
+                            per_kernel.setdefault(m[0], {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
+    except Exception as e:  # noqa: BLE001 — a profiler problem must not cost the line
+        return None, f"profiler pass failed: {e!r}"
+    fpl = float(lines["fetch"]["roofline"]["launch"]["frames_per_launch"])
+    res = {"command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE | SQ_*> --output-format csv -- python3 bench.py " + " ".join(child[2:]),
+           "frames_per_launch": fpl, "per_kernel": {}}
+    raw = doubled = valu = 0.0
+    for k in ("trace_kernel", "bounce_kernel"):
+        c = per_kernel.get(k, {})
+        f, w = c.get("FETCH_SIZE", []), c.get("WRITE_SIZE", [])
+        if not f or not w or not c.get("SQ_INSTS_VALU"):
+            return None, f"no counters for {k}"
+        fk, wk = sum(f[-4:]) / len(f[-4:]), sum(w[-4:]) / len(w[-4:])        # the last launches: steady state (KB per launch)
+        n = len(c["SQ_WAVES"])
+        act, thr, cyc = sum(c["SQ_ACTIVE_INST_VALU"]), sum(c["SQ_THREAD_CYCLES_VALU"]), sum(c["SQ_WAVE_CYCLES"])
+        res["per_kernel"][k] = {"launches_seen": len(f), "fetch_size_kb_per_launch": round(fk, 1), "write_size_kb_per_launch": round(wk, 1),
+                                "valu_wave_instr_per_launch": round(sum(c["SQ_INSTS_VALU"]) / n), "salu_per_launch": round(sum(c["SQ_INSTS_SALU"]) / n),
+                                "lane_utilisation": round(thr / (act * 64), 4) if act else None,
+                                "waitcnt_share_of_wave_cycles": round(sum(c["SQ_WAIT_ANY"]) / cyc, 4) if cyc else None}
+        raw += (fk + wk) * 1024
+        doubled += (2 * fk + wk) * 1024
+        valu += sum(c["SQ_INSTS_VALU"]) / n
+    res["hbm_bytes_per_step_raw"] = raw / fpl
+    res["hbm_bytes_per_step_read_doubled"] = doubled / fpl
+    res["valu_wave_instr_per_step"] = valu / fpl
+    res["ms_per_step_under_the_profiler"] = {k: v["ms_per_step"] for k, v in lines.items()}
+    return res, "measured"
+
+
 def recorded_json(name):
     """profiles/rNN/<name>, newest round first -> (parsed, path) or (None, None).  RECORDED values: counters need profiler passes of
     their own and are not measurements of this run (profiles/README.md says which script and schedule made each file)."""
@@ -579,7 +654,23 @@ def trace_bench(args):
                        "concurrent_launches": conc, "algorithmic_bytes_per_launch": int(alg * frames_per_launch),
                        "gbs_one_launch_alone": round(alg * frames_per_launch / (launch_ms * 1e-3) / 1e9, 2) if launch_ms > 0 else None},
         }
-        if prof is not None and default_cfg:
+        live = getattr(args, "live_counters", None)
+        if live is not None:
+            # counters of THIS invocation (child passes under rocprofv3, made before this process touched the GPU)
+            roof["traffic"] = live["hbm_bytes_per_step_read_doubled"]
+            roof["traffic_raw"] = live["hbm_bytes_per_step_raw"]
+            roof["traffic_over_algorithmic"] = round(live["hbm_bytes_per_step_read_doubled"] / alg, 3)
+            roof["traffic_source"] = ("MEASURED in this invocation: " + live["command"] + f" ({live['frames_per_launch']} frames per launch; separate "
+                                      "FETCH_SIZE and WRITE_SIZE passes, read side doubled per MI355X_MICROARCH.md, `traffic_raw` as counted), per step")
+            per_frame = live["valu_wave_instr_per_step"]
+            roof["valu"] = {"source": "MEASURED in this invocation (the SQ_* pass of the same child command)",
+                            "valu_wave_instr_per_step": round(per_frame),
+                            "issue_slot_frac": round(per_frame * 2 / (1024 * 2.4e9 * (elapsed / args.steps)), 3),
+                            "lane_utilisation": {k: v["lane_utilisation"] for k, v in live["per_kernel"].items()},
+                            "waitcnt_share": {k: v["waitcnt_share_of_wave_cycles"] for k, v in live["per_kernel"].items()},
+                            "per_kernel": live["per_kernel"], "ms_per_step_under_the_profiler": live["ms_per_step_under_the_profiler"]}
+        elif prof is not None and default_cfg:
+            roof["counters_note"] = getattr(args, "live_counters_note", None)
             drv = prof.get("driver_schedule") or {}
             t, same = prof.get("traffic"), False
             try:   # the recorded pass whose schedule is nearest to this run's (frames per launch)
@@ -817,6 +908,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (latency, close view, config 5's scene)")
     ap.add_argument("--no-config5", action="store_true", help="skip the extra that builds the 5.6 GB procedural scene")
+    ap.add_argument("--no-counters", action="store_true", help="skip the three rocprofv3 child passes that measure this invocation's HBM bytes and SQ counters "
+                                                                "(the line then quotes the RECORDED values of profiles/)")
     ap.add_argument("--no-config3", action="store_true", help="skip the extra that times BASELINE configs[2]'s frame loop at 4K")
     ap.add_argument("--pipeline", action="store_true", help="time the whole frame loop with the denoise halo exchange (BASELINE configs[3])")
     ap.add_argument("--radius", type=int, default=8, help="--pipeline: denoise radius")
@@ -839,6 +932,14 @@ def main():
         spawn_ranks(args.gpus, sys.argv[1:])      # does not return
     if os.environ.get("VXRT_BENCH_DRY") == "1":
         return dry_run(args)
+    args.live_counters, args.live_counters_note = None, "not asked for"
+    if (not args.pipeline and "WORLD_SIZE" not in os.environ and args.gpus == 1 and not args.no_counters and not args.no_extras and args.tracer == 0
+            and not any(k.startswith("ROCPROF") for k in os.environ) and "rocprofiler" not in os.environ.get("LD_PRELOAD", "")):   # not under a profiler already
+        # BEFORE this process makes its first HIP call: the profiler passes run as children (no exec from a process that has the GPU)
+        a = argparse.Namespace(**vars(args))
+        a.steps = a.steps or 960
+        a.warmup = 96 if a.warmup < 0 else a.warmup
+        args.live_counters, args.live_counters_note = live_counters(a)
     if args.pipeline:
         args.steps = args.steps or 24
         args.warmup = 4 if args.warmup < 0 else args.warmup
