@@ -72,14 +72,10 @@ def recorded_profile():
 SQ_COUNTERS = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"]
 
 
-def live_counters(args):
-    """HBM bytes and SQ instruction counters of THIS invocation's workload and schedule, from three profiler passes run as CHILD
-    processes before this process touches the GPU: `rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py <the same steps /
-    schedule, no extras>` for FETCH_SIZE, WRITE_SIZE and the SQ set, each a pass of its own (counters are never combined with API
-    tracing; the program itself stands after `--`).  The HBM correction is MI355X_MICROARCH.md's: WRITE_SIZE as counted, the read side
-    doubled (gfx950 counts a wide coalesced read at half its bytes; for the 4-16-byte gathers here the truth lies between raw and
-    doubled: both are kept).  Returns (dict, note): dict None when rocprofv3 is missing or a pass fails — the line then falls back
-    to the RECORDED values of profiles/ and says so."""
+def pmc_pass(counters, child_args, kernels, timeout=150):
+    """One profiler pass as a CHILD process: `rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python3 bench.py
+    <child_args>` (cwd /tmp; the program itself after `--`; counters never combined with API tracing).  -> ({kernel: {counter: [value
+    per dispatch, in order]}}, the child's JSON line).  Raises on any failure."""
     import csv
     import glob
     import re
@@ -88,36 +84,50 @@ def live_counters(args):
     import tempfile
     rocprof = shutil.which("rocprofv3")
     if rocprof is None:
-        return None, "rocprofv3 not on PATH"
+        raise RuntimeError("rocprofv3 not on PATH")
+    tmp = tempfile.mkdtemp(prefix="vxrt_pmc_", dir="/tmp")
+    try:
+        out = subprocess.run([rocprof, "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", tmp, "--", sys.executable,
+                              os.path.abspath(__file__)] + list(child_args), cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True,
+                             text=True, timeout=timeout)
+        js = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if out.returncode != 0 or not js:
+            raise RuntimeError(f"pass {counters[0]} failed (status {out.returncode}): {out.stderr[-200:]!r}")
+        per_kernel = {}
+        for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                m = re.search(kernels, r["Kernel_Name"])
+                if m:
+                    per_kernel.setdefault(m[0], {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        return per_kernel, json.loads(js[-1])
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def live_counters(args):
+    """HBM bytes and SQ instruction counters of THIS invocation's workload and schedule, from three profiler passes run as CHILD
+    processes before this process touches the GPU (pmc_pass: FETCH_SIZE, WRITE_SIZE and the SQ set, each a pass of its own, over
+    `bench.py <the same steps / schedule, no extras>`).  The HBM correction is MI355X_MICROARCH.md's: WRITE_SIZE as counted, the read
+    side doubled (gfx950 counts a wide coalesced read at half its bytes; for the 4-16-byte gathers here the truth lies between raw and
+    doubled: both are kept).  Returns (dict, note): dict None when rocprofv3 is missing or a pass fails — the line then falls back
+    to the RECORDED values of profiles/ and says so."""
     steady = args.steps >= 96
-    child = [sys.executable, os.path.abspath(__file__), "--steps", "96" if steady else str(args.steps), "--warmup", "32" if steady else str(max(args.warmup, 0)),
+    child = ["--steps", "96" if steady else str(args.steps), "--warmup", "32" if steady else str(max(args.warmup, 0)),
              "--blocks", "2" if steady else "12", "--no-cpu-baseline", "--no-extras", "--no-counters", "--bounces", str(args.bounces), "--view", args.view,
              "--frame", args.frame]
     if args.inflight:
         child += ["--inflight", str(args.inflight)]
     if args.batch:
         child += ["--batch", str(args.batch)]
-    env = dict(os.environ, TMPDIR="/tmp")
     per_kernel, lines = {}, {}
     try:
         for name, ctrs in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", SQ_COUNTERS)):
-            tmp = tempfile.mkdtemp(prefix=f"vxrt_pmc_{name}_", dir="/tmp")
-            try:
-                out = subprocess.run([rocprof, "--kernel-trace", "--pmc"] + ctrs + ["--output-format", "csv", "-d", tmp, "--"] + child,
-                                     cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
-                js = [l for l in out.stdout.splitlines() if l.startswith("{")]
-                if out.returncode != 0 or not js:
-                    return None, f"the {name} pass failed (status {out.returncode}): {out.stderr[-200:]!r}"
-                lines[name] = json.loads(js[-1])
-                for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
-                    for r in csv.DictReader(open(f)):
-                        m = re.search(r"(trace_kernel|bounce_kernel)", r["Kernel_Name"])
-                        if m:
-                            per_kernel.setdefault(m[0], {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-            finally:
-                shutil.rmtree(tmp, ignore_errors=True)
+            got, lines[name] = pmc_pass(ctrs, child, r"(trace_kernel|bounce_kernel)")
+            for k, c in got.items():
+                per_kernel.setdefault(k, {}).update(c)
     except Exception as e:  # noqa: BLE001 — a profiler problem must not cost the line
         return None, f"profiler pass failed: {e!r}"
+    child = [sys.executable, os.path.abspath(__file__)] + child
     fpl = float(lines["fetch"]["roofline"]["launch"]["frames_per_launch"])
     res = {"command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE | SQ_*> --output-format csv -- python3 bench.py " + " ".join(child[2:]),
            "frames_per_launch": fpl, "per_kernel": {}}
@@ -144,6 +154,52 @@ def live_counters(args):
     return res, "measured"
 
 
+def live_probes():
+    """The two secondary counter figures of the line, measured the same way (children, before this process touches the GPU):
+    config 5's scene from outside -> FETCH_SIZE per frame of trace_kernel; config 3's frame loop at r = 8 -> SQ_INSTS_VALU per launch of
+    denoise_pair_kernel.  -> dict (possibly partial); a probe that fails is simply absent and the line falls back to profiles/."""
+    out = {}
+    try:
+        got, line = pmc_pass(["FETCH_SIZE"], ["--probe", "config5"], r"trace_kernel")
+        f = got["trace_kernel"]["FETCH_SIZE"]
+        out["config5_fetch_bytes_per_frame"] = sum(f[-8:]) / len(f[-8:]) * 1024.0
+        out["config5_probe_ms_per_frame"] = line.get("ms_per_frame")
+    except Exception as e:  # noqa: BLE001
+        out["config5_error"] = repr(e)[:200]
+    try:
+        got, line = pmc_pass(["SQ_INSTS_VALU", "SQ_WAVES"], ["--probe", "config3"], r"denoise_pair_kernel")
+        v = got["denoise_pair_kernel"]["SQ_INSTS_VALU"]
+        out["denoise_r8_valu_wave_instr_per_launch"] = sum(v[-4:]) / len(v[-4:])
+    except Exception as e:  # noqa: BLE001
+        out["config3_error"] = repr(e)[:200]
+    return out
+
+
+def run_probe(which):
+    """`bench.py --probe config5 | config3` (a child of live_probes, under rocprofv3): a few frames of the extra's workload, one line."""
+    from gpu_voxel_raytracer_amd import ALL, TRACE, Camera, Context, scenes
+    if which == "config5":
+        with Context(3840, 2160, max_bounces=8, frames_in_flight=1, frames_per_launch=1) as ctx:
+            ctx.set_menger(*scenes.CONFIG5)
+            ctx.camera = Camera(*scenes.config5_cameras()["outside"])
+            ctx.render_frames(TRACE, 4)
+            ctx.sync()
+            t0 = time.perf_counter()
+            ctx.render_frames(TRACE, 8)
+            ctx.sync()
+            print(json.dumps({"probe": which, "ms_per_frame": round((time.perf_counter() - t0) / 8 * 1e3, 4)}), flush=True)
+    else:
+        pos, mrgb, size = scenes.load_scene("monu10")
+        with Context(3840, 2160, max_bounces=8, frames_in_flight=2, frames_per_launch=4) as ctx:
+            ctx.recreate_octree(pos, mrgb)
+            ctx.camera = Camera(*scenes.bench_camera(size))
+            ctx.denoise_uniforms.radius = 8
+            for _ in range(5):
+                ctx.render_spp(ALL, 4)
+            ctx.sync()
+            print(json.dumps({"probe": which}), flush=True)
+
+
 def recorded_json(name):
     """profiles/rNN/<name>, newest round first -> (parsed, path) or (None, None).  RECORDED values: counters need profiler passes of
     their own and are not measurements of this run (profiles/README.md says which script and schedule made each file)."""
@@ -156,7 +212,7 @@ def recorded_json(name):
     return None, None
 
 
-def measure_config3(Context, Camera, ALL, TIMED, scenes, device, shown=12):
+def measure_config3(Context, Camera, ALL, TIMED, scenes, device, shown=12, live_valu=None):
     """BASELINE configs[2] on this GPU, whole frame loop: vox/monu10.vox 3840x2160, 4 samples per pixel per displayed frame
     (vxrt_render_spp), 8 bounces, temporal + denoise at radius 2 and radius 8 (exact mode, bit-identical to the oracle).  Per
     displayed frame: wall ms, per-stage ms from HIP events (the stages overlap the next frame's trace launch, so they do not add up),
@@ -187,15 +243,19 @@ def measure_config3(Context, Camera, ALL, TIMED, scenes, device, shown=12):
                  "stage_ms": {"trace": round(st.trace_ms / shown, 4), "temporal": round(st.temporal_ms / shown, 4), "denoise": round(st.denoise_ms / shown, 4)},
                  "roofline": {"bound": "hbm", "algorithmic_bytes_per_displayed_frame": alg, "achieved": round(alg / dt / 1e9, 1), "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": round(alg / dt / 1e9 / HBM_PEAK_GBS, 4)}}
-            if radius == 8 and post is not None:
+            if radius == 8 and (post is not None or live_valu):
+                post = post or {"kernels": {"denoise r=8 exact": {"sq_insts_valu_per_launch": live_valu}}}
                 try:    # VALU issue of denoise_pair_kernel: wave-instructions (RECORDED) x 2 cycles on 1024 SIMDs at 2.4 GHz / this run's stage time
                     k = post["kernels"]["denoise r=8 exact"]
-                    issue_ms = k["sq_insts_valu_per_launch"] * 2 / (1024 * 2.4e9) * 1e3
-                    r["denoise_valu"] = {"kernel": "denoise_pair_kernel<exact, 8>", "valu_wave_instr_per_launch": int(k["sq_insts_valu_per_launch"]),
-                                         "lane_instr_per_tap": k["valu_lane_instr_per_tap"], "issue_ms": round(issue_ms, 3),
+                    instr = float(live_valu) if live_valu else float(k["sq_insts_valu_per_launch"])
+                    issue_ms = instr * 2 / (1024 * 2.4e9) * 1e3
+                    r["denoise_valu"] = {"kernel": "denoise_pair_kernel<exact, 8>", "valu_wave_instr_per_launch": int(instr),
+                                         "lane_instr_per_tap": round(instr * 64 / (w * h * 289), 2), "issue_ms": round(issue_ms, 3),
                                          "issue_slot_frac": round(issue_ms / (st.denoise_ms / shown), 3),
-                                         "source": f"instruction count RECORDED in {post_path} (rocprofv3 --pmc SQ_INSTS_VALU pass of scripts/profile_post.sh), "
-                                                   f"divided by this run's HIP-event time of the stage"}
+                                         "source": (("instruction count MEASURED in this invocation (a rocprofv3 --pmc SQ_INSTS_VALU child pass over `bench.py "
+                                                     "--probe config3`)" if live_valu else
+                                                     f"instruction count RECORDED in {post_path} (rocprofv3 --pmc SQ_INSTS_VALU pass of scripts/profile_post.sh)") +
+                                                    ", divided by this run's HIP-event time of the stage")}
                 except (KeyError, ZeroDivisionError, TypeError):
                     pass
             out[f"radius_{radius}"] = r
@@ -746,6 +806,9 @@ def trace_bench(args):
                     try:
                         o = rec["formats"]["8-byte records"]["outside"]
                         fetch = float(o["fetch_size_kb"]) * 1024.0
+                        live_fetch = getattr(args, "live_probes", {}).get("config5_fetch_bytes_per_frame")
+                        if live_fetch:
+                            fetch = float(live_fetch)
                         written = 48.0 * 3840 * 2160
                         sec = c5["ms_per_frame"] * 1e-3
                         c5["roofline"] = {"bound": "hbm", "kernel": "trace_kernel (all-in-one, 6 waves per SIMD)", "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -755,9 +818,12 @@ def trace_bench(args):
                                           "frac_read_doubled": round((written + 2 * fetch) / sec / 1e9 / HBM_PEAK_GBS, 4),
                                           "fetch_over_written": round(fetch / written, 2), "l2_hit_rate_recorded": o.get("l2_hit_rate"),
                                           "lane_utilisation_recorded": o.get("lane_utilisation"),
-                                          "source": f"FETCH_SIZE RECORDED in {rec_path} (rocprofv3 --pmc pass of scripts/profile_config5.sh, same scene, view "
-                                                    f"and frame size, {o.get('avg_ms')} ms per frame there) over this run's frame time; read-doubled = the "
-                                                    f"guide's gfx950 correction of the read side"}
+                                          "source": (("FETCH_SIZE MEASURED in this invocation (a rocprofv3 --pmc FETCH_SIZE child pass over `bench.py --probe config5`: "
+                                                      "the same scene, view and frame size)" if live_fetch else
+                                                      f"FETCH_SIZE RECORDED in {rec_path} (rocprofv3 --pmc pass of scripts/profile_config5.sh, same scene, view "
+                                                      f"and frame size, {o.get('avg_ms')} ms per frame there)") +
+                                                     " over this run's frame time; read-doubled = the guide's gfx950 correction of the read side; the L2 hit rate "
+                                                     f"and lane utilisation are RECORDED in {rec_path}")}
                     except (KeyError, TypeError, ValueError, ZeroDivisionError):
                         pass
                     extra["config5_outside_view"] = c5
@@ -766,7 +832,8 @@ def trace_bench(args):
             if default_cfg and not args.no_config3:
                 try:
                     from gpu_voxel_raytracer_amd import ALL
-                    extra["config3_pipeline"] = measure_config3(Context, Camera, ALL, TIMED, scenes, device)
+                    extra["config3_pipeline"] = measure_config3(Context, Camera, ALL, TIMED, scenes, device,
+                                                                live_valu=getattr(args, "live_probes", {}).get("denoise_r8_valu_wave_instr_per_launch"))
                 except Exception as e:  # noqa: BLE001
                     extra["config3_pipeline"] = {"error": repr(e)}
                 try:
@@ -910,6 +977,7 @@ def main():
     ap.add_argument("--no-config5", action="store_true", help="skip the extra that builds the 5.6 GB procedural scene")
     ap.add_argument("--no-counters", action="store_true", help="skip the three rocprofv3 child passes that measure this invocation's HBM bytes and SQ counters "
                                                                 "(the line then quotes the RECORDED values of profiles/)")
+    ap.add_argument("--probe", default="", choices=["", "config5", "config3"], help=argparse.SUPPRESS)     # a child of live_probes
     ap.add_argument("--no-config3", action="store_true", help="skip the extra that times BASELINE configs[2]'s frame loop at 4K")
     ap.add_argument("--pipeline", action="store_true", help="time the whole frame loop with the denoise halo exchange (BASELINE configs[3])")
     ap.add_argument("--radius", type=int, default=8, help="--pipeline: denoise radius")
@@ -932,7 +1000,9 @@ def main():
         spawn_ranks(args.gpus, sys.argv[1:])      # does not return
     if os.environ.get("VXRT_BENCH_DRY") == "1":
         return dry_run(args)
-    args.live_counters, args.live_counters_note = None, "not asked for"
+    if args.probe:
+        return run_probe(args.probe)
+    args.live_counters, args.live_counters_note, args.live_probes = None, "not asked for", {}
     if (not args.pipeline and "WORLD_SIZE" not in os.environ and args.gpus == 1 and not args.no_counters and not args.no_extras and args.tracer == 0
             and not any(k.startswith("ROCPROF") for k in os.environ) and "rocprofiler" not in os.environ.get("LD_PRELOAD", "")):   # not under a profiler already
         # BEFORE this process makes its first HIP call: the profiler passes run as children (no exec from a process that has the GPU)
@@ -940,6 +1010,8 @@ def main():
         a.steps = a.steps or 960
         a.warmup = 96 if a.warmup < 0 else a.warmup
         args.live_counters, args.live_counters_note = live_counters(a)
+        if args.live_counters is not None and a.steps >= 96 and args.view == "bench" and args.bounces == 4 and args.frame == "1080p":
+            args.live_probes = live_probes()
     if args.pipeline:
         args.steps = args.steps or 24
         args.warmup = 4 if args.warmup < 0 else args.warmup

@@ -308,14 +308,15 @@ def test_bench_contract_line():
         assert abs(e["roofline"]["frac"] - e["roofline"]["achieved"] / 8000.0) < 1e-3
         assert e["roofline"]["algorithmic_bytes_per_displayed_frame"] == ((48 + 16) * 4 + 16 + 80 + 64) * 3840 * 2160
     assert c3["radius_8"]["ms_per_displayed_frame"] > c3["radius_2"]["ms_per_displayed_frame"]
-    assert 0.3 < c3["radius_8"]["denoise_valu"]["issue_slot_frac"] < 1.0 and "RECORDED" in c3["radius_8"]["denoise_valu"]["source"]
+    assert 0.3 < c3["radius_8"]["denoise_valu"]["issue_slot_frac"] < 1.0 and ("RECORDED" in c3["radius_8"]["denoise_valu"]["source"] or
+                                                                              "MEASURED" in c3["radius_8"]["denoise_valu"]["source"])
     m4 = d["extra"]["menger_4k"]                  # north_star: 1080p and 4K frames
     assert "3840x2160" in m4["workload"] and m4["value"] > 1000.0 and abs(m4["roofline"]["frac"] - m4["roofline"]["achieved"] / 8000.0) < 1e-3
     c4 = d["extra"]["config4_one_rank_of_8"]      # BASELINE configs[3]: what one of its 8 ranks does per displayed frame
     assert c4["local_rows"] == 272 and c4["halo_rows"] == 8 and 10e6 < c4["halo_bytes_per_rank_per_frame"] < 12e6
     assert 0.2 < c4["ms_per_displayed_frame"] < 5 and c4["stage_ms"]["halo_pack"] > 0 and c4["stage_ms"]["denoise"] > 0
     c5 = d["extra"]["config5_outside_view"]["roofline"]
-    assert c5["bound"] == "hbm" and c5["frac_raw"] < c5["frac_read_doubled"] < 1.0 and "RECORDED" in c5["source"]
+    assert c5["bound"] == "hbm" and c5["frac_raw"] < c5["frac_read_doubled"] < 1.0 and ("RECORDED" in c5["source"] or "MEASURED" in c5["source"])
     r = d["roofline"]
     assert r["bound"] == "hbm" and "valu" in r["limited_by"] and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
