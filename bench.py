@@ -812,7 +812,7 @@ def trace_bench(args):
                         written = 48.0 * 3840 * 2160
                         sec = c5["ms_per_frame"] * 1e-3
                         c5["roofline"] = {"bound": "hbm", "kernel": "trace_kernel (all-in-one, 6 waves per SIMD)", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                          "bytes_written_per_frame": int(written), "bytes_fetched_per_frame_recorded": int(fetch),
+                                          "bytes_written_per_frame": int(written), "bytes_fetched_per_frame": int(fetch),
                                           "achieved_raw": round((written + fetch) / sec / 1e9, 1), "frac_raw": round((written + fetch) / sec / 1e9 / HBM_PEAK_GBS, 4),
                                           "achieved_read_doubled": round((written + 2 * fetch) / sec / 1e9, 1),
                                           "frac_read_doubled": round((written + 2 * fetch) / sec / 1e9 / HBM_PEAK_GBS, 4),
