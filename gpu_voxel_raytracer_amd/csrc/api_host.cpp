@@ -1,6 +1,8 @@
 // api_host.cpp — the host-only entry points of libvxrt (no GPU needed): .vox decoding, the reference-layout octree, the device record
 // formats, the camera basis, the stand-in noise table, the blue-noise archive format, procedural voxel lists
 // (src/vox.rs, src/context.rs:710-834, 913-933, 1042-1116, src/camera.rs).
+#include <cmath>
+
 #include "ctx.h"
 
 namespace vxrt {
@@ -76,6 +78,51 @@ int vxrt_camera_axis_scaled(const float position[3], const float direction[3], f
     memcpy(right, b.right, sizeof b.right);
     memcpy(up, b.up, sizeof b.up);
     memcpy(forward_ray, b.forward_ray, sizeof b.forward_ray);
+    return VXRT_OK;
+} VXRT_CATCH
+
+// Multi-GPU: how many rows of the neighbouring ranks' history the exchange after a frame rendered from camera A must carry
+// (VXRT_OPT_HALO_ROWS) so that temporal.comp's reprojection (shaders/temporal.comp:75-113) of the NEXT frame, rendered from camera B,
+// stays inside what a rank can see: the largest vertical image motion, in rows, of a point at distance >= `near` along any pixel's
+// ray of B, + 2 (the bilinear footprint's second row and rounding), capped at band_rows.  Along a ray the reprojected row is a
+// linear-fractional function of 1 / distance, so both ends of [near, inf) are evaluated, on a 33 x 33 grid of pixels that holds the
+// frame's borders.  Every rank computes the same number from the same cameras (the message sizes of an exchange must agree).
+// The same arithmetic as distributed.halo_rows_for_motion (tests/test_host_logic.py compares them).
+int vxrt_halo_rows_for_motion(const float pos_a[3], const float dir_a[3], const float pos_b[3], const float dir_b[3], float fov, uint32_t width,
+                              uint32_t height, float near_distance, uint32_t band_rows, uint32_t* rows) try {
+    if (!pos_a || !dir_a || !pos_b || !dir_b || !rows || width == 0 || height == 0) { set_error("null argument"); return VXRT_E_INVALID; }
+    *rows = band_rows;
+    const CameraBasis a = camera_axis_scaled(dir_a, fov, width, height), b = camera_axis_scaled(dir_b, fov, width, height);
+    // inverse of M = [right_a | up_a | forward_a] (columns), by cofactors in binary64
+    const double m[3][3] = {{a.right[0], a.up[0], a.forward_ray[0]}, {a.right[1], a.up[1], a.forward_ray[1]}, {a.right[2], a.up[2], a.forward_ray[2]}};
+    const double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+                       m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+    if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return VXRT_OK;       // no bound: every row travels
+    double inv[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+            inv[j][i] = (m[i1][j1] * m[i2][j2] - m[i1][j2] * m[i2][j1]) / det;
+        }
+    double worst = 0.0;
+    for (int gy = 0; gy <= 32; gy++)
+        for (int gx = 0; gx <= 32; gx++) {
+            const double x = double(width - 1) * gx / 32.0, y = double(height - 1) * gy / 32.0;
+            double d[3], len = 0.0;
+            for (int k = 0; k < 3; k++) { d[k] = x * b.right[k] - y * b.up[k] + b.forward_ray[k]; len += d[k] * d[k]; }
+            len = std::sqrt(len);
+            for (const double dist : {double(near_distance), 1e9}) {
+                double p[3], s[3];
+                for (int k = 0; k < 3; k++) p[k] = double(pos_b[k]) + dist * d[k] / len - double(pos_a[k]);
+                for (int r = 0; r < 3; r++) s[r] = inv[r][0] * p[0] + inv[r][1] * p[1] + inv[r][2] * p[2];
+                if (!(s[2] > 1e-12)) return VXRT_OK;                              // a point behind the old camera: no bound
+                const double moved = std::fabs(-(s[1] / s[2]) - y);
+                worst = moved > worst ? moved : worst;
+            }
+        }
+    if (!std::isfinite(worst)) return VXRT_OK;
+    const double want = std::ceil(worst - 1e-6) + 2.0;
+    *rows = want < double(band_rows) ? uint32_t(want) : band_rows;
     return VXRT_OK;
 } VXRT_CATCH
 

@@ -260,6 +260,15 @@ def build_records(pos, mrgb):
     return svo, wide, leaves, int(depth.value)
 
 
+def halo_rows_for_motion(cam_a, cam_b, width, height, near, band_rows):
+    """vxrt_halo_rows_for_motion: cam_a / cam_b are Camera objects with the same fov (see distributed.halo_rows_for_motion)."""
+    rows = C.c_uint32(0)
+    _check(lib().vxrt_halo_rows_for_motion(_p(cam_a.position), _p(cam_a.direction), _p(cam_b.position), _p(cam_b.direction), C.c_float(cam_a.fov),
+                                           C.c_uint32(width), C.c_uint32(height), C.c_float(near), C.c_uint32(band_rows), C.byref(rows)),
+           "vxrt_halo_rows_for_motion")
+    return int(rows.value)
+
+
 def noise_table(seed=DEFAULT_NOISE_SEED, n=NOISE_LEN):
     out = np.zeros(n, np.float32)
     _check(lib().vxrt_noise_table(C.c_uint32(seed), _p(out), C.c_size_t(n)), "vxrt_noise_table")

@@ -329,6 +329,12 @@ int vxrt_halo_unpack(vxrt_ctx* ctx, const void* dev_from_prev, const void* dev_f
 int vxrt_stream_wait_context(vxrt_ctx* ctx, void* stream);
 int vxrt_context_wait_stream(vxrt_ctx* ctx, void* stream);
 /* Synchronous forms: pack / unpack and wait for the launch (the buffers are borrowed for the call only). */
+/* Host-only helper: VXRT_OPT_HALO_ROWS for the exchange after a frame rendered from camera A when the next frame comes from camera B —
+ * the largest vertical image motion (rows) of any point at distance >= near_distance between the two, + 2, at most band_rows: with it
+ * the next frame's reprojection (shaders/temporal.comp:75-113) finds its history across band edges exactly as one GPU would.  The
+ * reference has no counterpart (one GPU sees the whole history); a frame loop sets it one frame ahead on a camera path. */
+int vxrt_halo_rows_for_motion(const float pos_a[3], const float dir_a[3], const float pos_b[3], const float dir_b[3], float fov, uint32_t width,
+                              uint32_t height, float near_distance, uint32_t band_rows, uint32_t* rows);
 int vxrt_halo_export(vxrt_ctx* ctx, void* dev_to_prev, void* dev_to_next);
 int vxrt_halo_import(vxrt_ctx* ctx, const void* dev_from_prev, const void* dev_from_next);
 

@@ -297,3 +297,7 @@ def test_halo_rows_for_motion_bounds_the_reprojection(H):
         assert worst <= rows - 2 + 0.51, (worst, rows)      # the 33 x 33 grid holds the borders, where the motion peaks
         assert rows <= worst + 3
         assert D.halo_rows_for_motion(a, b, w, h, 0.25, 16) == min(16, rows)
+        # the C ABI's version of the same arithmetic (a C++ / Rust host has no distributed.py)
+        assert H.halo_rows_for_motion(H.Camera(p0, d0, fov), H.Camera(p1, d1, fov), w, h, 0.25, 10 ** 6) == rows
+        assert H.halo_rows_for_motion(H.Camera(p0, d0, fov), H.Camera(p1, d1, fov), w, h, 0.25, 16) == min(16, rows)
+    assert H.halo_rows_for_motion(H.Camera(p0, d0, fov), H.Camera(p0, d0, fov), w, h, 0.25, 64) == 2

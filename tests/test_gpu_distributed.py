@@ -226,3 +226,16 @@ def test_bench_survives_a_real_rccl_failure():
     d = run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--blocks", "3"], env={"VXRT_BENCH_SPAWN_TIMEOUT": "300"})
     assert d["n_gpus"] == 2 and d["value"] > 1000.0
     assert d["rccl"]["backend"].startswith("gloo") and "nccl failed" in d["rccl"]["backend"]
+
+
+def test_cpp_multi_rank_host_with_a_panning_camera(tmp_path):
+    """tools/vxrt_multi.cpp --pan: the camera tilts by ~9 rows per frame; the host sizes every exchange for the next frame's
+    reprojection with vxrt_halo_rows_for_motion (the C ABI's form of distributed.halo_rows_for_motion) and three ranks still equal one
+    context bit for bit — the accumulated history survives the band edges.  With one history row (--halo-rows 1, no --pan sizing) the
+    same path differs: the check fails."""
+    args = ["menger:4", 384, 256, 5, 3, 2, tmp_path / "m.ppm", "--ranks", 3, "--transport", "copy", "--band", 32, "--check"]
+    out, d = run_multi(args + ["--pan", "-0.03"])
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-500:]
+    assert d["differing_values"] == 0 and d["rays_equal"] and 8 <= d["halo_rows"] <= 32
+    still, e = run_multi(args)
+    assert still.returncode == 0 and e["halo_rows"] == 2 and e["differing_values"] == 0     # at rest: the denoise radius' rows suffice

@@ -7,13 +7,16 @@
 //     -> vxrt_render(DENOISE_INTERIOR) -> vxrt_context_wait_stream(comm) -> vxrt_halo_unpack -> vxrt_render(DENOISE_EDGE)
 //
 //   vxrt_multi <scene.vox | menger:<level>[:clip[:period]] | default[:seed]> <width> <height> <frames> <bounces> <radius> <out.ppm>
-//              [--ranks N] [--transport rccl|copy] [--band ROWS] [--spp S] [--check] [--halo-rows R]
+//              [--ranks N] [--transport rccl|copy] [--band ROWS] [--spp S] [--check] [--halo-rows R] [--pan DY [--near D]]
 //
 // --transport rccl (default): rank r drives device r; needs N devices (RCCL refuses two ranks on one device; N = 1 works and sends
 //     nothing).  ncclCommInitAll makes the communicators in this one process.
 // --transport copy: the four transfers of a frame are hipMemcpyPeerAsync on the communication streams, ordered by events and two
 //     thread barriers per frame; rank r drives device r mod (device count), so any N runs on one GPU.  Everything but the four
 //     nccl calls is the same code: it is how this host is tested where there is one GPU.
+// --pan DY: a moving camera — frame f looks along direction + f * DY * (0, 1, 0) (a vertical pan, the motion that crosses band
+//     edges); every frame's exchange is sized for the NEXT frame's reprojection with vxrt_halo_rows_for_motion (points no nearer
+//     than --near, default 0.25), so the temporal history survives the band edges exactly as on one GPU.
 // --check: the same frames in ONE context on device 0, compared with the stitched frame bit for bit.
 // Prints one JSON line: ranks, devices, ms per frame, halo bytes per rank and frame, differing values.
 #include <hip/hip_runtime_api.h>
@@ -112,11 +115,19 @@ void place(vxrt::Context& ctx, const Scene& s, unsigned radius) {
     }
 }
 
+// frame f of a vertical pan: the placed camera's direction + f * pan * (0, 1, 0)
+vxrt::Camera camera_of_frame(const vxrt::Camera& base, float pan, int f) {
+    vxrt::Camera c = base;
+    c.direction[1] += pan * float(f);
+    return c;
+}
+
 struct Options {
     std::string scene, out;
     uint32_t width = 0, height = 0, bounces = 3, radius = 0, band = 0, spp = 1, halo_rows = 0;
     int frames = 1, ranks = 0;
     bool rccl = true, check = false;
+    float pan = 0.0f, near_distance = 0.25f;
 };
 
 struct Rank {   // what the ranks' threads share with each other (the copy transport reads a neighbour's buffers)
@@ -127,6 +138,7 @@ struct Rank {   // what the ranks' threads share with each other (the copy trans
     std::vector<uint32_t> rows;
     std::vector<float> image;
     size_t message_bytes = 0;
+    uint32_t halo_rows = 0;
     double seconds = 0.0;
     uint64_t rays = 0;
     std::string error;
@@ -152,6 +164,8 @@ int main(int argc, char** argv) {
         else if (a == "--spp") o.spp = std::atoi(next());
         else if (a == "--halo-rows") o.halo_rows = std::atoi(next());
         else if (a == "--check") o.check = true;
+        else if (a == "--pan") o.pan = float(std::atof(next()));
+        else if (a == "--near") o.near_distance = float(std::atof(next()));
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     try {
@@ -184,8 +198,22 @@ int main(int argc, char** argv) {
                                   /*frames_per_launch=*/o.spp > 1 ? std::min(o.spp, 32u) : 1u, o.band);
                 place(ctx, scene, o.radius);
                 if (o.halo_rows) ctx.set_option(VXRT_OPT_HALO_ROWS, o.halo_rows);
+                const vxrt::Camera base = ctx.camera;
+                if (o.pan != 0.0f && n > 1) {                     // the messages are sized for the largest motion of the path (one size for the run)
+                    uint32_t most = 1;
+                    for (int f = 0; f + 1 < o.frames; f++) {
+                        const vxrt::Camera a = camera_of_frame(base, o.pan, f), b = camera_of_frame(base, o.pan, f + 1);
+                        uint32_t rows = 0;
+                        vxrt::check(vxrt_halo_rows_for_motion(a.position.data(), a.direction.data(), b.position.data(), b.direction.data(), a.fov, o.width,
+                                                              o.height, o.near_distance, o.band, &rows), "vxrt_halo_rows_for_motion");
+                        most = std::max(most, rows);
+                    }
+                    ctx.set_option(VXRT_OPT_HALO_ROWS, most);
+                    me.halo_rows = most;
+                }
                 const vxrt_halo_info info = ctx.halo_info();
                 me.message_bytes = n > 1 ? size_t(info.message_bytes) : 0;
+                me.halo_rows = info.rows;
                 hip_check(hipStreamCreateWithFlags(&me.comm, hipStreamNonBlocking), "hipStreamCreate");
                 hip_check(hipEventCreateWithFlags(&me.packed, hipEventDisableTiming), "hipEventCreate");
                 hip_check(hipEventCreateWithFlags(&me.copied, hipEventDisableTiming), "hipEventCreate");
@@ -198,6 +226,7 @@ int main(int argc, char** argv) {
                 std::chrono::steady_clock::time_point t0;
                 for (int f = 0; f < o.frames; f++) {
                     if (f == 1) { ctx.sync(); if (!barrier.wait()) return; t0 = std::chrono::steady_clock::now(); }
+                    ctx.camera = camera_of_frame(base, o.pan, f);
                     // without a window (radius 0) the denoise stage is a per-pixel pass the library fuses into the temporal kernel; the
                     // halo then carries the history rows for the next frame's reprojection only
                     const uint32_t first = (n == 1 || o.radius == 0) ? uint32_t(VXRT_ALL) : uint32_t(VXRT_TRACE | VXRT_TEMPORAL);
@@ -273,7 +302,9 @@ int main(int argc, char** argv) {
             hip_check(hipSetDevice(0), "hipSetDevice");
             vxrt::Context one(o.width, o.height, o.bounces, 0, 1, 0, 1, o.spp > 1 ? std::min(o.spp, 32u) : 1u);
             place(one, scene, o.radius);
+            const vxrt::Camera base = one.camera;
             for (int f = 0; f < o.frames; f++) {
+                one.camera = camera_of_frame(base, o.pan, f);
                 if (o.spp > 1) one.render_spp(VXRT_ALL, o.spp);
                 else one.render(VXRT_ALL);
             }
@@ -296,9 +327,9 @@ int main(int argc, char** argv) {
         int version = 0;
         (void)ncclGetVersion(&version);
         std::printf("{\"tool\": \"vxrt_multi\", \"scene\": \"%s\", \"width\": %u, \"height\": %u, \"frames\": %d, \"spp\": %u, \"radius\": %u, \"ranks\": %d, "
-                    "\"transport\": \"%s\", \"rccl_version\": %d, \"devices\": [%s], \"band_rows\": %u, \"halo_bytes_per_rank_per_frame\": %zu, "
+                    "\"transport\": \"%s\", \"rccl_version\": %d, \"devices\": [%s], \"band_rows\": %u, \"halo_rows\": %u, \"halo_bytes_per_rank_per_frame\": %zu, "
                     "\"ms_per_frame\": %.4f, \"rays\": %llu, \"checked\": %s, \"differing_values\": %lld, \"rays_equal\": %s}\n",
-                    o.scene.c_str(), o.width, o.height, o.frames, o.spp, o.radius, n, o.rccl ? "rccl" : "copy", version, devs.c_str(), o.band,
+                    o.scene.c_str(), o.width, o.height, o.frames, o.spp, o.radius, n, o.rccl ? "rccl" : "copy", version, devs.c_str(), o.band, ranks[0].halo_rows,
                     2 * ranks[0].message_bytes, o.frames > 1 ? seconds / (o.frames - 1) * 1e3 : 0.0, (unsigned long long)rays,
                     o.check ? "true" : "false", differing, rays_equal ? "true" : "false");
         return (o.check && (differing != 0 || !rays_equal)) ? 3 : 0;
