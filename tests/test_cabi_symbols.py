@@ -118,3 +118,24 @@ def test_multi_gpu_cpp_host_compiles_and_links():
     for sym in ("ncclCommInitAll", "ncclSend", "ncclRecv", "ncclGroupStart", "ncclGroupEnd", "vxrt_halo_pack", "vxrt_halo_unpack",
                 "vxrt_stream_wait_context", "vxrt_context_wait_stream"):
         assert sym in und, sym
+
+
+def test_header_is_plain_c_and_a_c99_client_links(tmp_path):
+    """include/vxrt.h is a C header (the boundary a Rust / C host binds): it passes `gcc -std=c11 -pedantic` as C, and a C99 program
+    that includes it links against libvxrt.so and sees the structs at the sizes the reference's Rust structs have (Uniforms: 148 B,
+    src/context.rs:425-469)."""
+    from gpu_voxel_raytracer_amd import _build
+    hdr = os.path.join(ROOT, "include", "vxrt.h")
+    chk = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-fsyntax-only", "-x", "c", hdr], capture_output=True, text=True)
+    assert chk.returncode == 0 and not chk.stderr.strip(), chk.stderr
+    src = tmp_path / "client.c"
+    src.write_text('#include "vxrt.h"\n#include <stdio.h>\n'
+                   'int main(void) { vxrt_uniforms u; vxrt_default_uniforms(&u);\n'
+                   '  printf("%u %u %u %u %.2f\\n", vxrt_abi_version(), (unsigned)sizeof(vxrt_uniforms), (unsigned)sizeof(vxrt_temporal), (unsigned)sizeof(vxrt_denoise), u.sun_size);\n'
+                   '  return vxrt_create(0, 0) == VXRT_E_INVALID ? 0 : 1; }\n')
+    exe = tmp_path / "client"
+    build = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                            "-L" + os.path.dirname(_build.LIB), "-lvxrt", "-Wl,-rpath," + os.path.dirname(_build.LIB)], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert run.returncode == 0 and run.stdout.split() == ["5", "148", "12", "16", "0.05"], run.stdout
