@@ -475,3 +475,19 @@ def test_tolerant_denoise_mode_at_4k_radius_8(O, H, scenes, noise):
     assert rmse <= 1e-3                      # BASELINE.json north_star: per-pixel RMSE <= 1e-3
     assert rmse <= 2e-5 and worst <= 2e-3 and rel <= 1e-3
     assert (tolerant[..., 3] == 1).all() and np.isfinite(tolerant).all()
+
+
+def test_bench_quotes_recorded_counters_when_it_does_not_measure_them():
+    """`--no-extras` (or a box without rocprofv3) skips the profiler child passes: the line then quotes the RECORDED counters of the newest
+    profiles/rNN/ and says so — never a bare number of unknown origin."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "48", "--warmup", "8", "--blocks", "6", "--no-extras", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    r = d["roofline"]
+    assert r["traffic"] > 50e6 and r["traffic_source"].startswith("RECORDED in profiles/r0") and "not measured by this run" in r["traffic_source"]
+    assert r["valu"]["source"].startswith("RECORDED") and "extra" not in d and "cpu_baseline" not in d
