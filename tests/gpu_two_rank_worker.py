@@ -26,12 +26,6 @@ def main():
         torch.cuda.set_device(dev)
         dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         comm, red = None, torch.device("cuda", dev)      # messages GPU to GPU; reductions on the device
-    elif backend == "gloo-direct":
-        # gloo carrying the halo's GPU buffers directly (it stages them itself): the ranks share GPU 0, and HaloExchange takes the very
-        # branch it takes over RCCL (comm_device = the GPU: batch_isend_irecv on the side stream, Work.wait under it) with two REAL ranks
-        dev = 0
-        dist.init_process_group("gloo")
-        comm, red = None, "cpu"
     else:
         dev = 0
         dist.init_process_group(backend)

@@ -239,16 +239,3 @@ def test_cpp_multi_rank_host_with_a_panning_camera(tmp_path):
     assert d["differing_values"] == 0 and d["rays_equal"] and 8 <= d["halo_rows"] <= 32
     still, e = run_multi(args)
     assert still.returncode == 0 and e["halo_rows"] == 2 and e["differing_values"] == 0     # at rest: the denoise radius' rows suffice
-
-
-def test_the_rccl_branch_of_the_halo_exchange_with_two_real_ranks_over_gloo():
-    """distributed.HaloExchange with its buffers on the GPU and no host staging of its own — the branch RCCL takes — between two REAL
-    ranks (sharing this box's GPU), the messages carried by gloo, which accepts GPU tensors for send / recv: the same stitch, bit for
-    bit.  Together with test_halo_messages_over_rccl_on_one_gpu (that branch through RCCL itself, one rank) this leaves only the
-    pairing of both — two ranks AND RCCL — to the first box with two GPUs."""
-    d = launch(2, [os.path.join(ROOT, "tests", "gpu_two_rank_worker.py")], env={"VXRT_TEST_RADIUS": "3", "VXRT_TEST_BACKEND": "gloo-direct"})
-    assert d["backend"] == "gloo-direct" and d["world_size"] == 2
-    for name in ("rest", "slow"):
-        r = d[name]
-        assert r["rays_equal"] and r["sampled_differing_pixels"] == 0 and r["accum_differing_pixels"] == 0 and r["denoised_differing_pixels"] == 0, (name, r)
-    assert d["fast"]["rays_equal"] and d["fast"]["accum_differs_only_where_treated_as_disocclusion"]
