@@ -25,10 +25,6 @@ def main():
     w, h, radius, band = 640, 384, 3, 32
     pos, mrgb, size = scenes.load_scene("castle")
     cam = scenes.close_camera(size)
-    ctx = Context(w, h, device=0, max_bounces=3, rank=0, nranks=2, band_rows=band)
-    ctx.recreate_octree(pos, mrgb)
-    ctx.camera = Camera(*cam)
-    ctx.denoise_uniforms.radius = radius
 
     class SelfLoop(distributed.HaloExchange):
         """prev and next are this rank: `nranks` 1 for the peer arithmetic of _ops, 2 for everything else."""
@@ -39,27 +35,51 @@ def main():
             finally:
                 self.nranks = 2
 
-    halo = SelfLoop(ctx, dist, 0, 2, torch.device("cuda", 0), torch)
     res = {"backend": dist.get_backend(), "frames": 0, "to_prev_arrived_as_from_next": True, "to_next_arrived_as_from_prev": True,
            "messages_differ": True}
-    for frame in range(4):
-        ctx.render(TRACE | TEMPORAL)
-        halo.start()
-        ctx.render_stage(DENOISE_INTERIOR)
-        halo.finish()
-        ctx.render_stage(DENOISE_EDGE)
-        ctx.sync()
-        torch.cuda.synchronize()
-        to_prev, to_next, from_prev, from_next = (b.cpu().numpy().view(np.uint32) for b in halo.bufs)
-        res["to_prev_arrived_as_from_next"] &= bool((to_prev == from_next).all())
-        res["to_next_arrived_as_from_prev"] &= bool((to_next == from_prev).all())
-        res["messages_differ"] &= bool((to_prev != to_next).any() and to_prev.any() and to_next.any())
-        res["frames"] += 1
-    res["message_bytes"] = int(ctx.halo_info().message_bytes)
-    res["exchanges"] = halo.exchanges
+
+    def run(synchronous):
+        """Four frames of the overlapped loop.  synchronous: the host waits after every step, so nothing depends on the events between
+        the context's stream, the communication stream and RCCL's — the reference for the run in which everything is asynchronous."""
+        from gpu_voxel_raytracer_amd import ACCUM_COLOR, DENOISED
+        ctx = Context(w, h, device=0, max_bounces=3, rank=0, nranks=2, band_rows=band)
+        ctx.recreate_octree(pos, mrgb)
+        ctx.camera = Camera(*cam)
+        ctx.denoise_uniforms.radius = radius
+        halo = SelfLoop(ctx, dist, 0, 2, torch.device("cuda", 0), torch)
+
+        def settle():
+            if synchronous:
+                ctx.sync()
+                torch.cuda.synchronize()
+        images = []
+        for frame in range(4):
+            ctx.render(TRACE | TEMPORAL); settle()
+            halo.start(); settle()
+            ctx.render_stage(DENOISE_INTERIOR); settle()
+            halo.finish(); settle()
+            ctx.render_stage(DENOISE_EDGE); settle()
+            if not synchronous:      # look at the messages only after the frame: the loop itself never waits on the host
+                ctx.sync()
+                torch.cuda.synchronize()
+                to_prev, to_next, from_prev, from_next = (b.cpu().numpy().view(np.uint32) for b in halo.bufs)
+                res["to_prev_arrived_as_from_next"] &= bool((to_prev == from_next).all())
+                res["to_next_arrived_as_from_prev"] &= bool((to_next == from_prev).all())
+                res["messages_differ"] &= bool((to_prev != to_next).any() and to_prev.any() and to_next.any())
+                res["frames"] += 1
+            images.append((ctx.read(ACCUM_COLOR).view(np.uint32).copy(), ctx.read(DENOISED).view(np.uint32).copy()))
+        info = (int(ctx.halo_info().message_bytes), halo.exchanges)
+        ctx.close()
+        return images, info
+
+    asynchronous, (message_bytes, exchanges) = run(False)
+    reference, _ = run(True)
+    # the unpack must have waited for the receives and the edge tiles for the unpack: the asynchronous loop's frames equal the frames of
+    # the loop in which the host waited after every step (both see the same — deliberately wrong — neighbours)
+    res["asynchronous_frames_equal_synchronous_frames"] = all(bool((a[0] == b[0]).all() and (a[1] == b[1]).all()) for a, b in zip(asynchronous, reference))
+    res["message_bytes"], res["exchanges"] = message_bytes, exchanges
     res["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
     res["device"] = torch.cuda.get_device_name(0)
-    ctx.close()
     dist.barrier()
     torch.cuda.synchronize()
     print(json.dumps(res), flush=True)

@@ -113,6 +113,7 @@ def test_halo_messages_over_rccl_on_one_gpu():
     assert d["backend"] == "nccl" and d["frames"] >= 3 and d["message_bytes"] > 100000
     assert d["to_prev_arrived_as_from_next"] and d["to_next_arrived_as_from_prev"] and d["messages_differ"], d
     assert d["exchanges"] == d["frames"], d
+    assert d["asynchronous_frames_equal_synchronous_frames"], d      # the event ordering holds: nothing ran ahead of its data
 
 
 @needs_two_gpus
