@@ -240,3 +240,13 @@ def test_cpp_multi_rank_host_with_a_panning_camera(tmp_path):
     assert d["differing_values"] == 0 and d["rays_equal"] and 8 <= d["halo_rows"] <= 32
     still, e = run_multi(args)
     assert still.returncode == 0 and e["halo_rows"] == 2 and e["differing_values"] == 0     # at rest: the denoise radius' rows suffice
+
+
+def test_cpp_host_sends_and_receives_over_rccl_on_one_gpu(tmp_path):
+    """tools/vxrt_multi.cpp --self-loop: ncclCommInitAll + the frame's ncclGroupStart / 2 x ncclSend / 2 x ncclRecv / ncclGroupEnd from
+    C++ on this box's ONE GPU, both neighbours mapped onto the rank itself: after every frame the message for the previous rank has
+    arrived in the buffer for "from the next rank" and vice versa, bit for bit (the tool exits non-zero otherwise) — the in-order
+    matching of two sends and two receives to one peer that a 2-rank job relies on, this time without torch in the process."""
+    out, d = run_multi(["menger:4", 512, 288, 4, 3, 3, tmp_path / "m.ppm", "--ranks", 1, "--transport", "rccl", "--band", 32, "--self-loop"])
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-500:]
+    assert d["transport"] == "rccl" and d["self_loop_frames_crossed"] == 4 and d["halo_bytes_per_rank_per_frame"] > 100000

@@ -17,6 +17,10 @@
 // --pan DY: a moving camera — frame f looks along direction + f * DY * (0, 1, 0) (a vertical pan, the motion that crosses band
 //     edges); every frame's exchange is sized for the NEXT frame's reprojection with vxrt_halo_rows_for_motion (points no nearer
 //     than --near, default 0.25), so the temporal history survives the band edges exactly as on one GPU.
+// --self-loop (with --transport rccl --ranks 1): ncclSend / ncclRecv on ONE GPU — the context is rank 0 of 2 and both neighbours are
+//     mapped onto the rank itself, so the messages it sends come back to it (not what a frame needs: the image is not checked).  The
+//     transport is: after every frame `to_prev` must have arrived as `from_next` and `to_next` as `from_prev`, bit for bit — the
+//     in-order matching of two sends and two receives to one peer that a 2-rank job relies on.
 // --check: the same frames in ONE context on device 0, compared with the stitched frame bit for bit.
 // Prints one JSON line: ranks, devices, ms per frame, halo bytes per rank and frame, differing values.
 #include <hip/hip_runtime_api.h>
@@ -126,7 +130,7 @@ struct Options {
     std::string scene, out;
     uint32_t width = 0, height = 0, bounces = 3, radius = 0, band = 0, spp = 1, halo_rows = 0;
     int frames = 1, ranks = 0;
-    bool rccl = true, check = false;
+    bool rccl = true, check = false, self_loop = false;
     float pan = 0.0f, near_distance = 0.25f;
 };
 
@@ -139,6 +143,7 @@ struct Rank {   // what the ranks' threads share with each other (the copy trans
     std::vector<float> image;
     size_t message_bytes = 0;
     uint32_t halo_rows = 0;
+    int self_loop_frames = 0;
     double seconds = 0.0;
     uint64_t rays = 0;
     std::string error;
@@ -164,6 +169,7 @@ int main(int argc, char** argv) {
         else if (a == "--spp") o.spp = std::atoi(next());
         else if (a == "--halo-rows") o.halo_rows = std::atoi(next());
         else if (a == "--check") o.check = true;
+        else if (a == "--self-loop") o.self_loop = true;
         else if (a == "--pan") o.pan = float(std::atof(next()));
         else if (a == "--near") o.near_distance = float(std::atof(next()));
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
@@ -173,6 +179,8 @@ int main(int argc, char** argv) {
         hip_check(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
         if (ndev < 1) throw std::runtime_error("no HIP device");
         const int n = o.ranks > 0 ? o.ranks : ndev;
+        if (o.self_loop && !(o.rccl && n == 1 && !o.check)) throw std::runtime_error("--self-loop goes with --transport rccl --ranks 1 (and without --check)");
+        const int ctx_ranks = o.self_loop ? 2 : n;       // what the contexts believe
         if (o.rccl && n > ndev) throw std::runtime_error("the rccl transport needs one device per rank (RCCL refuses two ranks on one device): " +
                                                          std::to_string(n) + " ranks, " + std::to_string(ndev) + " devices; use --transport copy");
         if (o.band == 0) {   // >= 8 radius in whole 16-row tiles (the halo at most a quarter of a rank's rows), 16 without a window
@@ -194,7 +202,7 @@ int main(int argc, char** argv) {
             Rank& me = ranks[size_t(r)];
             try {
                 hip_check(hipSetDevice(me.device), "hipSetDevice");
-                vxrt::Context ctx(o.width, o.height, o.bounces, me.device, /*frames_in_flight=*/1, uint32_t(r), uint32_t(n),
+                vxrt::Context ctx(o.width, o.height, o.bounces, me.device, /*frames_in_flight=*/1, uint32_t(r), uint32_t(ctx_ranks),
                                   /*frames_per_launch=*/o.spp > 1 ? std::min(o.spp, 32u) : 1u, o.band);
                 place(ctx, scene, o.radius);
                 if (o.halo_rows) ctx.set_option(VXRT_OPT_HALO_ROWS, o.halo_rows);
@@ -212,7 +220,7 @@ int main(int argc, char** argv) {
                     me.halo_rows = most;
                 }
                 const vxrt_halo_info info = ctx.halo_info();
-                me.message_bytes = n > 1 ? size_t(info.message_bytes) : 0;
+                me.message_bytes = ctx_ranks > 1 ? size_t(info.message_bytes) : 0;
                 me.halo_rows = info.rows;
                 hip_check(hipStreamCreateWithFlags(&me.comm, hipStreamNonBlocking), "hipStreamCreate");
                 hip_check(hipEventCreateWithFlags(&me.packed, hipEventDisableTiming), "hipEventCreate");
@@ -229,10 +237,10 @@ int main(int argc, char** argv) {
                     ctx.camera = camera_of_frame(base, o.pan, f);
                     // without a window (radius 0) the denoise stage is a per-pixel pass the library fuses into the temporal kernel; the
                     // halo then carries the history rows for the next frame's reprojection only
-                    const uint32_t first = (n == 1 || o.radius == 0) ? uint32_t(VXRT_ALL) : uint32_t(VXRT_TRACE | VXRT_TEMPORAL);
+                    const uint32_t first = (ctx_ranks == 1 || o.radius == 0) ? uint32_t(VXRT_ALL) : uint32_t(VXRT_TRACE | VXRT_TEMPORAL);
                     if (o.spp > 1) ctx.render_spp(first, o.spp);
                     else ctx.render(first);
-                    if (n == 1) continue;
+                    if (ctx_ranks == 1) continue;
                     if (!o.rccl) vxrt::check(vxrt_context_wait_stream(ctx.handle(), me.comm), "vxrt_context_wait_stream");   // the neighbours have read last frame's messages
                     ctx.halo_pack(me.bufs[0], me.bufs[1], me.comm);      // one kernel; the communication stream waits for it (event)
                     if (o.rccl) {
@@ -260,6 +268,19 @@ int main(int argc, char** argv) {
                     if (o.radius > 0) ctx.render_stage(VXRT_DENOISE_INTERIOR);     // runs while the messages travel
                     ctx.halo_unpack(me.bufs[2], me.bufs[3], me.comm);              // the context's stream waits for the receives (event)
                     if (o.radius > 0) ctx.render_stage(VXRT_DENOISE_EDGE);
+                    if (o.self_loop) {      // the transport test: what left must have come back crossed, bit for bit
+                        ctx.sync();
+                        hip_check(hipStreamSynchronize(me.comm), "hipStreamSynchronize");
+                        std::vector<uint8_t> host[4];
+                        for (int b = 0; b < 4; b++) {
+                            host[b].resize(me.message_bytes);
+                            hip_check(hipMemcpy(host[b].data(), me.bufs[b], me.message_bytes, hipMemcpyDeviceToHost), "hipMemcpy");
+                        }
+                        const bool crossed = host[0] == host[3] && host[1] == host[2];
+                        const bool distinct = host[0] != host[1] && std::any_of(host[0].begin(), host[0].end(), [](uint8_t v) { return v != 0; });
+                        if (!crossed || !distinct) throw std::runtime_error("self-loop: the messages did not come back crossed (frame " + std::to_string(f) + ")");
+                        me.self_loop_frames++;
+                    }
                 }
                 ctx.sync();
                 hip_check(hipStreamSynchronize(me.comm), "hipStreamSynchronize");
@@ -328,10 +349,10 @@ int main(int argc, char** argv) {
         (void)ncclGetVersion(&version);
         std::printf("{\"tool\": \"vxrt_multi\", \"scene\": \"%s\", \"width\": %u, \"height\": %u, \"frames\": %d, \"spp\": %u, \"radius\": %u, \"ranks\": %d, "
                     "\"transport\": \"%s\", \"rccl_version\": %d, \"devices\": [%s], \"band_rows\": %u, \"halo_rows\": %u, \"halo_bytes_per_rank_per_frame\": %zu, "
-                    "\"ms_per_frame\": %.4f, \"rays\": %llu, \"checked\": %s, \"differing_values\": %lld, \"rays_equal\": %s}\n",
+                    "\"ms_per_frame\": %.4f, \"rays\": %llu, \"checked\": %s, \"differing_values\": %lld, \"rays_equal\": %s, \"self_loop_frames_crossed\": %d}\n",
                     o.scene.c_str(), o.width, o.height, o.frames, o.spp, o.radius, n, o.rccl ? "rccl" : "copy", version, devs.c_str(), o.band, ranks[0].halo_rows,
                     2 * ranks[0].message_bytes, o.frames > 1 ? seconds / (o.frames - 1) * 1e3 : 0.0, (unsigned long long)rays,
-                    o.check ? "true" : "false", differing, rays_equal ? "true" : "false");
+                    o.check ? "true" : "false", differing, rays_equal ? "true" : "false", ranks[0].self_loop_frames);
         return (o.check && (differing != 0 || !rays_equal)) ? 3 : 0;
     } catch (const std::exception& ex) {
         std::fprintf(stderr, "vxrt_multi: %s\n", ex.what());
