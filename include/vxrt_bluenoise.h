@@ -13,7 +13,7 @@
  *               every window cell that belongs to the minority set, accumulated in that order in binary32
  *               ("gather").  Afterwards inserting / removing a point p adds / subtracts K[dy][dx] at every
  *               window cell of p ("splat"), one binary32 operation per cell.
- *   K[dy][dx]   = vx_exp(-(dx*dx + dy*dy) / (2 * 1.9 * 1.9)) from include/vxrt_detmath.h, R = 7.
+ *   K[dy][dx]   = vx_exp_unfused(-(dx*dx + dy*dy) / (2 * 1.9 * 1.9)) from include/vxrt_detmath.h, R = 7.
  *   tightest cluster = the minority cell of maximal E; largest void = the majority cell of minimal E; ties go to
  *               the lowest cell index.
  *   1. initial pattern: n0 = N*N/10 ones at cells vxbn_hash(seed, layer, i) % (N*N), i = 0, 1, ... (cells already
@@ -49,7 +49,7 @@ VX_HD uint32_t vxbn_hash(uint32_t seed, uint32_t layer, uint32_t i) {
 
 /* K[dy + R][dx + R] */
 VX_HD float vxbn_kernel(int dx, int dy) {
-    return vx_exp(-(float)(dx * dx + dy * dy) / (2.0f * 1.9f * 1.9f));
+    return vx_exp_unfused(-(float)(dx * dx + dy * dy) / (2.0f * 1.9f * 1.9f));
 }
 
 #endif /* VXRT_BLUENOISE_H */
