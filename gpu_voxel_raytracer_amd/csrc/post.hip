@@ -440,7 +440,10 @@ __device__ __forceinline__ void pair_window(const DenoiseArgs& a, PairCentre& c0
 }
 
 template <bool kTolerant, int kR>
-__global__ __launch_bounds__(256) void denoise_pair_kernel(const DenoiseArgs a) {
+// Waves per SIMD the registers must leave room for: what the block's LDS allows (30 KB at radius 8: 5 blocks per CU, one wave of each
+// per SIMD) or 6.  Without the bound the multi-rank row mapping inlined into the staging loop took the tolerant radius-8 kernel from 77
+// to 106 VGPRs — 4 waves per SIMD, 13 % slower at the same instruction count (round 4; found in profiles/r04/post_stages_summary.json).
+__global__ __launch_bounds__(256, (kR >= 6 ? 5 : 6)) void denoise_pair_kernel(const DenoiseArgs a) {
     extern __shared__ float4 lds_raw[];
     __shared__ int block_exotic;
     const int r = kR;
