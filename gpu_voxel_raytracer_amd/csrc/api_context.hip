@@ -164,11 +164,14 @@ int set_band(vxrt_ctx* c, uint32_t width, uint32_t height) {
     b.rank = int(cfg.rank);
     b.band_rows = cfg.band_rows == 0 ? 16 : int(cfg.band_rows);
     if (b.nranks == 1) b.rank = 0;
-    // whole rounds of nranks bands at band_rows rows, then one round of shorter bands over what is left (kernels.h: BandMap)
+    // whole rounds of nranks bands at band_rows rows; the LAST round takes what is left as well, in taller bands (kernels.h: BandMap)
     const int tile = b.band_rows % 16 == 0 ? 16 : 8;
-    b.full_bands = (b.height / (b.nranks * b.band_rows)) * b.nranks;
+    const int round_rows = b.nranks * b.band_rows;
+    int rounds = b.height / round_rows;
+    if (b.height % round_rows != 0 && rounds > 0) rounds -= 1;               // fold the remainder into the last whole round
+    b.full_bands = rounds * b.nranks;
     b.tail_y0 = b.full_bands * b.band_rows;
-    const int rest = b.height - b.tail_y0;                                  // < nranks * band_rows
+    const int rest = b.height - b.tail_y0;                                  // 0, or < 2 * nranks * band_rows
     b.tail_rows = rest == 0 ? b.band_rows : ((rest + b.nranks - 1) / b.nranks + tile - 1) / tile * tile;
     b.local_rows = count_local_rows(b);
     c->band = b;

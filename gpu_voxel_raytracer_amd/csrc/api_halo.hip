@@ -28,12 +28,21 @@ HaloView view_for(const vxrt_ctx* c, uint32_t rows) {
 }
 }  // namespace
 
+// The most rows per band edge the layout can carry: a neighbour's rows beyond its band belong to a third rank, so the lowest band
+// that has a band below it.  With the remainder folded into the last round (kernels.h: BandMap) that is band_rows; only a frame
+// lower than one round of bands has lower ones.  (The frame's very last band may be clipped lower still: nothing lies below it.)
+uint32_t halo_rows_max(const vxrt_ctx* c) {
+    const BandMap& b = c->band;
+    if (b.nranks < 2) return 0;
+    const int lowest = b.tail_y0 < b.height ? (b.full_bands > 0 && b.band_rows < b.tail_rows ? b.band_rows : b.tail_rows) : b.band_rows;
+    return uint32_t(lowest);
+}
+
 uint32_t halo_rows_wanted(const vxrt_ctx* c) {
     if (c->band.nranks < 2) return 0;
-    uint32_t rows = c->denoise.radius > c->halo_min_rows ? c->denoise.radius : c->halo_min_rows;
-    // at most a band: a neighbour's rows beyond that belong to a third rank.  The tail round's bands may be lower than band_rows.
-    const uint32_t lowest = uint32_t(c->band.tail_y0 < c->band.height ? c->band.tail_rows : c->band.band_rows);
-    return rows > lowest ? lowest : rows;
+    const uint32_t rows = c->denoise.radius > c->halo_min_rows ? c->denoise.radius : c->halo_min_rows;
+    const uint32_t most = halo_rows_max(c);
+    return rows > most ? most : rows;
 }
 
 void free_halo(vxrt_ctx* c) {
@@ -85,6 +94,7 @@ int vxrt_halo_info_get(vxrt_ctx* c, vxrt_halo_info* out) try {
     if (rows == 0) return VXRT_OK;
     const HaloView v = view_for(c, rows);
     out->rows = rows;
+    out->max_rows = halo_rows_max(c);
     out->slots = uint32_t(v.slots);
     out->bytes_per_pixel = 36;
     out->message_bytes = v.message * sizeof(float4);

@@ -48,16 +48,19 @@ struct Cam {  // first 64 bytes of Uniforms, without padding
 };
 
 // Which rows of the frame this context owns (vxrt_config.rank / nranks / band_rows).  The rows are dealt to the ranks in interleaved
-// bands, band gb -> rank gb % nranks.  Whole ROUNDS of nranks bands are band_rows rows high (`full_bands` bands, rows [0, tail_y0));
-// what is left below them — fewer than nranks * band_rows rows — is ONE more round of bands `tail_rows` rows high, the smallest
-// multiple of the tile height (16 rows when band_rows is a multiple of 16, else 8) that covers the rest in nranks bands.  So every
-// rank's row count is within one tile row of height / nranks (round 4; until then the last round's bands were band_rows high too and
-// the first ranks of that round owned up to a band more than the others: 288 against 240 rows at 2160 rows / 8 ranks / 48-row bands).
+// bands, band gb -> rank gb % nranks.  Whole ROUNDS of nranks bands are band_rows rows high (`full_bands` bands, rows [0, tail_y0)).
+// When the frame is not a whole number of rounds, the LAST round takes the remainder as well: its bands are `tail_rows` rows high, the
+// smallest multiple of the tile height (16 rows when band_rows is a multiple of 16, else 8) that covers the last round + remainder in
+// nranks bands — band_rows <= tail_rows < 2 band_rows + tile.  Every rank's row count is within one tile row of height / nranks, and no
+// band but the frame's very last (clipped by the frame's edge) is lower than band_rows, so a halo can be up to band_rows rows deep at
+// every band edge (round 5; round 4 put the remainder into an EXTRA round of LOWER bands, same balance — 272 / 256 rows at 2160 rows on
+// 8 ranks with 64-row bands either way — but the halo of the whole frame was capped at those bands' 16 rows: ADVICE r4).  Only a frame
+// lower than one round (height < nranks * band_rows) has nothing to fold into: its single round's bands are lower than band_rows.
 struct BandMap {
     int width, height, local_rows, band_rows, rank, nranks;
     int full_bands;   // bands of band_rows rows (a multiple of nranks)
-    int tail_y0;      // = full_bands * band_rows: where the tail round starts (== height: there is none)
-    int tail_rows;    // height of the tail round's bands: <= band_rows, a multiple of the tile height
+    int tail_y0;      // = full_bands * band_rows: where the last, taller round starts (== height: every round is band_rows high)
+    int tail_rows;    // height of that round's bands, a multiple of the tile height (>= band_rows unless it is the frame's only round)
 };
 #define VX_BAND_FN __host__ __device__ __forceinline__
 VX_BAND_FN int band_of_row(const BandMap& b, int y) { return y < b.tail_y0 ? y / b.band_rows : b.full_bands + (y - b.tail_y0) / b.tail_rows; }

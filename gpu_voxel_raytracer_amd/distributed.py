@@ -47,9 +47,11 @@ def band_rows_for(radius, height=None, nranks=None, minimum=16):
 
 class BandLayout:
     """Row ownership and halo message layout; mirrors BandMap (csrc/kernels.h) and csrc/api_halo.hip / csrc/halo_view.h.
-    Band gb -> rank gb % nranks.  Whole rounds of nranks bands are band_rows rows high (`full_bands` of them, rows [0, tail_y0));
-    what is left is one more round of bands `tail_rows` high — the smallest multiple of the tile height (16, or 8 for 8-row bands)
-    that covers the rest in nranks bands — so every rank owns within one tile row of height / nranks rows."""
+    Band gb -> rank gb % nranks.  Whole rounds of nranks bands are band_rows rows high (`full_bands` of them, rows [0, tail_y0)); when
+    the frame is not a whole number of rounds the LAST round takes the remainder too, in bands `tail_rows` high — the smallest multiple
+    of the tile height (16, or 8 for 8-row bands) that covers it in nranks bands, band_rows <= tail_rows < 2 band_rows + tile — so every
+    rank owns within one tile row of height / nranks rows and no band but the frame's last is lower than band_rows (a frame lower than
+    one round has only that round, in bands lower than band_rows)."""
 
     def __init__(self, width, height, nranks, band_rows=16, radius=None):
         # the library's rule (vxrt_create / check_render): bands are multiples of the tracer's 8-row tiles;
@@ -60,7 +62,10 @@ class BandLayout:
             raise ValueError("band_rows must be a multiple of 16 for a denoise radius > 0 (pass radius=0 for 8-row bands)")
         self.width, self.height, self.nranks, self.band_rows = width, height, nranks, band_rows
         tile = 16 if band_rows % 16 == 0 else 8
-        self.full_bands = (height // (nranks * band_rows)) * nranks
+        rounds = height // (nranks * band_rows)
+        if height % (nranks * band_rows) and rounds > 0:
+            rounds -= 1                     # the last whole round takes the remainder as well (taller bands)
+        self.full_bands = rounds * nranks
         self.tail_y0 = self.full_bands * band_rows
         rest = height - self.tail_y0
         self.tail_rows = band_rows if rest == 0 else ((rest + nranks - 1) // nranks + tile - 1) // tile * tile
@@ -98,12 +103,20 @@ class BandLayout:
     def max_bands(self):
         return (self.bands + self.nranks - 1) // self.nranks
 
-    def halo_rows(self, radius, min_rows=1):
-        """Rows per band edge an exchange carries (vxrt_halo_info.rows): at most the lowest band."""
+    def halo_rows_max(self):
+        """The most rows per band edge the layout can carry (vxrt_halo_info.max_rows): the lowest band that has a band below it —
+        band_rows, unless the frame is lower than one round of bands.  The cap to pass to halo_rows_for_motion."""
         if self.nranks < 2:
             return 0
-        lowest = self.tail_rows if self.tail_y0 < self.height else self.band_rows
-        return min(lowest, max(radius, min_rows))
+        if self.tail_y0 < self.height:
+            return min(self.band_rows, self.tail_rows) if self.full_bands > 0 else self.tail_rows
+        return self.band_rows
+
+    def halo_rows(self, radius, min_rows=1):
+        """Rows per band edge an exchange carries (vxrt_halo_info.rows): at most halo_rows_max()."""
+        if self.nranks < 2:
+            return 0
+        return min(self.halo_rows_max(), max(radius, min_rows))
 
     def plane(self, rows):
         """float4 per A / B plane of a message."""
@@ -266,7 +279,8 @@ def halo_rows_for_motion(cam_a, cam_b, width, height, near, band_rows, margin=2)
     """Rows of the neighbours' history a rank must see so that temporal.comp's reprojection (shaders/temporal.comp:75-113) from the
     frame of camera `cam_b` into the frame of camera `cam_a` stays inside what it has: the largest vertical image motion, in rows,
     of a point at distance >= `near` along any pixel's ray, + `margin` (the bilinear footprint's second row and rounding), capped
-    at band_rows (then every row of the neighbours travels).  A camera is (origin, right, up, forward) as Camera.axis_scaled gives
+    at band_rows — pass BandLayout.halo_rows_max() / vxrt_halo_info.max_rows, what the layout can carry; a result equal to the cap means
+    every row of the neighbours travels and a faster motion reaches rows of a third rank (a disocclusion there).  A camera is (origin, right, up, forward) as Camera.axis_scaled gives
     them (pixel ray = x right - y up + forward, shaders/voxels.comp:299-303).  Along a pixel's ray the reprojected row is a
     linear-fractional function of 1 / distance, so its extremes over [near, inf) are at the two ends; over the screen the motion is
     evaluated on a 33 x 33 grid of pixels including the borders.  Every rank computes the same number from the same cameras — the

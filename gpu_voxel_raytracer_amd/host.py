@@ -157,7 +157,7 @@ def tuning_from_env(environ=None):
 class HaloInfo(C.Structure):
     """vxrt_halo_info (include/vxrt.h)."""
     _fields_ = [("rows", C.c_uint32), ("slots", C.c_uint32), ("bytes_per_pixel", C.c_uint32), ("interior_tile_rows", C.c_uint32),
-                ("edge_tile_rows", C.c_uint32), ("reserved", C.c_uint32), ("message_bytes", C.c_uint64)]
+                ("edge_tile_rows", C.c_uint32), ("max_rows", C.c_uint32), ("message_bytes", C.c_uint64)]
 
 
 class Camera:
@@ -178,6 +178,23 @@ class Camera:
         return r, u, f
 
 
+_LOADED = {}     # path -> CDLL: every library this process has loaded (each keeps its own state; handles are never unloaded)
+
+
+def _load(path):
+    path = os.path.abspath(path)
+    L = _LOADED.get(path)
+    if L is None:
+        L = C.CDLL(path)
+        L.vxrt_last_error.restype = C.c_char_p
+        L.vxrt_status_string.restype = C.c_char_p
+        L.vxrt_abi_version.restype = C.c_uint32
+        L.vxrt_build_features.restype = C.c_uint32
+        L.vxrt_status_string.argtypes = [C.c_int]
+        _LOADED[path] = L
+    return L
+
+
 def lib():
     """Load libvxrt.so, building it with hipcc first if it is missing or was built from other sources than the tree holds
     (compared by content hash, _build.needs_build: a stale binary must never run silently).  No fallback: without the
@@ -187,14 +204,27 @@ def lib():
         path = os.environ.get("VXRT_LIB")  # A/B builds of the library (scripts/ab_build.sh); the product build otherwise
         if not path:
             path = _build.build()
-        L = C.CDLL(path)
-        L.vxrt_last_error.restype = C.c_char_p
-        L.vxrt_status_string.restype = C.c_char_p
-        L.vxrt_abi_version.restype = C.c_uint32
-        L.vxrt_build_features.restype = C.c_uint32
-        L.vxrt_status_string.argtypes = [C.c_int]
-        _LIB = L
+        _LIB = _load(path)
     return _LIB
+
+
+def use_library(path=None):
+    """Tests: make `path` (None = the product build, or VXRT_LIB) the library new contexts and the module-level helpers use.
+    A context keeps the library it was created in.  Returns the path now in use."""
+    global _LIB
+    if path is None:
+        _LIB = None
+        lib()
+    else:
+        _LIB = _load(path)
+    return _LIB._name
+
+
+def variants_library():
+    """Path of the -DVXRT_VARIANTS=1 build (tracers 2 / 3 / 5, the wide scene records: the schedules and the scene format that
+    measured slower and stay out of the product), built first if it is missing or stale.  Test infrastructure: the parity cases of
+    those variants load it beside the product library."""
+    return _build.build(variants=True)
 
 
 def build_features():
@@ -362,6 +392,7 @@ class Context:
         """tuning: [(OPT_*, value)] applied by vxrt_create_tuned before anything is allocated (scheduling options for experiments
         and tests; the image never depends on them)."""
         self._h = C.c_void_p()
+        self._L = lib()      # the library this context lives in (tests load the -DVXRT_VARIANTS=1 build beside the product: use_library)
         tuning = list(tuning or [])
         if _env_knobs_enabled:
             tuning = tuning_from_env() + tuning
@@ -378,15 +409,19 @@ class Context:
                 raise ValueError("noise table must hold 512*128*128 floats")
             cfg.noise = keep.ctypes.data
         pairs = (Tuning * max(len(tuning), 1))(*[Tuning(int(o), int(v)) for o, v in tuning])
-        _check(lib().vxrt_create_tuned(C.byref(cfg), pairs, C.c_size_t(len(tuning)), C.byref(self._h)), "vxrt_create_tuned")
+        self._chk(self._L.vxrt_create_tuned(C.byref(cfg), pairs, C.c_size_t(len(tuning)), C.byref(self._h)), "vxrt_create_tuned")
         self.uniforms = Uniforms.default()
         self.temporal_uniforms = TemporalUniforms.default()
         self.denoise_uniforms = DenoiseUniforms.default()
 
+    def _chk(self, status, where):
+        if status != 0:
+            raise VxrtError(status, where, (self._L.vxrt_last_error() or b"").decode(errors="replace"))
+
     # -- lifetime ------------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            lib().vxrt_destroy(self._h)
+            self._L.vxrt_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -408,27 +443,27 @@ class Context:
         mrgb = np.ascontiguousarray(mrgb, np.uint8)
         if pos.shape != (len(pos), 3) or mrgb.shape != (len(pos), 4):
             raise ValueError("pos must be [n,3] int16 and mrgb [n,4] uint8")
-        _check(lib().vxrt_set_voxels(self._h, _p(pos), _p(mrgb), C.c_size_t(len(pos))), "vxrt_set_voxels")
+        self._chk(self._L.vxrt_set_voxels(self._h, _p(pos), _p(mrgb), C.c_size_t(len(pos))), "vxrt_set_voxels")
 
     def set_menger(self, level, clip=0, mrgb=(0, 0xb0, 0xd0, 0x60), emissive_period=0):
         """Procedural Menger sponge built straight into the device scene format (BASELINE config 5)."""
         m = np.asarray(mrgb, np.uint8)
-        _check(lib().vxrt_set_menger(self._h, C.c_uint32(level), C.c_uint32(clip), _p(m), C.c_uint32(emissive_period)),
+        self._chk(self._L.vxrt_set_menger(self._h, C.c_uint32(level), C.c_uint32(clip), _p(m), C.c_uint32(emissive_period)),
                "vxrt_set_menger")
 
     def read_scene(self):
         """Test hook (vxrt_debug_read_scene): the device's scene -> (svo uint32[n,2] = masks, base; leaves int32[k])."""
         ns, nl = C.c_size_t(0), C.c_size_t(0)
-        _check(lib().vxrt_debug_read_scene(self._h, None, C.c_size_t(0), C.byref(ns), None, C.c_size_t(0), C.byref(nl)), "vxrt_debug_read_scene")
+        self._chk(self._L.vxrt_debug_read_scene(self._h, None, C.c_size_t(0), C.byref(ns), None, C.c_size_t(0), C.byref(nl)), "vxrt_debug_read_scene")
         svo, leaves = np.zeros((ns.value, 2), np.uint32), np.zeros(nl.value, np.int32)
-        _check(lib().vxrt_debug_read_scene(self._h, _p(svo), C.c_size_t(len(svo)), C.byref(ns), _p(leaves), C.c_size_t(len(leaves)), C.byref(nl)),
+        self._chk(self._L.vxrt_debug_read_scene(self._h, _p(svo), C.c_size_t(len(svo)), C.byref(ns), _p(leaves), C.c_size_t(len(leaves)), C.byref(nl)),
                "vxrt_debug_read_scene")
         return svo, leaves
 
     def load_vox(self, path, flags=0):
         """vox::load + voxels_from_vox + recreate_octree (src/context.rs:1817-1821); flags: VOX_* for whole scenes."""
         if flags == 0:
-            _check(lib().vxrt_load_vox(self._h, os.fsencode(path)), "vxrt_load_vox")
+            self._chk(self._L.vxrt_load_vox(self._h, os.fsencode(path)), "vxrt_load_vox")
         else:
             with open(path, "rb") as f:
                 pos, mrgb, _ = vox_scene_to_voxels(f.read(), flags)
@@ -439,35 +474,35 @@ class Context:
         t = np.ascontiguousarray(table, np.float32).reshape(-1)
         if t.size != NOISE_LEN:
             raise ValueError("noise table must hold 512*128*128 floats")
-        _check(lib().vxrt_set_noise(self._h, _p(t)), "vxrt_set_noise")
+        self._chk(self._L.vxrt_set_noise(self._h, _p(t)), "vxrt_set_noise")
 
     def load_vox_bytes(self, data: bytes):
         buf = np.frombuffer(data, np.uint8)
-        _check(lib().vxrt_load_vox_memory(self._h, _p(buf), C.c_size_t(len(data))), "vxrt_load_vox_memory")
+        self._chk(self._L.vxrt_load_vox_memory(self._h, _p(buf), C.c_size_t(len(data))), "vxrt_load_vox_memory")
 
     # -- frame ---------------------------------------------------------------------------------------
     def resize(self, width, height):
-        _check(lib().vxrt_resize(self._h, C.c_uint32(width), C.c_uint32(height)), "vxrt_resize")
+        self._chk(self._L.vxrt_resize(self._h, C.c_uint32(width), C.c_uint32(height)), "vxrt_resize")
         self.width, self.height = int(width), int(height)
 
     def update_bindings(self):
         """Push camera + parameter blocks (Context::update_bindings, src/context.rs:2136-2162)."""
         cam = self.camera
-        _check(lib().vxrt_set_camera(self._h, _p(np.asarray(cam.position, np.float32)),
+        self._chk(self._L.vxrt_set_camera(self._h, _p(np.asarray(cam.position, np.float32)),
                                      _p(np.asarray(cam.direction, np.float32)), C.c_float(cam.fov)), "vxrt_set_camera")
-        _check(lib().vxrt_set_scene_params(self._h, C.byref(self.uniforms)), "vxrt_set_scene_params")
-        _check(lib().vxrt_set_temporal(self._h, C.byref(self.temporal_uniforms)), "vxrt_set_temporal")
-        _check(lib().vxrt_set_denoise(self._h, C.byref(self.denoise_uniforms)), "vxrt_set_denoise")
+        self._chk(self._L.vxrt_set_scene_params(self._h, C.byref(self.uniforms)), "vxrt_set_scene_params")
+        self._chk(self._L.vxrt_set_temporal(self._h, C.byref(self.temporal_uniforms)), "vxrt_set_temporal")
+        self._chk(self._L.vxrt_set_denoise(self._h, C.byref(self.denoise_uniforms)), "vxrt_set_denoise")
 
     def render(self, flags=ALL):
         """Context::render(): frame_number += 1, voxels -> temporal -> denoise, history hand-over."""
         self.update_bindings()
-        _check(lib().vxrt_render(self._h, C.c_uint32(flags)), "vxrt_render")
+        self._chk(self._L.vxrt_render(self._h, C.c_uint32(flags)), "vxrt_render")
 
     def render_frames(self, flags, count):
         """`count` frames with the current camera and parameters in one call (vxrt_render_frames)."""
         self.update_bindings()
-        _check(lib().vxrt_render_frames(self._h, C.c_uint32(flags), C.c_uint32(count)), "vxrt_render_frames")
+        self._chk(self._L.vxrt_render_frames(self._h, C.c_uint32(flags), C.c_uint32(count)), "vxrt_render_frames")
 
     def cast_rays(self, origins, dirs):
         """Test hook (vxrt_debug_cast_rays): the kernels' cast_bounded_ray for given rays -> (hit bool[n], time, node int32, normal[n,3])."""
@@ -475,7 +510,7 @@ class Context:
         d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
         n = len(o)
         hit, time, node, normal = np.zeros(n, np.uint8), np.zeros(n, np.float32), np.zeros(n, np.int32), np.zeros((n, 3), np.float32)
-        _check(lib().vxrt_debug_cast_rays(self._h, _p(o), _p(d), C.c_size_t(n), _p(hit), _p(time), _p(node), _p(normal)), "vxrt_debug_cast_rays")
+        self._chk(self._L.vxrt_debug_cast_rays(self._h, _p(o), _p(d), C.c_size_t(n), _p(hit), _p(time), _p(node), _p(normal)), "vxrt_debug_cast_rays")
         return hit.astype(bool), time, node, normal
 
     def path_log(self, x, y):
@@ -483,7 +518,7 @@ class Context:
         (origin, direction, hit, time, bits(leaf word), normal)."""
         self.update_bindings()
         log, n = np.zeros((32, 12), np.float32), C.c_int32(0)
-        _check(lib().vxrt_debug_path_log(self._h, C.c_int32(x), C.c_int32(y), _p(log), C.byref(n)), "vxrt_debug_path_log")
+        self._chk(self._L.vxrt_debug_path_log(self._h, C.c_int32(x), C.c_int32(y), _p(log), C.byref(n)), "vxrt_debug_path_log")
         return log[:n.value]
 
     def render_path(self, flags, positions, directions, fov=None):
@@ -494,108 +529,108 @@ class Context:
             raise ValueError("one direction per position")
         self.update_bindings()
         fov = self.camera.fov if fov is None else float(np.float32(fov))
-        _check(lib().vxrt_render_path(self._h, C.c_uint32(flags), C.c_uint32(len(pos)), _p(pos), _p(dirs), C.c_float(fov)), "vxrt_render_path")
+        self._chk(self._L.vxrt_render_path(self._h, C.c_uint32(flags), C.c_uint32(len(pos)), _p(pos), _p(dirs), C.c_float(fov)), "vxrt_render_path")
         if len(pos):
             self.camera = Camera(pos[-1], dirs[-1], fov)
 
     def render_spp(self, flags, spp):
         """One displayed frame of `spp` samples per pixel (vxrt_render_spp): spp trace frames averaged, then temporal / denoise."""
         self.update_bindings()
-        _check(lib().vxrt_render_spp(self._h, C.c_uint32(flags), C.c_uint32(spp)), "vxrt_render_spp")
+        self._chk(self._L.vxrt_render_spp(self._h, C.c_uint32(flags), C.c_uint32(spp)), "vxrt_render_spp")
 
     def render_stage(self, flags):
         """vxrt_render without re-pushing parameters (multi-GPU: DENOISE after the halo exchange)."""
-        _check(lib().vxrt_render(self._h, C.c_uint32(flags)), "vxrt_render")
+        self._chk(self._L.vxrt_render(self._h, C.c_uint32(flags)), "vxrt_render")
 
     def culled_pixels(self):
         """vxrt_debug_culled_pixels: primary rays of the next frame (camera as set) that the sky cull decides without a walk."""
         n = C.c_uint64(0)
         self.update_bindings()
-        _check(lib().vxrt_debug_culled_pixels(self._h, C.byref(n)), "vxrt_debug_culled_pixels")
+        self._chk(self._L.vxrt_debug_culled_pixels(self._h, C.byref(n)), "vxrt_debug_culled_pixels")
         return int(n.value)
 
     def set_option(self, option, value):
         """vxrt_set_option: OPT_DENOISE_MODE (0 exact, 1 tolerant), OPT_TAIL_CAPACITY (records per queue shard; 0 = automatic)."""
-        _check(lib().vxrt_set_option(self._h, C.c_int(option), C.c_uint32(value)), "vxrt_set_option")
+        self._chk(self._L.vxrt_set_option(self._h, C.c_int(option), C.c_uint32(value)), "vxrt_set_option")
 
     def sync(self):
-        _check(lib().vxrt_sync(self._h), "vxrt_sync")
+        self._chk(self._L.vxrt_sync(self._h), "vxrt_sync")
 
     def reset_history(self):
-        _check(lib().vxrt_reset_history(self._h), "vxrt_reset_history")
+        self._chk(self._L.vxrt_reset_history(self._h), "vxrt_reset_history")
 
     def set_frame_number(self, n):
-        _check(lib().vxrt_set_frame_number(self._h, C.c_uint32(n)), "vxrt_set_frame_number")
+        self._chk(self._L.vxrt_set_frame_number(self._h, C.c_uint32(n)), "vxrt_set_frame_number")
 
     # -- outputs -------------------------------------------------------------------------------------
     def local_rows(self):
         n = C.c_uint32(0)
-        _check(lib().vxrt_local_rows(self._h, C.byref(n), None), "vxrt_local_rows")
+        self._chk(self._L.vxrt_local_rows(self._h, C.byref(n), None), "vxrt_local_rows")
         rows = np.zeros(n.value, np.uint32)
         if n.value:
-            _check(lib().vxrt_local_rows(self._h, C.byref(n), _p(rows)), "vxrt_local_rows")
+            self._chk(self._L.vxrt_local_rows(self._h, C.byref(n), _p(rows)), "vxrt_local_rows")
         return rows
 
     def read(self, which):
         """-> float32[local_rows, width, 4] (whole frame for a single-GPU context)."""
         n = C.c_uint32(0)
-        _check(lib().vxrt_local_rows(self._h, C.byref(n), None), "vxrt_local_rows")
+        self._chk(self._L.vxrt_local_rows(self._h, C.byref(n), None), "vxrt_local_rows")
         out = np.zeros((n.value, self.width, 4), np.float32)
-        _check(lib().vxrt_read(self._h, C.c_int(which), _p(out), C.c_size_t(out.nbytes)), "vxrt_read")
+        self._chk(self._L.vxrt_read(self._h, C.c_int(which), _p(out), C.c_size_t(out.nbytes)), "vxrt_read")
         return out
 
     def device_image(self, which):
         ptr = C.c_void_p()
         nbytes = C.c_size_t(0)
-        _check(lib().vxrt_device_image(self._h, C.c_int(which), C.byref(ptr), C.byref(nbytes)), "vxrt_device_image")
+        self._chk(self._L.vxrt_device_image(self._h, C.c_int(which), C.byref(ptr), C.byref(nbytes)), "vxrt_device_image")
         return ptr.value, nbytes.value
 
     def stats(self):
         s = Stats()
-        _check(lib().vxrt_get_stats(self._h, C.byref(s)), "vxrt_get_stats")
+        self._chk(self._L.vxrt_get_stats(self._h, C.byref(s)), "vxrt_get_stats")
         return s
 
     def reset_stats(self):
-        _check(lib().vxrt_reset_stats(self._h), "vxrt_reset_stats")
+        self._chk(self._L.vxrt_reset_stats(self._h), "vxrt_reset_stats")
 
     # -- multi-GPU halo (include/vxrt.h "halo") --------------------------------------------------------
     def _push_denoise(self):
         # the halo's row count follows the denoise radius: the library must know the radius the caller has set
-        _check(lib().vxrt_set_denoise(self._h, C.byref(self.denoise_uniforms)), "vxrt_set_denoise")
+        self._chk(self._L.vxrt_set_denoise(self._h, C.byref(self.denoise_uniforms)), "vxrt_set_denoise")
 
     def halo_info(self):
         self._push_denoise()
         info = HaloInfo()
-        _check(lib().vxrt_halo_info_get(self._h, C.byref(info)), "vxrt_halo_info_get")
+        self._chk(self._L.vxrt_halo_info_get(self._h, C.byref(info)), "vxrt_halo_info_get")
         return info
 
     def halo_bytes(self):
         self._push_denoise()
         n = C.c_size_t(0)
-        _check(lib().vxrt_halo_bytes(self._h, C.byref(n)), "vxrt_halo_bytes")
+        self._chk(self._L.vxrt_halo_bytes(self._h, C.byref(n)), "vxrt_halo_bytes")
         return n.value
 
     def halo_pack(self, dev_to_prev, dev_to_next):
         """One pack launch on the context's stream; returns at once (order the communication with stream_wait_context)."""
-        _check(lib().vxrt_halo_pack(self._h, C.c_void_p(dev_to_prev), C.c_void_p(dev_to_next)), "vxrt_halo_pack")
+        self._chk(self._L.vxrt_halo_pack(self._h, C.c_void_p(dev_to_prev), C.c_void_p(dev_to_next)), "vxrt_halo_pack")
 
     def halo_unpack(self, dev_from_prev, dev_from_next):
         """One unpack launch on the context's stream; returns at once."""
-        _check(lib().vxrt_halo_unpack(self._h, C.c_void_p(dev_from_prev), C.c_void_p(dev_from_next)), "vxrt_halo_unpack")
+        self._chk(self._L.vxrt_halo_unpack(self._h, C.c_void_p(dev_from_prev), C.c_void_p(dev_from_next)), "vxrt_halo_unpack")
 
     def stream_wait_context(self, stream):
         """`stream` (a raw hipStream_t, e.g. torch.cuda.Stream.cuda_stream; 0 = the default stream) waits for what the context has enqueued."""
-        _check(lib().vxrt_stream_wait_context(self._h, C.c_void_p(stream)), "vxrt_stream_wait_context")
+        self._chk(self._L.vxrt_stream_wait_context(self._h, C.c_void_p(stream)), "vxrt_stream_wait_context")
 
     def context_wait_stream(self, stream):
         """The context's stream waits for what `stream` has enqueued so far."""
-        _check(lib().vxrt_context_wait_stream(self._h, C.c_void_p(stream)), "vxrt_context_wait_stream")
+        self._chk(self._L.vxrt_context_wait_stream(self._h, C.c_void_p(stream)), "vxrt_context_wait_stream")
 
     def halo_export(self, dev_to_prev, dev_to_next):
         """Synchronous halo_pack."""
-        _check(lib().vxrt_halo_export(self._h, C.c_void_p(dev_to_prev), C.c_void_p(dev_to_next)), "vxrt_halo_export")
+        self._chk(self._L.vxrt_halo_export(self._h, C.c_void_p(dev_to_prev), C.c_void_p(dev_to_next)), "vxrt_halo_export")
 
     def halo_import(self, dev_from_prev, dev_from_next):
         """Synchronous halo_unpack."""
-        _check(lib().vxrt_halo_import(self._h, C.c_void_p(dev_from_prev), C.c_void_p(dev_from_next)),
+        self._chk(self._L.vxrt_halo_import(self._h, C.c_void_p(dev_from_prev), C.c_void_p(dev_from_next)),
                "vxrt_halo_import")

@@ -313,7 +313,10 @@ typedef struct vxrt_halo_info {
     uint32_t slots;             /* bands a message has room for: ceil(bands / nranks)                                    */
     uint32_t bytes_per_pixel;   /* 36                                                                                    */
     uint32_t interior_tile_rows, edge_tile_rows;   /* rows of 16x16 denoise tiles that need no halo / that read it      */
-    uint32_t reserved;
+    uint32_t max_rows;          /* the most rows per band edge this band layout can carry: the lowest band that has a band below it —
+                                 * band_rows, unless the frame is lower than one round of bands (height < nranks * band_rows).  rows =
+                                 * min(max_rows, max(denoise radius, VXRT_OPT_HALO_ROWS)): a larger wish is clamped, and THIS is the
+                                 * bound to pass to vxrt_halo_rows_for_motion (round 5; `reserved` until then)                  */
     uint64_t message_bytes;     /* size of each of the four buffers (>= slots * rows * width * 36, whole 256-byte lines) */
 } vxrt_halo_info;
 int vxrt_halo_info_get(vxrt_ctx* ctx, vxrt_halo_info* out);
@@ -330,8 +333,10 @@ int vxrt_stream_wait_context(vxrt_ctx* ctx, void* stream);
 int vxrt_context_wait_stream(vxrt_ctx* ctx, void* stream);
 /* Synchronous forms: pack / unpack and wait for the launch (the buffers are borrowed for the call only). */
 /* Host-only helper: VXRT_OPT_HALO_ROWS for the exchange after a frame rendered from camera A when the next frame comes from camera B —
- * the largest vertical image motion (rows) of any point at distance >= near_distance between the two, + 2, at most band_rows: with it
- * the next frame's reprojection (shaders/temporal.comp:75-113) finds its history across band edges exactly as one GPU would.  The
+ * the largest vertical image motion (rows) of any point at distance >= near_distance between the two, + 2, at most `band_rows` — pass
+ * vxrt_halo_info.max_rows there, the depth the context's band layout can carry.  While the returned value is BELOW that cap the next
+ * frame's reprojection (shaders/temporal.comp:75-113) finds its history across band edges exactly as one GPU would; a result equal to
+ * the cap says the motion may reach beyond a neighbour's band (rows of a third rank: treated as a disocclusion, temporal.comp:92).  The
  * reference has no counterpart (one GPU sees the whole history); a frame loop sets it one frame ahead on a camera path. */
 int vxrt_halo_rows_for_motion(const float pos_a[3], const float dir_a[3], const float pos_b[3], const float dir_b[3], float fov, uint32_t width,
                               uint32_t height, float near_distance, uint32_t band_rows, uint32_t* rows);

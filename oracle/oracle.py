@@ -79,20 +79,54 @@ class Denoise(C.Structure):
         return cls(0, 2.0, 1.5, 1.0)
 
 
+def _declare(L):
+    L.orc_voxels_from_vox.restype = C.c_long
+    L.orc_create_octree.restype = C.c_long
+    L.orc_trace.restype = C.c_longlong
+    L.orc_trace_menger.restype = C.c_longlong
+    L.orc_menger_lazy_nodes.restype = C.c_longlong
+    L.orc_default_scene.restype = C.c_long
+    L.orc_parse_raw_f32img.restype = C.c_long
+    return L
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
-        _lib = C.CDLL(_LIB_PATH)
-        _lib.orc_voxels_from_vox.restype = C.c_long
-        _lib.orc_create_octree.restype = C.c_long
-        _lib.orc_trace.restype = C.c_longlong
-        _lib.orc_trace_menger.restype = C.c_longlong
-        _lib.orc_menger_lazy_nodes.restype = C.c_longlong
-        _lib.orc_default_scene.restype = C.c_long
-        _lib.orc_parse_raw_f32img.restype = C.c_long
+        _lib = _declare(C.CDLL(_LIB_PATH))
     return _lib
+
+
+_ALT_PATH = os.path.join(_HERE, "_build", "liboracle_alt.so")
+_alt = None
+ALT_LIBM, ALT_NORMALIZE, ALT_SAMPLER, ALT_INVERSE = 1, 2, 4, 8     # oracle/ovec.h: which driver-defined choice is made the other way
+ALT_ALL = 15
+
+
+class alt_builtins:
+    """with oracle.alt_builtins(mask): every call of this module goes to liboracle_alt.so (`make -C oracle alt`), the same restatement
+    with the choices GLSL / Vulkan leave to the driver (U4, U5, U6) made the other way where `mask` says so (oracle/ovec.h).  Only
+    tests/test_oracle_builtin_sensitivity.py uses it: how far can an image move between two conforming implementations?"""
+
+    def __init__(self, mask):
+        self.mask = int(mask)
+
+    def __enter__(self):
+        global _lib, _alt
+        if _alt is None:
+            subprocess.check_call(["make", "-s", "-C", _HERE, "alt"])
+            _alt = _declare(C.CDLL(_ALT_PATH))
+        self._saved = lib()
+        _alt.orc_set_alt(C.c_int(self.mask))
+        _lib = _alt
+        return self
+
+    def __exit__(self, *exc):
+        global _lib
+        _alt.orc_set_alt(C.c_int(0))
+        _lib = self._saved
 
 
 def _p(a):

@@ -30,6 +30,10 @@
 
 namespace orc {
 
+#if ORC_ALT_BUILTINS
+int g_alt_mask = 0;   // ovec.h: which driver-defined choices are made the other way (orc_set_alt)
+#endif
+
 static const float ALMOST_INFINITY = 1073741824.0f;  // float(1 << 30), voxels.comp:8
 static const int32_t LEAF_BIT = (int32_t)0x80000000u;  // voxels.comp:10
 static const int32_t EMMITANCE_BIT = 1 << 30;          // voxels.comp:11
@@ -335,6 +339,20 @@ static void parallel_rows(int y0, int y1, int nthreads, F f) {
 
 // affine inverse of [R U F O; 0 0 0 1] (U5): rows of A^-1 and t = -A^-1 O, as 12 floats.
 static void affine_inverse(const float* R, const float* U, const float* F, const float* O, float inv[12]) {
+#if ORC_ALT_BUILTINS
+    if (g_alt_mask & 8) {   // U5 the other way: the same adjugate / determinant, every operation in binary32
+        float a = R[0], b = U[0], c = F[0], d = R[1], e = U[1], f = F[1], g = R[2], h = U[2], i = F[2];
+        float A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+        float det = (a * A + b * B) + c * C;
+        float m[9] = {A, -(b * i - c * h), b * f - c * e, B, a * i - c * g, -(a * f - c * d), C, -(a * h - b * g), a * e - b * d};
+        for (int r = 0; r < 3; r++) {
+            float r0 = m[3 * r] / det, r1 = m[3 * r + 1] / det, r2 = m[3 * r + 2] / det;
+            inv[4 * r] = r0; inv[4 * r + 1] = r1; inv[4 * r + 2] = r2;
+            inv[4 * r + 3] = -((r0 * O[0] + r1 * O[1]) + r2 * O[2]);
+        }
+        return;
+    }
+#endif
     double a = R[0], b = U[0], c = F[0], d = R[1], e = U[1], f = F[1], g = R[2], h = U[2], i = F[2];
     double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
     double det = a * A + b * B + c * C;
@@ -357,6 +375,9 @@ struct Tex {  // rgba32f image + the Linear/ClampToEdge sampler of src/context.r
         float fx = u * (float)w - 0.5f, fy = v * (float)h - 0.5f;
         float x0 = vx_floor(fx), y0 = vx_floor(fy);
         float ax = vx_floor((fx - x0) * 256.0f + 0.5f) / 256.0f, ay = vx_floor((fy - y0) * 256.0f + 0.5f) / 256.0f;
+#if ORC_ALT_BUILTINS
+        if (g_alt_mask & 4) { ax = fx - x0; ay = fy - y0; }   // U4 the other way: weights at full precision
+#endif
         float t00[4], t10[4], t01[4], t11[4];
         int ix0 = vx_f2i(x0), iy0 = vx_f2i(y0);
         ix0 = ix0 > w ? w : (ix0 < -2 ? -2 : ix0);
@@ -377,6 +398,11 @@ struct Tex {  // rgba32f image + the Linear/ClampToEdge sampler of src/context.r
 using namespace orc;
 
 extern "C" {
+
+#if ORC_ALT_BUILTINS
+// liboracle_alt.so only: bits of ovec.h's table; returns the previous mask
+int orc_set_alt(int mask) { int old = g_alt_mask; g_alt_mask = mask; return old; }
+#endif
 
 // Path-trace rows [y0,y1) x columns [x0,x1) of a width x height frame (voxels.comp main(), one
 // thread per pixel; pixel coordinates are frame-absolute so a crop equals the same region of the

@@ -48,13 +48,23 @@ def scenes():
 
 
 def require_variants(H, env=None, tracer=None, wide=None):
-    """Skip a case that needs a schedule or scene format the default library does not hold (tracers 2 / 3 / 5, the wide records):
-    they are compiled only with -DVXRT_VARIANTS=1 (scripts/test_variants.sh runs these cases over that build)."""
+    """A case that needs a schedule or scene format the product library does not hold (tracers 2 / 3 / 5, the wide records: compiled
+    only with -DVXRT_VARIANTS=1) runs in libvxrt_variants.so, loaded beside the product for the length of the test (round 5; until
+    then these cases were skipped unless VXRT_LIB pointed at that build).  The autouse fixture below switches back."""
     env = env or {}
     needs = (str(env.get("VXRT_TRACE_VARIANT", "")) in ("2", "3", "5") or str(env.get("VXRT_WIDE", "")) == "1" or
              str(tracer) in ("2", "3", "5") or str(wide) in ("1", "True", "wide"))
     if needs and not H.has_variants():
-        pytest.skip("needs libvxrt built with -DVXRT_VARIANTS=1 (scripts/test_variants.sh)")
+        H.use_library(H.variants_library())
+        assert H.has_variants()
+
+
+@pytest.fixture(autouse=True)
+def _product_library_after_each_test():
+    yield
+    from gpu_voxel_raytracer_amd import host
+    if host._LIB is not None and host.has_variants() and not os.environ.get("VXRT_LIB"):
+        host.use_library(None)
 
 
 def have_reference():

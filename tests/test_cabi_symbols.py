@@ -139,3 +139,23 @@ def test_header_is_plain_c_and_a_c99_client_links(tmp_path):
     assert build.returncode == 0, build.stderr
     run = subprocess.run([str(exe)], capture_output=True, text=True)
     assert run.returncode == 0 and run.stdout.split() == ["5", "148", "12", "16", "0.05"], run.stdout
+
+
+def test_variants_library_loads_beside_the_product(H):
+    """The -DVXRT_VARIANTS=1 build (tracers 2 / 3 / 5, the wide scene records) is test infrastructure: the parity cases of those variants
+    load it BESIDE the product library in the same process (conftest.require_variants).  Here, without a GPU: it builds, exports the
+    same C ABI, says what it is, and switching between the two leaves the product the one in use."""
+    from conftest import require_variants
+    product = H.lib()
+    assert not H.has_variants()
+    path = H.variants_library()
+    assert os.path.basename(path) == "libvxrt_variants.so"
+    require_variants(H, tracer=3)
+    assert H.has_variants() and H.lib() is not product
+    missing = [n for n in declared_functions() if not hasattr(H.lib(), n)]
+    assert not missing, missing
+    assert H.lib().vxrt_abi_version() == product.vxrt_abi_version() == 5
+    require_variants(H, tracer=4)            # a default-library case after it does not switch anything by itself ...
+    assert H.has_variants()
+    H.use_library(None)                      # ... the autouse fixture of conftest.py does, after every test
+    assert H.lib() is product and not H.has_variants()

@@ -23,8 +23,8 @@ def hip():
 @pytest.mark.parametrize("nranks,w,h,radius,band,split", [(2, 128, 80, 3, 16, False), (3, 96, 100, 8, 16, True), (4, 160, 72, 1, 16, False),
                                                           (8, 64, 200, 8, 16, False), (5, 80, 40, 2, 16, True), (2, 100, 300, 8, 64, True),
                                                           (3, 64, 250, 4, 32, True), (2, 72, 130, 8, 48, False),
-                                                          # the last round in shorter bands (kernels.h: BandMap): 3 tail bands of 32 rows below one
-                                                          # round of 48-row bands; two 16-row tail bands for four ranks (two of them get none)
+                                                          # frames that are not a whole number of rounds (kernels.h: BandMap): the last round takes
+                                                          # the remainder in taller bands (240 rows / 3 ranks: 80-row bands; 224 / 4: 64 + 64 + 64 + 32)
                                                           (3, 64, 240, 8, 48, True), (4, 96, 224, 4, 48, False), (8, 64, 432, 8, 48, True)])
 def test_bands_and_halo_equal_single_context(H, scenes, noise, nranks, w, h, radius, band, split):
     """split: the denoise stage in two launches around the exchange (DENOISE_INTERIOR before the unpack, DENOISE_EDGE after)."""
@@ -213,3 +213,67 @@ def test_history_rows_cross_band_edges_without_a_denoise_window(H, scenes, noise
             finally:
                 for c in ctxs:
                     c.close()
+
+
+def test_fast_pan_keeps_its_history_on_every_band_edge_when_the_frame_is_not_whole_rounds(H, scenes, noise):
+    """round 4 dealt a frame's remainder as an extra round of LOWER bands and silently capped the halo of the whole frame at
+    them (304 rows on 4 ranks with 32-row bands: 16 rows), so a pan faster than that lost its history at every band edge although the
+    documentation promised band_rows - 2.  Now the last round is taller instead (bands of 48 there), vxrt_halo_info.max_rows says what the
+    layout carries (32), and a ~20-row tilt sized by halo_rows_for_motion against that cap gives the single-context frames bit for bit."""
+    from gpu_voxel_raytracer_amd import ALL, DENOISE, TEMPORAL, TRACE, Camera, Context, distributed
+    from gpu_voxel_raytracer_amd.host import OPT_HALO_ROWS
+    w, h, nranks, band, radius = 160, 304, 4, 32, 2
+    pos, mrgb, size = scenes.load_scene("castle")
+    p0, d0, fov = scenes.close_camera(size)
+    tilt = np.float32(0.06 * float(np.linalg.norm(d0))) * np.array([0, -1, 0], np.float32)
+    path = [(p0, d0), (p0, d0), (p0, d0 + tilt), (p0, d0 + tilt)]
+    layout = distributed.BandLayout(w, h, nranks, band, radius=radius)
+    assert (layout.full_bands, layout.tail_rows, layout.halo_rows_max()) == (4, 48, 32)
+    rt = hip()
+    with Context(w, h, max_bounces=2, noise=noise) as single:
+        ctxs = [Context(w, h, max_bounces=2, noise=noise, rank=r, nranks=nranks, band_rows=band) for r in range(nranks)]
+        try:
+            for c in [single] + ctxs:
+                c.recreate_octree(pos, mrgb)
+                c.denoise_uniforms.radius = radius
+            rows = [c.local_rows() for c in ctxs]
+            for r in range(nranks):
+                assert np.array_equal(rows[r], layout.rows(r))
+            assert ctxs[0].halo_info().max_rows == 32
+            chosen = []
+            for k, (cp, cd) in enumerate(path):
+                nxt = path[min(k + 1, len(path) - 1)]
+                axes = [(c[0],) + Camera(c[0], c[1], fov).axis_scaled(w, h) for c in ((cp, cd), nxt)]
+                want_rows = distributed.halo_rows_for_motion(axes[0], axes[1], w, h, near=0.25, band_rows=layout.halo_rows_max())
+                chosen.append(want_rows)
+                for c in [single] + ctxs:
+                    c.camera = Camera(cp, cd, fov)
+                single.render(ALL)
+                bufs = {}
+                for r, c in enumerate(ctxs):
+                    c.set_option(OPT_HALO_ROWS, want_rows)
+                    c.render(TRACE | TEMPORAL)
+                    nbytes = c.halo_bytes()
+                    assert c.halo_info().rows == max(radius, want_rows)
+                    p, n = C.c_void_p(), C.c_void_p()
+                    assert rt.hipMalloc(C.byref(p), nbytes) == 0 and rt.hipMalloc(C.byref(n), nbytes) == 0
+                    c.halo_export(p.value, n.value)
+                    bufs[r] = (p, n)
+                for r, c in enumerate(ctxs):
+                    c.halo_import(bufs[(r - 1) % nranks][1].value, bufs[(r + 1) % nranks][0].value)
+                    c.render_stage(DENOISE)
+                for c in ctxs:
+                    c.sync()
+                for p, n in bufs.values():
+                    rt.hipFree(p); rt.hipFree(n)
+                for img in (0, 3, 4):
+                    want = single.read(img)
+                    got = np.zeros_like(want)
+                    for c, rr in zip(ctxs, rows):
+                        got[rr] = c.read(img)
+                    assert_bits_equal(got, want, f"frame {k}: image {img}, halo rows {want_rows}")
+            assert chosen[0] == 2 and 17 < chosen[1] < 32 and chosen[2] == 2, chosen      # deeper than round 4's cap of 16, below this layout's 32
+            assert (single.read(1)[..., 3] >= 0).mean() > 0.3                             # the pan looks at geometry, not at sky
+        finally:
+            for c in ctxs:
+                c.close()

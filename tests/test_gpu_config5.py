@@ -11,7 +11,7 @@ Parity status: unpinned by the reference (it has no procedural scene; the config
 import numpy as np
 import pytest
 
-from conftest import assert_bits_equal
+from conftest import assert_bits_equal, require_variants
 from test_oracle_procedural import FULL, compare_with_dda, full_size_cameras, primary_rays
 
 pytestmark = pytest.mark.gpu
@@ -45,7 +45,8 @@ def test_config5_one_rank_of_the_8k_frame_vs_oracle(O, H, noise):
     u = oracle_uniforms(O, cam)
     results = {}
     # 0: what the library picks for a scene of this size; 1: all-in-one kernel; 4: head + compacted tail; "wide": the wide scene records
-    for tracer in (0, 1, 4) + (("wide",) if H.has_variants() else ()):
+    for tracer in (0, 1, 4, "wide"):
+        require_variants(H, wide=tracer)       # the wide records live in the -DVXRT_VARIANTS=1 build, loaded beside the product
         with make_context(noise, 4 if tracer == "wide" else tracer, wide=tracer == "wide") as ctx:
             st = ctx.stats()
             assert (st.scene_format, st.wide_nodes > 30_000_000) == ((1, True) if tracer == "wide" else (0, False))

@@ -57,10 +57,10 @@ def test_config3_full_size_pipeline(O, H, scenes, noise):
 
 def test_config4_eight_ranks_with_halo_at_4k(O, H, scenes, noise):
     """BASELINE configs[3] as this build defines it (BASELINE names no bounce count): castle at 3840x2160, 4 spp,
-    8 bounces, temporal + denoise r = 8 on 8 ranks, 64-row interleaved bands (distributed.band_rows_for: 8 r; since round 4 the last
-    round of bands is dealt in shorter ones — here 7 bands of 16 rows below 32 of 64 — so the busiest rank owns 272 of 2160 rows,
-    270 being even; round 3's whole-band deal gave it 288 with 48-row bands and 320 with 64), the denoise stage split around the
-    halo exchange."""
+    8 bounces, temporal + denoise r = 8 on 8 ranks, 64-row interleaved bands (distributed.band_rows_for: 8 r; the frame is 33.75 such
+    bands, so the last round takes the remainder in taller bands — seven of 80 rows and one of 64 below 24 of 64 — and the busiest rank
+    owns 272 of 2160 rows, 270 being even; round 3's whole-band deal gave it 288 with 48-row bands and 320 with 64), the denoise stage
+    split around the halo exchange."""
     from gpu_voxel_raytracer_amd import ALL, DENOISE_EDGE, DENOISE_INTERIOR, TEMPORAL, TRACE, Camera, Context
     from gpu_voxel_raytracer_amd.distributed import band_rows_for
     w, h, bounces, radius, nranks = 3840, 2160, 8, 8, 8
@@ -84,8 +84,8 @@ def test_config4_eight_ranks_with_halo_at_4k(O, H, scenes, noise):
                 setup(c)
             rows = [c.local_rows() for c in ctxs]
             info = ctxs[0].halo_info()
-            # 32 bands of 64 rows + 7 of 16 over 8 ranks: 5 slots x 8 rows x 3840 px x 36 B = 5.5 MB per message, two per rank and frame
-            assert (info.rows, info.slots) == (8, 5) and info.message_bytes <= 5 * 8 * 3840 * 36 + 256 and 2 * info.message_bytes <= 12e6
+            # 24 bands of 64 rows + 8 of 80 over 8 ranks: 4 slots x 8 rows x 3840 px x 36 B = 4.4 MB per message, two per rank and frame
+            assert (info.rows, info.slots, info.max_rows) == (8, 4, 64) and info.message_bytes <= 4 * 8 * 3840 * 36 + 256 and 2 * info.message_bytes <= 9e6
             assert info.interior_tile_rows >= info.edge_tile_rows - 1 > 0        # two of a 64-row band's four tile rows need no neighbour
             assert [len(r) for r in rows] == [272] * 7 + [256]
             for frame in range(2):

@@ -61,9 +61,9 @@ def test_pipeline_bench_two_ranks_on_one_gpu():
                env={"VXRT_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["steps"] == 4 and "castle" in d["config"]["workload"] and "x2" in d["config"]["parallelism"]
     hl = d["halo"]
-    # 64-row bands (>= 8 r), 34 of them over 2 ranks: two messages of 17 slots x 8 rows x 3840 px x 36 B per rank and frame
+    # 64-row bands (>= 8 r): 30 of them and a last round of 128 + 112 rows over 2 ranks: two messages of 16 slots x 8 rows x 3840 px x 36 B per rank and frame
     assert hl["band_rows"] == 64 and hl["rows"] == 8 and hl["bytes_per_pixel"] == 36
-    assert 2 * 17 * 8 * 3840 * 36 <= hl["bytes_per_rank_per_frame"] <= 2 * 17 * 8 * 3840 * 36 + 512
+    assert 2 * 16 * 8 * 3840 * 36 <= hl["bytes_per_rank_per_frame"] <= 2 * 16 * 8 * 3840 * 36 + 512
     assert hl["pack_ms"] > 0 and hl["unpack_ms"] > 0 and hl["exchange_ms_synchronous"] > 0 and d["value"] > 100.0
     s = d["stage_ms_per_frame"]
     assert s["trace"] > 0 and s["temporal"] > 0 and s["denoise"] > 0

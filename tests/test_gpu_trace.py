@@ -353,10 +353,10 @@ def test_tracer_field_of_the_config(O, H, scenes, noise):
     cam = scenes.close_camera(size)
     imgs = []
     for tracer, bounces in ((0, 8), (1, 8), (2, 8), (3, 8), (4, 8), (5, 8)):
-        if tracer in (2, 3, 5) and not H.has_variants():     # not in the default library: refused, loudly
+        if tracer in (2, 3, 5) and not H.has_variants():     # not in the product library: refused, loudly
             with pytest.raises(VxrtError, match="VXRT_VARIANTS"):
                 Context(128, 80, max_bounces=bounces, noise=noise, tracer=tracer)
-            continue
+            require_variants(H, tracer=tracer)               # ... and run in the -DVXRT_VARIANTS=1 build, loaded beside it
         with Context(128, 80, max_bounces=bounces, noise=noise, tracer=tracer) as ctx:
             ctx.recreate_octree(pos, mrgb)
             ctx.camera = Camera(*cam)

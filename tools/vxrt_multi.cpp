@@ -209,11 +209,12 @@ int main(int argc, char** argv) {
                 const vxrt::Camera base = ctx.camera;
                 if (o.pan != 0.0f && n > 1) {                     // the messages are sized for the largest motion of the path (one size for the run)
                     uint32_t most = 1;
+                    const uint32_t cap = std::max<uint32_t>(ctx.halo_info().max_rows, 1u);    // what this band layout can carry (<= the band height)
                     for (int f = 0; f + 1 < o.frames; f++) {
                         const vxrt::Camera a = camera_of_frame(base, o.pan, f), b = camera_of_frame(base, o.pan, f + 1);
                         uint32_t rows = 0;
                         vxrt::check(vxrt_halo_rows_for_motion(a.position.data(), a.direction.data(), b.position.data(), b.direction.data(), a.fov, o.width,
-                                                              o.height, o.near_distance, o.band, &rows), "vxrt_halo_rows_for_motion");
+                                                              o.height, o.near_distance, cap, &rows), "vxrt_halo_rows_for_motion");
                         most = std::max(most, rows);
                     }
                     ctx.set_option(VXRT_OPT_HALO_ROWS, most);
