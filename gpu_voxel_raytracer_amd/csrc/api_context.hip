@@ -43,6 +43,8 @@ void free_images(vxrt_ctx* c) {
         if (sq.counts3) (void)hipFree(sq.counts3);
         if (sq.rq_block) (void)hipFree(sq.rq_block);
         if (sq.host_counts) (void)hipHostFree(sq.host_counts);
+        if (sq.host_ctl) (void)hipHostFree(sq.host_ctl);
+        if (sq.fused_ctl) (void)hipFree(sq.fused_ctl);
         if (sq.counts_ready) (void)hipEventDestroy(sq.counts_ready);
     }
     c->queues.clear();
@@ -152,6 +154,13 @@ int alloc_images(vxrt_ctx* c) {
 int sync_all(vxrt_ctx* c) {
     for (hipStream_t t : c->trace_streams) HIP_TRY(hipStreamSynchronize(t));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    for (vxrt_ctx::StreamQueues& sq : c->queues)      // fused_kernel's report of the last launch (copied back behind it)
+        if (sq.host_ctl != nullptr && sq.host_ctl[2] != 0u) { c->fused_errors++; sq.host_ctl[2] = 0u; }
+    if (c->fused_errors != 0) {
+        c->fused_errors = 0;
+        set_error("fused head + tail: a bounded wait of fused_kernel ran out (frames of the last launches are incomplete)");
+        return VXRT_E_DEVICE;
+    }
     return VXRT_OK;
 }
 
@@ -165,7 +174,7 @@ int set_band(vxrt_ctx* c, uint32_t width, uint32_t height) {
     b.band_rows = cfg.band_rows == 0 ? 16 : int(cfg.band_rows);
     if (b.nranks == 1) b.rank = 0;
     // whole rounds of nranks bands at band_rows rows; the LAST round takes what is left as well, in taller bands (kernels.h: BandMap)
-    const int tile = b.band_rows % 16 == 0 ? 16 : 8;
+    const int tile = b.band_rows % 16 == 0 ? 16 : (b.band_rows % 8 == 0 ? 8 : b.band_rows);
     const int round_rows = b.nranks * b.band_rows;
     int rounds = b.height / round_rows;
     if (b.height % round_rows != 0 && rounds > 0) rounds -= 1;               // fold the remainder into the last whole round
@@ -329,6 +338,18 @@ int apply_option(vxrt_ctx* c, uint32_t option, uint32_t value, bool at_create) {
             if (!create_only()) return VXRT_E_INVALID;
             c->rays_per_wave = value;
             return VXRT_OK;
+        case VXRT_OPT_FUSED_TAIL:
+            if (value > 1) { set_error("fused tail must be 0 or 1"); return VXRT_E_INVALID; }
+            c->fused_tail = int(value);
+            return VXRT_OK;
+        case VXRT_OPT_LONG_TILES:
+            if (value > 500) { set_error("long tiles: 0 (off) .. 500 per mille of the tiles"); return VXRT_E_INVALID; }
+            c->long_tiles_permille = value;
+            return VXRT_OK;
+        case VXRT_OPT_HEAD_STAGGER:
+            if (value > 1) { set_error("head stagger must be 0 or 1"); return VXRT_E_INVALID; }
+            c->head_stagger = int(value);
+            return VXRT_OK;
         default:
             set_error("unknown option");
             return VXRT_E_INVALID;
@@ -388,7 +409,10 @@ int vxrt_create_tuned(const vxrt_config* cfg, const vxrt_tuning* tuning, size_t 
     uint32_t nranks = cfg->nranks == 0 ? 1 : cfg->nranks;
     if (nranks > 1 && cfg->rank >= nranks) { set_error("rank >= nranks"); return VXRT_E_INVALID; }
     uint32_t band_rows = cfg->band_rows == 0 ? 16 : cfg->band_rows;
-    if (band_rows % 8 != 0) { set_error("band_rows must be a multiple of 8 (of 16 for a denoise radius > 0)"); return VXRT_E_INVALID; }
+    // 16 for a denoise window (its 16 x 16 tiles must not straddle bands: check_render); 8 = the tracer's tile height, what a launch of
+    // single frames wants (a wave is an 8 x 8 pixel tile); 2 or 4 rows are for launches of frame groups, whose waves hold 2 rows x 4
+    // frames or 1 row x 8 frames (VXRT_OPT_FRAME_LANES): the finer the interleave, the more alike the ranks' shares
+    if (band_rows % 2 != 0 || (band_rows % 8 != 0 && band_rows > 8)) { set_error("band_rows must be 2, 4 or a multiple of 8 (of 16 for a denoise radius > 0)"); return VXRT_E_INVALID; }
 
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -448,6 +472,9 @@ int vxrt_create_tuned(const vxrt_config* cfg, const vxrt_tuning* tuning, size_t 
     }
     c->launch_events.assign(size_t(c->inflight) * 2, nullptr);
     c->launch_event_turn.assign(size_t(c->inflight), 0u);
+    c->head_events.assign(size_t(c->inflight), nullptr);
+    for (hipEvent_t& e : c->head_events)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipEventCreate"));
     for (hipEvent_t& e : c->launch_events)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipEventCreate"));
     set_band(c, cfg->width, cfg->height);
@@ -481,6 +508,10 @@ int vxrt_destroy(vxrt_ctx* c) try {
     for (hipStream_t t : c->trace_streams) if (t && t != c->stream) (void)hipStreamDestroy(t);
     if (c->halo_event) (void)hipEventDestroy(c->halo_event);
     for (hipEvent_t e : c->launch_events) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->head_events) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->aux_fork) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->aux_join) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t t : c->aux_streams) if (t) (void)hipStreamDestroy(t);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return VXRT_OK;

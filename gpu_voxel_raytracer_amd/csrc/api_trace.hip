@@ -35,6 +35,7 @@ int resize_tail_queues(vxrt_ctx* c, unsigned want) {
                 c->queue_bytes += new_bytes - old_bytes;
             }
     c->shard_capacity = want;
+    for (vxrt_ctx::StreamQueues& q : c->queues) q.stamps_clean = false;   // fresh memory: fused_kernel's stamps must be cleared before its next launch
     return VXRT_OK;
 }
 
@@ -45,6 +46,7 @@ int grow_tail_queues(vxrt_ctx* c, size_t lane) {
     vxrt_ctx::StreamQueues& sq = c->queues[lane];
     if (!sq.counts_pending || hipEventQuery(sq.counts_ready) != hipSuccess) return VXRT_OK;
     sq.counts_pending = false;
+    if (sq.host_ctl != nullptr && sq.host_ctl[2] != 0u) { c->fused_errors++; sq.host_ctl[2] = 0u; }
     unsigned peak = 0;
     for (unsigned s = 0; s < 64; s++) {
         const unsigned n = sq.host_counts[s * 16];
@@ -91,6 +93,7 @@ void frame_constants(const vxrt_ctx* c, TraceArgs& a) {
     a.band = c->band;
     a.max_bounces = int(c->cfg.max_bounces);
     a.launch_index = 0;
+    a.block_first = 0;
     a.cull = 0;
     a.stack_levels = c->depth < 1 ? 1 : int(c->depth);
     // voxels.comp:296 and the other per-frame constants, evaluated once with the same operations
@@ -232,15 +235,92 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
                 a.tail = PathQueue{sq.hitq[0], sets[(J + 1) % 3], c->shard_capacity};
                 a.tail_zero = sets[(J + 2) % 3];
                 a.tail_from = c->tail_from;
-                HIP_TRY(launch_trace(a, use_wide(c) && c->trace_variant == 4, scene_bytes > (size_t(256) << 20), ts));
+                // head stagger (VXRT_OPT_HEAD_STAGGER): this launch's head starts when the previous launch's head (another stream) has
+                // finished, so that a head runs beside the previous launch's tail instead of beside its head
+                if (c->head_stagger && c->last_head_lane >= 0 && size_t(c->last_head_lane) != lane)
+                    HIP_TRY(hipStreamWaitEvent(ts, c->head_events[size_t(c->last_head_lane)], 0));
+                // Fused head + tail (VXRT_OPT_FUSED_TAIL): one grid of persistent waves takes the launch's blocks and then its queued
+                // paths, chunk by chunk as they become complete (trace.hip: fused_kernel).  For tails of ONE launch (the 4-bounce
+                // benchmark; a tail that compacts again keeps its launches), the 8-byte records, scenes in cache.
+                bool one_tail_launch = true, fused_done = false;
+                for (int k = c->tail_from + 1; k < int(c->cfg.max_bounces); k++)
+                    if (sq.hitq[1] && ((c->tail_split >> k) & 1u)) one_tail_launch = false;
+                if (c->fused_tail && c->trace_variant == 4 && one_tail_launch && !use_wide(c) && scene_bytes <= (size_t(256) << 20) && c->tail_from < int(c->cfg.max_bounces)) {
+                    if (sq.fused_ctl == nullptr) {
+                        HIP_TRY(hipMalloc(&sq.fused_ctl, fused_ctl_bytes()));
+                        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sq.host_ctl), 64, hipHostMallocDefault));
+                        memset(sq.host_ctl, 0, 64);
+                    }
+                    if (!sq.stamps_clean) {   // once per allocation of the queue: every slot's stamp must read 0
+                        HIP_TRY(hipMemsetAsync(sq.hitq[0], 0, (size_t(c->shard_capacity) * 64 + 1) * 64, ts));
+                        sq.stamps_clean = true;
+                    }
+                    HIP_TRY(hipMemsetAsync(sq.fused_ctl, 0, fused_ctl_bytes(), ts));
+                    const uint32_t stamp = (sq.fused_launches++ % 65535u) + 1u;
+                    const unsigned all_blocks = trace_tile_count(c->band.width, c->band.local_rows) * g;
+                    HIP_TRY(launch_fused(a, sq.fused_ctl, c->wave_slots < all_blocks ? c->wave_slots : all_blocks, stamp, ts));
+                    if (a.frame_lanes) c->frame_lane_launches++;
+                    sq.launches = J + 1;          // one kernel: it wrote set (J + 1) % 3 and cleared (J + 2) % 3, which the next launch writes
+                    if (!sq.counts_pending) {
+                        HIP_TRY(hipMemcpyAsync(sq.host_counts, sets[(J + 1) % 3], 64 * 64, hipMemcpyDeviceToHost, ts));
+                        HIP_TRY(hipMemcpyAsync(sq.host_ctl, sq.fused_ctl, 16, hipMemcpyDeviceToHost, ts));
+                        HIP_TRY(hipEventRecord(sq.counts_ready, ts));
+                        sq.counts_pending = true;
+                        sq.counts_capacity = c->shard_capacity;
+                    }
+                    fused_done = true;
+                }
+                if (!fused_done) {
+                // The longest tiles apart (VXRT_OPT_LONG_TILES, per mille of the tiles): the first tiles of the launch order — the
+                // longest chains of the last frames — run as an all-in-one grid of their own on a second stream (no hand-over: a
+                // path's whole chain in ONE wave, begun at the launch's start), beside the head + tail pair of all other tiles.  A
+                // launch that is little more than its chains (a rank's share of a short block on 8 GPUs) is two chains long as head +
+                // tail and one as the all-in-one kernel, which in turn needs 1.3 x the instructions: this takes the one chain where
+                // it matters and the cheaper instructions everywhere else.  Same pixels, same arithmetic, either way.
+                unsigned long_blocks = 0;
+                if (c->long_tiles_permille > 0 && a.tile_order != nullptr && c->trace_variant == 4 && !use_wide(c) && scene_bytes <= (size_t(256) << 20)) {
+                    const unsigned tiles = trace_tile_count(c->band.width, c->band.local_rows);
+                    unsigned n = unsigned((unsigned long long)tiles * c->long_tiles_permille / 1000u);
+                    n = n < 1u ? 1u : (n >= tiles ? tiles - 1u : n);
+                    long_blocks = n * g;
+                    if (c->aux_streams.size() <= lane) c->aux_streams.resize(lane + 1, nullptr);
+                    if (c->aux_fork.size() <= lane) { c->aux_fork.resize(lane + 1, nullptr); c->aux_join.resize(lane + 1, nullptr); }
+                    if (c->aux_streams[lane] == nullptr) {
+                        HIP_TRY(hipStreamCreateWithFlags(&c->aux_streams[lane], hipStreamNonBlocking));
+                        HIP_TRY(hipEventCreateWithFlags(&c->aux_fork[lane], hipEventDisableTiming));
+                        HIP_TRY(hipEventCreateWithFlags(&c->aux_join[lane], hipEventDisableTiming));
+                    }
+                    TraceArgs al = a;
+                    al.tail = PathQueue{nullptr, nullptr, 0};     // nothing is handed over: trace_kernel follows these paths to their end
+                    al.tail_zero = nullptr;
+                    HIP_TRY(hipEventRecord(c->aux_fork[lane], ts));                       // after everything this launch waits for
+                    HIP_TRY(hipStreamWaitEvent(c->aux_streams[lane], c->aux_fork[lane], 0));
+                    HIP_TRY(launch_trace(al, false, false, c->aux_streams[lane], 0u, long_blocks));
+                    HIP_TRY(hipEventRecord(c->aux_join[lane], c->aux_streams[lane]));
+                }
+                HIP_TRY(launch_trace(a, use_wide(c) && c->trace_variant == 4, scene_bytes > (size_t(256) << 20), ts, long_blocks, 0u));
+                if (c->head_stagger) {
+                    HIP_TRY(hipEventRecord(c->head_events[lane], ts));
+                    c->last_head_lane = int(lane);
+                }
                 if (a.frame_lanes && !(use_wide(c) && c->trace_variant == 4) && scene_bytes <= (size_t(256) << 20)) c->frame_lane_launches++;
                 sq.launches = J + 1;
-                if (!sq.counts_pending) {   // how much room this launch wanted (the set stays untouched until launch J + 2 clears it)
+                // how much room this launch wanted: its counter set, copied back for grow_tail_queues.  The set stays untouched until
+                // launch J + 2 clears it, so when the tail is ONE launch (J + 1) the copy goes behind it — a copy between the head and
+                // the tail costs the stream ~10 us of copy-engine hand-over on a block's critical path (round 5: the time line of a
+                // rank of 8 showed trace_kernel -> 4 us copy -> 5.6 us gap -> bounce_kernel); a tail of several launches clears it sooner
+                bool single_tail_launch = c->trace_variant == 4;
+                for (int k = c->tail_from + 1; k < int(c->cfg.max_bounces); k++)
+                    if (sq.hitq[1] && ((c->tail_split >> k) & 1u)) single_tail_launch = false;
+                auto copy_counts = [&]() -> int {
+                    if (sq.counts_pending) return VXRT_OK;
                     HIP_TRY(hipMemcpyAsync(sq.host_counts, sets[(J + 1) % 3], 64 * 64, hipMemcpyDeviceToHost, ts));
                     HIP_TRY(hipEventRecord(sq.counts_ready, ts));
                     sq.counts_pending = true;
                     sq.counts_capacity = c->shard_capacity;
-                }
+                    return VXRT_OK;
+                };
+                if (!single_tail_launch) { if (int rc = copy_counts()) return rc; }
 #if VXRT_VARIANTS
                 if (c->trace_variant == 5) {
                     HIP_TRY(launch_paths(a, a.tail, sets[J % 3], c->tail_from, c->path_blocks, ts));
@@ -252,6 +332,9 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
                     PathQueue queues[2] = {{sq.hitq[0], nullptr, c->shard_capacity}, {sq.hitq[1], nullptr, sq.hitq[1] ? c->shard_capacity : 0u}};
                     HIP_TRY(launch_bounces(a, use_wide(c), queues, sets, &sq.launches, c->trace_blocks, sq.hitq[1] ? c->tail_split : 0u, c->tail_from, ts));
                 }
+                if (single_tail_launch) { if (int rc = copy_counts()) return rc; }
+                if (long_blocks != 0u) HIP_TRY(hipStreamWaitEvent(ts, c->aux_join[lane], 0));   // the launch is over when both grids are
+                }   // !fused_done
             } else {
                 HIP_TRY(launch_trace(a, use_wide(c), scene_bytes > (size_t(256) << 20), ts));
                 if (a.frame_lanes && !use_wide(c) && scene_bytes <= (size_t(256) << 20)) c->frame_lane_launches++;

@@ -103,6 +103,14 @@ struct vxrt_ctx {
     std::vector<hipStream_t> trace_streams;   // inflight entries; entry 0 is `stream` when inflight == 1
     char* ring_arena = nullptr;               // the ring's images: one allocation (alloc_images)
     std::vector<hipEvent_t> launch_events;    // two per trace stream, used alternately: "this launch has finished"
+    std::vector<hipEvent_t> head_events;      // one per trace stream: "this stream's last trace_kernel has finished" (VXRT_OPT_HEAD_STAGGER)
+    std::vector<hipStream_t> aux_streams;     // one per trace stream, made on first use: the all-in-one grid of the longest tiles (VXRT_OPT_LONG_TILES)
+    std::vector<hipEvent_t> aux_fork, aux_join;
+    uint32_t long_tiles_permille = 0;         // 0: off
+    int fused_tail = 0;                       // VXRT_OPT_FUSED_TAIL: head and compacted tail of a launch as one grid of persistent waves
+    uint64_t fused_errors = 0;                // launches whose fused_kernel gave up a bounded wait (reported by vxrt_sync)
+    int head_stagger = 0;                     // 1: a launch's head waits for the previous launch's head on another stream
+    int last_head_lane = -1;
     std::vector<unsigned> launch_event_turn;
     int slot = 0;        // slot of the most recently traced frame
     int hist_slot = -1;  // slot whose normal/depth pairs with accum[hist] as the temporal history
@@ -152,6 +160,11 @@ struct vxrt_ctx {
         hipEvent_t counts_ready = nullptr;
         bool counts_pending = false;
         unsigned counts_capacity = 0;           // the shard capacity of the launch whose counters host_counts holds
+        // fused head + tail (VXRT_OPT_FUSED_TAIL; trace.hip: fused_kernel)
+        void* fused_ctl = nullptr;              // the launch's cursors, zeroed on the stream before every launch
+        unsigned* host_ctl = nullptr;           // pinned: the first 16 bytes of fused_ctl after a launch (word 2: a bounded wait ran out)
+        bool stamps_clean = false;              // every record slot of hitq[0] carries stamp 0 (set when the queue is cleared, lost when it is re-allocated)
+        unsigned fused_launches = 0;            // -> the launch's stamp, 1 .. 65535
     };
     std::vector<StreamQueues> queues;
     unsigned shard_capacity = 0;        // records per shard of the path queues

@@ -120,6 +120,7 @@ struct TraceArgs {
     int max_bounces;
     uint32_t frame_number;
     uint32_t launch_index;  // counts trace launches of the context (persistent kernel: which tile counter to use)
+    uint32_t block_first;   // trace_kernel: this grid's block 0 is block `block_first` of the launch (a launch in two grids: VXRT_OPT_LONG_TILES)
     int stack_levels;  // LDS stack entries per thread (= octree depth, >= 1)
     Cam cam;                 // = cams[0]: the single-frame kernels use this
     Cam cams[kMaxBatch];     // trace_kernel: frame f of the launch is seen through cams[f] (all equal for a camera at rest)
@@ -213,7 +214,11 @@ struct RayQueue {
 
 // `wide`: walk the wide records (TraceArgs::wide) instead of the 8-byte ones; same results
 // hbm_scene: the kernel compiled for one more wave per SIMD (a scene beyond the Infinity Cache)
-hipError_t launch_trace(const TraceArgs& a, bool wide, bool hbm_scene, hipStream_t s);
+// head and compacted tail of a launch as one grid of `waves` persistent waves (trace.hip: fused_kernel); ctl: fused_ctl_bytes() of zeros
+size_t fused_ctl_bytes();
+hipError_t launch_fused(const TraceArgs& a, void* ctl, unsigned waves, uint32_t stamp, hipStream_t s);
+// blocks [block_first, block_first + block_count) of the launch's tiles x frames; block_count 0: all of them
+hipError_t launch_trace(const TraceArgs& a, bool wide, bool hbm_scene, hipStream_t s, unsigned block_first = 0, unsigned block_count = 0);
 // test hook: the walk (cast_ray) for caller-given rays; out = 8 floats per ray (hit, time, bits(leaf word), normal, 0, 0)
 hipError_t launch_path_log(const TraceArgs& a, bool wide, int x, int y, float* log, hipStream_t s);
 hipError_t launch_count_culled(const TraceArgs& a, unsigned long long* count, hipStream_t s);   // diagnostics: pixels the sky cull decides

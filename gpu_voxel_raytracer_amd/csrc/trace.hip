@@ -32,6 +32,7 @@
 #include "vx_vec.h"
 
 #include "trace_common.h"
+#include "trace_tail_body.h"
 
 namespace vxrt {
 namespace {
@@ -95,10 +96,11 @@ constexpr int kTileW = kTB == 64 ? 8 : 16, kTileH = kTB == 256 ? 16 : 8;
 // rounds closer together (priced on the oracle's step counts, tests/sim_schedule.py: lane_mappings: - 12 % wave-instructions in this
 // kernel for kF = 8, - 10 % for 4; measured + 7 % on the bench view); each frame's stores stay whole 128-byte row segments (4 x 2
 // pixels x 8 frames, 64-byte segments, is priced 3 % better and measured 6 % worse).  The per-pixel operations are the same either way.
-template <bool kWide, int kWaves, int kF>
-__global__ __launch_bounds__(kTB, kWaves) void trace_kernel(const TraceArgs a) {
+// kFused: the block is one item of fused_kernel's head phase — `bid` comes from its work cursor, and a path that is handed over is
+// stored for a consumer that may be polling the record already (queue_store_fused).
+template <bool kWide, int kF, bool kFused>
+__device__ __forceinline__ void trace_block(const TraceArgs& a, const unsigned bid, uint4* lds_stack, const uint32_t stamp) {
     static_assert(kF == 1 || ((kF == 4 || kF == 8) && kTB == 64), "frame lanes: one wave per block");
-    extern __shared__ uint4 lds_stack[];  // the threads' frames: Caster<kWide>
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     // One kTileW x kTileH pixel tile per block, an 8x8 sub-tile per wave.  Blocks take tiles in the order of tile_order
@@ -112,9 +114,9 @@ __global__ __launch_bounds__(kTB, kWaves) void trace_kernel(const TraceArgs a) {
     const unsigned batch = unsigned(a.batch);
     constexpr unsigned kRows = 8u / unsigned(kF);
     const unsigned groups = batch / unsigned(kF);
-    const unsigned fb = (blockIdx.x % groups) * unsigned(kF) + unsigned(lane >> 3) / kRows;
-    const unsigned row_in_tile = ((blockIdx.x / groups) % unsigned(kF)) * kRows + unsigned(lane >> 3) % kRows;
-    const unsigned ord = blockIdx.x / batch;
+    const unsigned fb = (bid % groups) * unsigned(kF) + unsigned(lane >> 3) / kRows;
+    const unsigned row_in_tile = ((bid / groups) % unsigned(kF)) * kRows + unsigned(lane >> 3) % kRows;
+    const unsigned ord = bid / batch;
     const bool gbuf = ((a.gbuf_frames >> fb) & 1u) != 0u;   // this frame's normal/depth and albedo/node images are wanted
     const unsigned tile = a.tile_order ? a.tile_order[ord] : ord;
     const int x = int(tile % tiles_x) * kTileW + (wave & 1) * 8 + (lane & 7);
@@ -127,8 +129,8 @@ __global__ __launch_bounds__(kTB, kWaves) void trace_kernel(const TraceArgs a) {
     // the shard of the tail queue this wave appends to: the top bits of a multiplicative hash of the wave's index, because the waves
     // that append (tiles that see geometry) can sit at regular distances in the launch order (tile_scatter_kernel)
     static_assert(kShards == 64, "6 hash bits");
-    const unsigned tail_shard = ((blockIdx.x * unsigned(kTB / 64) + unsigned(wave)) * 0x9E3779B1u) >> 26;
-    if (a.tail.recs != nullptr) zero_counts(a.tail_zero, tid);
+    const unsigned tail_shard = ((bid * unsigned(kTB / 64) + unsigned(wave)) * 0x9E3779B1u) >> 26;
+    if (!kFused && a.tail.recs != nullptr) zero_counts(a.tail_zero, tid);
     bool walk = active;
     if (active) {   // the sky cull: a pixel whose primary ray certainly misses needs no walk
         const Cam& cam = a.cams[cam_index];
@@ -246,7 +248,8 @@ __global__ __launch_bounds__(kTB, kWaves) void trace_kernel(const TraceArgs a) {
                     rec.blend = blend;
                     rec.rng_index = rng.index;
                     rec.pix = uint32_t(pix) | fb << kPixBits;
-                    queue_store(a.tail, tail_shard, slot, rec);
+                    if (kFused) queue_store_fused(a.tail, tail_shard, slot, rec, stamp);
+                    else queue_store(a.tail, tail_shard, slot, rec);
                     handed_over = true;
                     break;
                 }
@@ -305,6 +308,123 @@ __global__ __launch_bounds__(kTB, kWaves) void trace_kernel(const TraceArgs a) {
         const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_start;
         atomicMax(a.tile_cost + tile, light_wave ? kLightCost : (dt > 0xffffffffull ? 0xffffffffu : (dt < 4ull ? 4u : uint32_t(dt))));
     }
+}
+
+template <bool kWide, int kWaves, int kF>
+__global__ __launch_bounds__(kTB, kWaves) void trace_kernel(const TraceArgs a) {
+    extern __shared__ uint4 lds_stack[];  // the threads' frames: Caster<kWide>
+    // a launch may come as two grids (the longest tiles apart: VXRT_OPT_LONG_TILES)
+    trace_block<kWide, kF, false>(a, blockIdx.x + a.block_first, lds_stack, 0u);
+}
+
+
+// ---- fused_kernel: head and compacted tail of a launch in ONE grid of persistent waves (VXRT_OPT_FUSED_TAIL) ----------------------------
+// A launch that is little more than its longest chains — a rank's share of a short block on many GPUs: 20 frames of an eighth of the
+// rows — spends its time DRAINING: trace_kernel ends when its longest wave ends (the chip two thirds idle by then), and only then may
+// bounce_kernel start, which drains again.  Two chains end to end, at 83 % and 64 % of the instruction rate the same kernels reach in
+// the steady state (round 5: profiles/r05/short_block_timelines.txt).  Here the waves are persistent: each takes the launch's blocks
+// (tile x frame group, in the launch order: longest first) from a cursor, and when those run out it takes CHUNKS of 64 queued paths,
+// as soon as a chunk is complete — the tail of the paths handed over early runs beside the long head chains, and nothing waits for a
+// kernel boundary.  Same records, same per-path operations (trace_block, bounce_path): same image.
+//
+// Protocol.  A head lane reserves its record slot with the shard's counter (queue_reserve, as before) and stores the record with
+// queue_store_fused: seven 8-byte stores at agent scope (write-through, visible to every XCD), s_waitcnt, then the eighth, which holds
+// the launch's 16-bit stamp in the unused top of normal_ambient.  A consumer lane polls that word (agent scope: served from memory,
+// not from its XCD's L2) until the stamp is there, then reads the rest and writes the word back with stamp 0.  After its last block
+// a wave adds to `blocks_done`; when that reaches the total every shard counter is final and what is left (part-filled last chunks)
+// is taken too.  Waiting is bounded in three ways: a wave only waits for work that resident, running waves are producing (a block is
+// claimed by a wave that is already running, so no wave ever waits for one that has no slot); every spin sleeps; and a spin that lasts
+// ~2^20 polls sets ctl->error and gives up (the frame is then wrong and vxrt_sync reports it, but the grid drains).
+struct FusedCtl {
+    unsigned next_block;   // head work cursor
+    unsigned blocks_done;  // head blocks finished (their records stored and stamped)
+    unsigned error;        // a bounded wait ran out
+    unsigned pad[13];
+    unsigned next_chunk[kShards * kCountStride];   // per shard: the next chunk nobody has claimed yet (one 64-byte line each)
+};
+
+__device__ __forceinline__ unsigned agent_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int kF>
+__global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void fused_kernel(const TraceArgs a, FusedCtl* ctl, const unsigned total_blocks, const uint32_t stamp,
+                                                                      const int first_bounce) {
+    static_assert(kTB == 64, "one wave per block");
+    extern __shared__ uint4 lds_stack[];
+    const int lane = threadIdx.x & 63;
+    zero_counts(a.tail_zero, threadIdx.x);
+    // ---- head phase: the launch's blocks, in launch order
+    for (;;) {
+        unsigned b = 0;
+        if (lane == 0) b = atomicAdd(&ctl->next_block, 1u);
+        b = __builtin_amdgcn_readfirstlane(b);
+        if (b >= total_blocks) break;
+        trace_block<false, kF, true>(a, b, lds_stack, stamp);
+        __builtin_amdgcn_s_waitcnt(0);             // this wave's record stores (and their stamps) have been written through
+        if (lane == 0) atomicAdd(&ctl->blocks_done, 1u);
+    }
+    // ---- tail phase: chunks of 64 records, shard by shard starting at this wave's own
+    const Caster<false> caster(a, lds_stack, int(threadIdx.x));
+    const f3 sun_dir = ld3(a.sun_dir), sun_color = ld3(a.sun_color), sky = ld3(a.sky_color);
+    const PathQueue none{nullptr, nullptr, 0u};
+    uint32_t rays = 0;
+    unsigned shard = blockIdx.x % kShards;
+    unsigned idle_polls = 0;
+    for (;;) {
+        const bool heads_done = agent_load(&ctl->blocks_done) >= total_blocks;     // read BEFORE the counters: then they are final
+        bool got = false;
+        unsigned chunk = 0, reserved = 0;
+        for (unsigned t = 0; t < kShards && !got; t++) {                           // uniform: every lane sees the same values
+            const unsigned q = (shard + t) % kShards;
+            unsigned n = agent_load(a.tail.counts + q * kCountStride);
+            n = n < a.tail.shard_capacity ? n : a.tail.shard_capacity;
+            const unsigned next = agent_load(&ctl->next_chunk[q * kCountStride]);
+            // a whole chunk is reserved (its records are there or on their way), or the shard is final and holds a part-filled one
+            if ((next + 1u) * 64u <= n || (heads_done && next * 64u < n)) {
+                unsigned c = 0;
+                if (lane == 0) c = atomicAdd(&ctl->next_chunk[q * kCountStride], 1u);
+                c = __builtin_amdgcn_readfirstlane(c);
+                if ((c + 1u) * 64u <= n || (heads_done && c * 64u < n)) { got = true; chunk = c; reserved = n; shard = q; }
+                // else: another wave took it between the look and the claim; the cursor has moved past what exists, which is harmless
+                // for whole chunks (nobody claims beyond the counter) — but a claim beyond a part-filled shard's end must not be lost:
+                else if (c * 64u < n || !heads_done) {
+                    // c is a chunk that is (or may still become) real but is not complete yet: keep it and wait for it below
+                    got = true; chunk = c; reserved = n; shard = q;
+                }
+            }
+        }
+        if (!got) {
+            if (heads_done) break;                 // every counter was final and every chunk is claimed: done
+            __builtin_amdgcn_s_sleep(64);
+            if (++idle_polls > (1u << 22)) { if (lane == 0) atomicOr(&ctl->error, 1u); break; }
+            continue;
+        }
+        // lane i takes record 64 chunk + i: wait for its stamp (it may not even be reserved yet when the chunk was claimed early)
+        const unsigned entry = chunk * 64u + unsigned(lane);
+        unsigned long long* word = reinterpret_cast<unsigned long long*>(a.tail.recs + (size_t(shard) * a.tail.shard_capacity + entry) * 4u) + 3;  // dir.z | normal_ambient
+        bool valid = false;
+        unsigned long long w3 = 0ull;
+        if (entry < a.tail.shard_capacity) {
+            for (unsigned polls = 0;; polls++) {
+                w3 = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (unsigned(w3 >> 48) == stamp) { valid = true; break; }
+                // not there: it is coming if it is reserved; if the heads are done and the final counter does not reach it, it never will
+                if (agent_load(&ctl->blocks_done) >= total_blocks) {
+                    unsigned n = agent_load(a.tail.counts + shard * kCountStride);
+                    n = n < a.tail.shard_capacity ? n : a.tail.shard_capacity;
+                    if (entry >= n) break;
+                }
+                __builtin_amdgcn_s_sleep(16);
+                if (polls > (1u << 20)) { atomicOr(&ctl->error, 2u); break; }
+            }
+        }
+        (void)reserved;
+        if (valid) {
+            PathRec rec = load_rec_fused(a.tail.recs + (size_t(shard) * a.tail.shard_capacity + entry) * 4u, w3);
+            __hip_atomic_store(word, w3 & 0x0000ffffffffffffull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // stamp 0: the slot is free for the next launch
+            bounce_path<false>(a, caster, rec, none, shard, first_bounce, a.max_bounces, sun_dir, sun_color, sky, rays);
+        }
+    }
+    count_rays(a.ray_counter, rays, lane);
 }
 
 // Counting sort of the tiles by descending cost (key = log2 of the cost with two mantissa bits: 128 bins) in three small launches:
@@ -540,12 +660,15 @@ void trace_tile_dims(int* w, int* h) { *w = kTileW; *h = kTileH; }
 // hbm_scene: the scene does not fit the Infinity Cache (BASELINE config 5: 5.6 GB), so a descend waits for HBM and one more wave per
 // SIMD hides more of that than its spilled registers cost: 2.25 -> 2.08 ms (outside view), 15.5 -> 14.1 ms (tunnel) at 4K, 8 bounces;
 // 8 waves: 3.79 / 26.1 ms.  On a cache-resident scene the same change loses 3-5 %.
-hipError_t launch_trace(const TraceArgs& args, bool wide, bool hbm_scene, hipStream_t s) {
+hipError_t launch_trace(const TraceArgs& args, bool wide, bool hbm_scene, hipStream_t s, unsigned block_first, unsigned block_count) {
     TraceArgs a = args;
+    a.block_first = block_first;
     // those kernels exist with one frame per wave only (for a scene in HBM, config 5 at 16 spp, frame lanes measured 7 % slower: 14.9
     // against 13.9 ms per displayed frame — a wave's 64 pixels are neighbours in the tree, its 8 frames of 8 pixels less so)
     if (hbm_scene || wide || kTB != 64) a.frame_lanes = 0;
-    dim3 grid(trace_tile_count(a.band.width, a.band.local_rows) * unsigned(a.batch));   // kF parts x batch / kF groups per tile
+    const unsigned all_blocks = trace_tile_count(a.band.width, a.band.local_rows) * unsigned(a.batch);   // kF parts x batch / kF groups per tile
+    if (block_first >= all_blocks) return hipSuccess;
+    dim3 grid(block_count == 0u || block_count > all_blocks - block_first ? all_blocks - block_first : block_count);
     const size_t lds = caster_lds_bytes(a, wide, kTB);
 #if VXRT_VARIANTS
     if (wide) {
@@ -558,6 +681,25 @@ hipError_t launch_trace(const TraceArgs& args, bool wide, bool hbm_scene, hipStr
     else if (a.frame_lanes == 8) hipLaunchKernelGGL((trace_kernel<false, VXRT_TRACE_WAVES, kF8>), grid, dim3(kTB), lds, s, a);
     else if (a.frame_lanes == 4) hipLaunchKernelGGL((trace_kernel<false, VXRT_TRACE_WAVES, kF4>), grid, dim3(kTB), lds, s, a);
     else hipLaunchKernelGGL((trace_kernel<false, VXRT_TRACE_WAVES, 1>), grid, dim3(kTB), lds, s, a);
+    return hipGetLastError();
+}
+
+
+size_t fused_ctl_bytes() { return sizeof(FusedCtl); }
+
+// One grid of persistent one-wave blocks for the whole launch (fused_kernel).  ctl: device memory of fused_ctl_bytes(), zeroed on the
+// stream before this call.  stamp: 1 .. 65535, different from the previous launch's on the same queue.
+hipError_t launch_fused(const TraceArgs& args, void* ctl, unsigned waves, uint32_t stamp, hipStream_t s) {
+    TraceArgs a = args;
+    a.block_first = 0;
+    if (kTB != 64) return hipErrorInvalidValue;
+    const unsigned all_blocks = trace_tile_count(a.band.width, a.band.local_rows) * unsigned(a.batch);
+    const size_t lds = caster_lds_bytes(a, false, kTB);
+    dim3 grid(waves < 1u ? 1u : waves);
+    constexpr int kF8 = kTB == 64 ? 8 : 1, kF4 = kTB == 64 ? 4 : 1;
+    if (a.frame_lanes == 8) hipLaunchKernelGGL((fused_kernel<kF8>), grid, dim3(kTB), lds, s, a, static_cast<FusedCtl*>(ctl), all_blocks, stamp, a.tail_from);
+    else if (a.frame_lanes == 4) hipLaunchKernelGGL((fused_kernel<kF4>), grid, dim3(kTB), lds, s, a, static_cast<FusedCtl*>(ctl), all_blocks, stamp, a.tail_from);
+    else hipLaunchKernelGGL((fused_kernel<1>), grid, dim3(kTB), lds, s, a, static_cast<FusedCtl*>(ctl), all_blocks, stamp, a.tail_from);
     return hipGetLastError();
 }
 

@@ -566,6 +566,35 @@ __device__ __forceinline__ uint32_t queue_reserve(const PathQueue& q, unsigned s
 __device__ __forceinline__ void queue_store(const PathQueue& q, unsigned shard, uint32_t slot, const PathRec& rec) {
     store_rec(q.recs + (size_t(shard) * q.shard_capacity + slot) * 4u, rec);
 }
+// fused_kernel's form (trace.hip): the consumer may be polling this slot already.  Seven 8-byte stores at agent scope — write-through, so
+// that a wave on another XCD reads them from memory — then, when those have been written (s_waitcnt), the eighth: dir.z and normal_ambient
+// with the launch's stamp in its top 16 bits, which is what the consumer waits for.
+__device__ __forceinline__ void queue_store_fused(const PathQueue& q, unsigned shard, uint32_t slot, const PathRec& r, uint32_t stamp) {
+    unsigned long long* w = reinterpret_cast<unsigned long long*>(q.recs + (size_t(shard) * q.shard_capacity + slot) * 4u);
+    auto pack = [](uint32_t lo, uint32_t hi) { return (unsigned long long)lo | (unsigned long long)hi << 32; };
+    const unsigned long long v[8] = {pack(vx_f2u(r.hit_pos.x), vx_f2u(r.hit_pos.y)), pack(vx_f2u(r.hit_pos.z), uint32_t(r.node)),
+                                     pack(vx_f2u(r.dir.x), vx_f2u(r.dir.y)), pack(vx_f2u(r.dir.z), (r.normal_ambient & 0xffffu) | stamp << 16),
+                                     pack(vx_f2u(r.sample.x), vx_f2u(r.sample.y)), pack(vx_f2u(r.sample.z), r.rng_index),
+                                     pack(vx_f2u(r.blend.x), vx_f2u(r.blend.y)), pack(vx_f2u(r.blend.z), r.pix)};
+    for (int i = 0; i < 8; i++)
+        if (i != 3) __hip_atomic_store(w + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);      // vmcnt(0): the seven are written through before the stamp can be seen
+    __hip_atomic_store(w + 3, v[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// ... and the consumer's side: w3 = the polled word (dir.z | normal_ambient with the stamp), the rest read after it at agent scope
+__device__ __forceinline__ PathRec load_rec_fused(const float4* q, unsigned long long w3) {
+    const unsigned long long* w = reinterpret_cast<const unsigned long long*>(q);
+    unsigned long long v[8];
+    for (int i = 0; i < 8; i++) v[i] = i == 3 ? w3 : __hip_atomic_load(w + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    auto lo = [](unsigned long long x) { return uint32_t(x); };
+    auto hi = [](unsigned long long x) { return uint32_t(x >> 32); };
+    PathRec r;
+    r.hit_pos = mk3(vx_u2f(lo(v[0])), vx_u2f(hi(v[0])), vx_u2f(lo(v[1]))); r.node = int32_t(hi(v[1]));
+    r.dir = mk3(vx_u2f(lo(v[2])), vx_u2f(hi(v[2])), vx_u2f(lo(v[3]))); r.normal_ambient = hi(v[3]) & 0xffffu;
+    r.sample = mk3(vx_u2f(lo(v[4])), vx_u2f(hi(v[4])), vx_u2f(lo(v[5]))); r.rng_index = hi(v[5]);
+    r.blend = mk3(vx_u2f(lo(v[6])), vx_u2f(hi(v[6])), vx_u2f(lo(v[7]))); r.pix = hi(v[7]);
+    return r;
+}
 // records a consumer finds in shard `shard`
 __device__ __forceinline__ unsigned queue_count(const PathQueue& q, unsigned shard) {
     const unsigned n = q.counts[shard * kCountStride];

@@ -56,12 +56,12 @@ class BandLayout:
     def __init__(self, width, height, nranks, band_rows=16, radius=None):
         # the library's rule (vxrt_create / check_render): bands are multiples of the tracer's 8-row tiles;
         # the denoise stage with a window (radius > 0) works on 16x16 tiles that must not straddle bands
-        if band_rows <= 0 or band_rows % 8:
-            raise ValueError("band_rows must be a multiple of 8")
+        if band_rows <= 0 or (band_rows % 8 and band_rows not in (2, 4)):
+            raise ValueError("band_rows must be 2, 4 or a multiple of 8")
         if band_rows % 16 and (radius is None or radius > 0):
             raise ValueError("band_rows must be a multiple of 16 for a denoise radius > 0 (pass radius=0 for 8-row bands)")
         self.width, self.height, self.nranks, self.band_rows = width, height, nranks, band_rows
-        tile = 16 if band_rows % 16 == 0 else 8
+        tile = 16 if band_rows % 16 == 0 else (8 if band_rows % 8 == 0 else band_rows)
         rounds = height // (nranks * band_rows)
         if height % (nranks * band_rows) and rounds > 0:
             rounds -= 1                     # the last whole round takes the remainder as well (taller bands)

@@ -218,6 +218,17 @@ typedef struct vxrt_stats {
  *                          (<= 576 bytes / <= 4.6 KB) — so that the end of a descent stays in one neighbourhood of memory (BASELINE
  *                          config 5's scene lives in HBM).  Node indices never reach an output and the children of a node stay
  *                          contiguous: same image, same walk code.  vxrt_stats.node_order reads what the scene in place has.
+ *   VXRT_OPT_HEAD_STAGGER  1: with several trace launches in flight (one stream each), a launch's trace_kernel starts only when the previous
+ *                          launch's trace_kernel has finished, so that it runs beside that launch's bounce_kernel (a short block of few
+ *                          launches: the heads do not drain together).  0 (default): launches overlap freely.
+ *   VXRT_OPT_FUSED_TAIL    1: head and compacted tail of a trace launch run as ONE grid of persistent waves that take the launch's tiles
+ *                          from a cursor and then its queued paths, chunk by chunk as they become complete — for launches that are
+ *                          little more than their longest chains (a rank's share of a short block on many GPUs); 4-bounce tails,
+ *                          8-byte records, scenes in cache.  Same image.  0 (default): trace_kernel, then bounce_kernel.
+ *   VXRT_OPT_LONG_TILES    per mille (0 = off .. 500) of a trace launch's tiles — the first of its longest-first order — that run as an
+ *                          all-in-one grid on a second stream (a path's whole chain in one wave, begun when the launch begins) beside
+ *                          the head + compacted tail of the others: for launches that are little more than their longest chains
+ *                          (a rank's share of a short block on many GPUs).  Same image.
  *   VXRT_OPT_TRACER_OVERRIDE   create: the internal schedule past vxrt_config.tracer's automatic choice: 0 all-in-one kernel, 4 head +
  *                          compacted tail; 2 / 3 / 5 (-DVXRT_VARIANTS=1 builds) wavefront, ray queues, path kernel.
  *   VXRT_OPT_TRACE_SPLIT / PATH_BLOCKS / SHADE_BLOCKS / RAYS_PER_WAVE   create: launch shapes of tracers 2, 3 and 5.                    */
@@ -225,7 +236,7 @@ typedef enum vxrt_option { VXRT_OPT_DENOISE_MODE = 1, VXRT_OPT_TAIL_CAPACITY = 2
                            VXRT_OPT_SKY_CULL = 5, VXRT_OPT_FRAME_LANES = 6, VXRT_OPT_TILE_ORDER = 7, VXRT_OPT_TILE_SPREAD = 8,
                            VXRT_OPT_TRACE_BLOCKS = 9, VXRT_OPT_TAIL_FROM = 10, VXRT_OPT_TAIL_SPLIT = 11, VXRT_OPT_HOST_SCENE_BUILD = 12,
                            VXRT_OPT_TRACER_OVERRIDE = 13, VXRT_OPT_TRACE_SPLIT = 14, VXRT_OPT_PATH_BLOCKS = 15, VXRT_OPT_SHADE_BLOCKS = 16,
-                           VXRT_OPT_RAYS_PER_WAVE = 17, VXRT_OPT_NODE_ORDER = 18 } vxrt_option;
+                           VXRT_OPT_RAYS_PER_WAVE = 17, VXRT_OPT_NODE_ORDER = 18, VXRT_OPT_HEAD_STAGGER = 19, VXRT_OPT_LONG_TILES = 20, VXRT_OPT_FUSED_TAIL = 21 } vxrt_option;
 #define VXRT_TILE_SPREAD_AUTO 0xffffffffu
 int vxrt_set_option(vxrt_ctx* ctx, vxrt_option option, uint32_t value);
 /* An (option, value) pair for vxrt_create_tuned. */

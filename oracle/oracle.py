@@ -401,7 +401,7 @@ class CpuRsBackend:
 
 
 def detmath(fn, x, y=None):
-    names = {"sin": 0, "cos": 1, "exp": 2, "log": 3, "pow": 4, "sqrt": 5, "div": 6, "tan": 7, "hemi_y": 9, "hemi_z": 10, "mul": 11, "sub": 12, "flip": 13, "min": 14, "max": 15, "max0": 16, "sign": 17, "clamp": 18, "min0": 19}
+    names = {"sin": 0, "cos": 1, "exp": 2, "log": 3, "pow": 4, "sqrt": 5, "div": 6, "tan": 7, "hemi_y": 9, "hemi_z": 10, "mul": 11, "sub": 12, "flip": 13, "min": 14, "max": 15, "max0": 16, "sign": 17, "clamp": 18, "min0": 19, "exp_unfused": 20}
     x = np.ascontiguousarray(x, np.float32)
     y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), np.float32)
     out = np.zeros_like(x)

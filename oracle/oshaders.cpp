@@ -77,6 +77,8 @@ static void log_ray(V3 o, V3 d, bool hit, const orc::Hit& h) {
     memcpy(&r[8], &h.node, 4); r[9] = h.normal.x; r[10] = h.normal.y; r[11] = h.normal.z;
 }
 thread_local int g_phase = 0;
+thread_local uint8_t* g_branch_log = nullptr;  // diagnostic: one byte per trip of the walk — 0 advance, 1 descend, 2 pop, 3 the trip that ends the ray
+static inline void log_branch(uint8_t kind) { if (g_branch_log) *g_branch_log++ = kind; }
 
 // voxels.comp:134-247
 // The octree buffer of voxels.comp:58-63 (header + nodes[]) as the walk sees it.  `lazy` != null: nodes[] is not stored but
@@ -129,9 +131,10 @@ bool cast_bounded_ray(const Scene& sc, V3 ray_origin, V3 ray_dir, float max_dist
         out->time = time;
         if (iterations >= 2048) {
             out->node = LEAF_BIT;
+            log_branch(3);
             return true;
         }
-        if (time > max_distance) return false;
+        if (time > max_distance) { log_branch(3); return false; }
 
         int32_t value = node_word(sc, node, octant);
 
@@ -144,6 +147,7 @@ bool cast_bounded_ray(const Scene& sc, V3 ray_origin, V3 ray_dir, float max_dist
             V3 mask = v3(distances.x == max_dist ? 1.0f : 0.0f, distances.y == max_dist ? 1.0f : 0.0f,
                          distances.z == max_dist ? 1.0f : 0.0f);
             out->normal = mask * (-vsign(ray_dir));
+            log_branch(3);
             return true;
         }
 
@@ -157,6 +161,7 @@ bool cast_bounded_ray(const Scene& sc, V3 ray_origin, V3 ray_dir, float max_dist
         uint32_t next_octant = octant ^ transition;
         bool has_next = next_time <= exit && transition != 0 && (directional_octant & transition) == 0;
 
+        log_branch(value > 0 ? 1 : (has_next ? 0 : 2));
         if (value > 0) {
             if (top >= MAX_DEPTH) return false;  // GLSL would write out of bounds; cannot happen for depth <= 15
             stack[top].node = has_next ? node : -1;
@@ -443,6 +448,22 @@ void orc_trace_steps(const int32_t* octree, const float* noise, const OrcUniform
     });
 }
 
+// Diagnostic (tests/sim_schedule.py: branch_coherence): the branch every trip of every ray of a pixel takes, one byte per trip
+// (0 advance, 1 descend, 2 pop, 3 the trip that ends the ray), the pixel's rays one after another: pixel (x, y) writes its
+// orc_trace_steps total (row[0]) bytes at flat + offsets[pixel].
+void orc_trace_branches(const int32_t* octree, const float* noise, const OrcUniforms* u, int max_bounces, int x0, int y0, int x1, int y1,
+                        const int64_t* offsets, uint8_t* flat, int nthreads) {
+    int cw = x1 - x0;
+    parallel_rows(y0, y1, nthreads, [&](int y) {
+        float c[4], n[4], a[4];
+        for (int x = x0; x < x1; x++) {
+            g_branch_log = flat + offsets[(size_t)(y - y0) * cw + (x - x0)];
+            trace_pixel(scene_of(octree), noise, *u, max_bounces, x, y, c, n, a);
+            g_branch_log = nullptr;
+        }
+    });
+}
+
 // Diagnostic: every cast of one pixel's path: 12 floats per ray (origin, dir, hit, time, node bits, normal); returns the ray count.
 int orc_trace_pixel_log(const int32_t* octree, const float* noise, const OrcUniforms* u, int max_bounces, int x, int y, float* log) {
     float c[4], n[4], a[4];
@@ -652,6 +673,7 @@ void orc_detmath(int fn, const float* x, const float* y, float* out, size_t n) {
             case 17: out[i] = vx_sign(x[i]) * y[i]; break;
             case 18: out[i] = vx_clamp(x[i], y[i], 1.0f); break;
             case 19: out[i] = vx_min(0.0f, x[i]) * y[i]; break;  // the GLSL wording; the device's vx_min0 must equal it
+            case 20: out[i] = vx_exp_unfused(x[i]); break;       // round 1-3's exp (every product and sum rounded)
             default: out[i] = 0.0f;
         }
     }

@@ -9,11 +9,11 @@ steps = int(sys.argv[5]) if len(sys.argv) > 5 else 20
 blocks = int(sys.argv[6]) if len(sys.argv) > 6 else 40
 pos, mrgb, size = scenes.load_scene("menger")
 cam = scenes.bench_camera(size)
-with Context(1920, 1080, max_bounces=4, rank=rank, nranks=nranks, frames_in_flight=infl, frames_per_launch=batch, band_rows=8) as ctx:
+with Context(1920, 1080, max_bounces=4, rank=rank, nranks=nranks, frames_in_flight=infl, frames_per_launch=batch, band_rows=int(os.environ.get('BAND', '8'))) as ctx:
     ctx.recreate_octree(pos, mrgb); ctx.camera = Camera(*cam)
     for _ in range(20):
         ctx.render_frames(TRACE, steps); ctx.sync()
     ts = []
     for _ in range(blocks):
         t0 = time.perf_counter(); ctx.render_frames(TRACE, steps); ctx.sync(); ts.append(time.perf_counter() - t0)
-    print(f"rank={rank}/{nranks} {batch}x{infl}: block of {steps} frames {statistics.median(ts) * 1e3:.4f} ms (min {min(ts) * 1e3:.4f})", flush=True)
+    print(f"rank={rank}/{nranks} band {os.environ.get('BAND', '8')} {batch}x{infl}: block of {steps} frames {statistics.median(ts) * 1e3:.4f} ms (min {min(ts) * 1e3:.4f})", flush=True)

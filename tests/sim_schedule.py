@@ -300,3 +300,114 @@ def lane_mappings(view="bench", frames=16, split=3):
         util = [a[:, :, r].sum() / (64 * a[:, :, r].max(axis=1).sum()) for r in range(split)]
         print(f"{pw}x{ph} px x {pf} frames: head {hc / F / 1e6:6.1f} M (lane utilisation of its rounds {util[0]:.2f} {util[1]:.2f} {util[2]:.2f})"
               f"  tail {tc / F / 1e6:6.1f} M  total {(hc + tc) / F / 1e6:6.1f} M wave-instr per frame")
+
+
+def branch_coherence(view="bench", split_round=3, frames=2, w=1920, h=1080, bounces=4):
+    """Round 5: what would BRANCH-COHERENT tail chunks give?  A lock-step trip of the walk costs (the gfx950 listing,
+    profiles/r04/walkf_step_isa.md) 32 VALU that every trip executes + 3 if any lane advances to a sibling + 57 if any lane descends + 53
+    if any lane pops: 127 when the lanes of a wave split over all three, 35-90 when they agree.  The oracle logs the branch of every trip
+    of every ray (orc_trace_branches); the tail's paths (alive at their second hit) are dealt to chunks of 64 in five ways and every
+    chunk is priced trip by trip:
+      shipped     shard = hash of the head wave's index (trace.hip: tail_shard), chunks = 64 consecutive records of a shard
+      tile order  no hash: consecutive records in the head's wave order (a chunk = neighbouring tiles)
+      cell        shard = the 4 x 4 x 4 cell of the hand-over hit inside the scene's box
+      normal+cell shard = the face the path sits on (6) x the 2 x 2 x 2 cell: the sun rays of a chunk start on one face of one region
+      oracle sort (bound) paths sorted by the branch string of their next ray — what no key known at the hand-over can reach
+    Costs in VALU wave-instructions per frame, shading rounds (C_SHADE) included."""
+    import ctypes as C
+    pos, mrgb, size = scenes.load_scene("menger")
+    cam = scenes.bench_camera(size) if view == "bench" else scenes.close_camera(size)
+    octree = O.create_octree(pos, mrgb)
+    noise = O.noise_table()
+    u = O.Uniforms.default()
+    u.set_camera(cam[0], O.camera_axis_scaled(cam[0], cam[1], cam[2], w, h))
+    lo, hi = pos.min(0).astype(np.float64) * 0.5, (pos.max(0).astype(np.float64) + 1) * 0.5      # the scene's box in world units (voxel = 0.5)
+    lo, hi = lo[[0, 2, 1]], hi[[0, 2, 1]]                                                            # voxel (x, y, z) -> world (x, z, y)
+    B_ADV, B_DESC, B_POP = 3.0, 57.0, 53.0
+    totals = {}
+    for f in range(frames):
+        u.frame_number = 1 + f
+        st = np.zeros((h, w, 17), np.int32)
+        O.lib().orc_trace_steps(O._p(octree), O._p(noise), C.byref(u), C.c_int(bounces), C.c_int(0), C.c_int(0), C.c_int(w), C.c_int(h), O._p(st),
+                                C.c_int(os.cpu_count()))
+        tot = st[..., 0].reshape(-1).astype(np.int64)
+        offs = np.concatenate([[0], np.cumsum(tot)[:-1]]).astype(np.int64)
+        flat = np.zeros(int(tot.sum()) + 16, np.uint8)
+        O.lib().orc_trace_branches(O._p(octree), O._p(noise), C.byref(u), C.c_int(bounces), C.c_int(0), C.c_int(0), C.c_int(w), C.c_int(h), O._p(offs),
+                                   O._p(flat), C.c_int(os.cpu_count()))
+        rays = st[..., 1:].reshape(-1, 16).astype(np.int64)
+        alive = np.nonzero(rays[:, split_round] > 0)[0]                       # pixels whose path reaches the tail
+        nr = rays.shape[1] - split_round
+        L = int(rays[alive][:, split_round:].max())
+        n = len(alive)
+        seq = np.full((n, nr, L), 255, np.uint8)                              # [path, tail round, trip] -> branch
+        start = offs[alive] + rays[alive][:, :split_round].sum(1)
+        for r in range(nr):
+            ln = rays[alive, split_round + r]
+            idx = start[:, None] + np.arange(L)[None, :]
+            ok = np.arange(L)[None, :] < ln[:, None]
+            seq[:, r, :][ok] = flat[idx[ok]]
+            start = start + ln
+        # where and on which face each path is handed over: the origin of its first tail ray (hit + 1e-5 normal) from the oracle's ray log
+        ys, xs = np.divmod(alive, w)
+        org = np.zeros((n, 3)); nrm = np.zeros((n, 3))
+        log = np.zeros((32, 12), np.float32)
+        for i in range(n):
+            k = O.lib().orc_trace_pixel_log(O._p(octree), O._p(noise), C.byref(u), C.c_int(bounces), C.c_int(int(xs[i])), C.c_int(int(ys[i])), O._p(log))
+            assert k > split_round
+            org[i] = log[split_round, 0:3]; nrm[i] = log[split_round - 1, 9:12]      # the ray before it (bounce ray of segment 1) hit with this normal
+        cell4 = np.clip(((org - lo) / (hi - lo) * 4).astype(int), 0, 3)
+        cell2 = cell4 // 2
+        face = np.argmax(np.abs(nrm), 1) * 2 + (nrm[np.arange(n), np.argmax(np.abs(nrm), 1)] > 0)
+        # the head's wave of every path: 8 x 8 pixel tiles in raster order (the cost order permutes waves, not a wave's contents)
+        wave = (ys // 8) * (w // 8) + xs // 8
+
+        def price(order):
+            s = seq[order]
+            pad = (-len(s)) % 64
+            s = np.concatenate([s, np.full((pad, nr, L), 255, np.uint8)]).reshape(-1, 64, nr, L)
+            live = (s != 255).any(1)                                         # [chunk, round, trip]: somebody is on this trip
+            cost = (32.0 * live + B_ADV * (s == 0).any(1) + B_DESC * (s == 1).any(1) + B_POP * (s == 2).any(1)).sum()
+            trips = live.sum()
+            return cost + live.any(2).sum() * C_SHADE, trips, cost / max(trips, 1)
+
+        def by_shard(key, nshards):
+            # records of a shard in the head's wave order; chunks never mix shards (the last chunk of a shard is part-filled)
+            out = []
+            for sh in range(nshards):
+                m = np.nonzero(key == sh)[0]
+                m = m[np.argsort(wave[m], kind="stable")]
+                out.append(m)
+                pad = (-len(m)) % 64
+                out.append(np.full(pad, -1))
+            return np.concatenate(out)
+
+        deals = {"shipped (hash of the head wave)": by_shard(((wave.astype(np.uint64) * 0x9E3779B1) & 0xffffffff) >> 26, 64),
+                 "tile order (no hash)": np.argsort(wave, kind="stable"),
+                 "4x4x4 cell of the hand-over hit": by_shard(cell4[:, 0] * 16 + cell4[:, 1] * 4 + cell4[:, 2], 64),
+                 "face x 2x2x2 cell": by_shard(face * 8 + cell2[:, 0] * 4 + cell2[:, 1] * 2 + cell2[:, 2], 48),
+                 "oracle sort by the next ray's branch string (bound)": np.lexsort(seq[:, 0, ::-1].T)}
+        seq_pad = np.concatenate([seq, np.full((1, nr, L), 255, np.uint8)])       # index -1 -> an idle lane
+        for name, order in deals.items():
+            s_order = np.where(order < 0, n, order)
+            c, trips, per = price_padded(seq_pad, s_order, nr, L, B_ADV, B_DESC, B_POP)
+            t = totals.setdefault(name, [0.0, 0, 0.0, 0])
+            t[0] += c; t[1] += trips; t[3] += (order >= 0).sum()
+        print(f"frame {f + 1}: {n} tail paths, {int((seq != 255).sum())} lane-trips", flush=True)
+    base = totals["shipped (hash of the head wave)"][0]
+    for name, (c, trips, _, lanes) in totals.items():
+        walk = c - 0
+        print(f"  {name:55s}: {c / frames / 1e6:7.2f} M VALU wave-instr per frame ({c / base:5.3f} x), {trips / frames / 1e3:7.1f} k wave-trips")
+    return totals
+
+
+def price_padded(seq_pad, order, nr, L, b_adv, b_desc, b_pop):
+    s = seq_pad[order]
+    pad = (-len(s)) % 64
+    if pad:
+        s = np.concatenate([s, np.full((pad, nr, L), 255, np.uint8)])
+    s = s.reshape(-1, 64, nr, L)
+    live = (s != 255).any(1)
+    cost = (32.0 * live + b_adv * (s == 0).any(1) + b_desc * (s == 1).any(1) + b_pop * (s == 2).any(1)).sum()
+    trips = int(live.sum())
+    return cost + live.any(2).sum() * C_SHADE, trips, cost / max(trips, 1)

@@ -33,6 +33,28 @@ def test_exp_log_pow(O):
     assert O.detmath("pow", np.array([0, 0, 1], np.float32), np.array([400, 0, 400], np.float32)).tolist() == [0, 1, 1]
 
 
+def test_fused_exp_is_within_one_ulp_of_the_unfused_form(O):
+    """round 4 rewrote vx_exp's kernel with fused multiply-adds and regenerated the self-golden frames in the same commit, so
+    "bit-exact against the oracle" held by construction.  What justifies the regenerated goldens is checked here: over the denoiser's
+    argument range (the exact tap's exp(-factor_range - factor_distance), a number in [-87.3, 0]) and over vx_pow's (y * log(x) for the
+    sun disc: x in (0, 1], y = 400 -> [-87.3, 0] as well; emitters and parameters outside the defaults: up to +88.7) the two forms
+    differ by at most one unit in the last place, the fused form is never further from the true value than the unfused one by more than
+    that, and both flush to +0 / overflow to inf at the same arguments.  Neither form is pinned by the reference (U6: parity unpinned)."""
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.uniform(-87.3, 0, 1_500_000), rng.uniform(0, 88.72, 500_000), -np.exp(rng.uniform(-30, 4.4, 500_000)),
+                        np.array([-87.3, -87.29999, 0.0, -0.0, 88.72, 88.71999, -1e-30, 1e-30])]).astype(np.float32)
+    fused, unfused = O.detmath("exp", x), O.detmath("exp_unfused", x)
+    ulps = np.abs(fused.view(np.int32).astype(np.int64) - unfused.view(np.int32).astype(np.int64))
+    assert ulps.max() <= 1, ulps.max()
+    assert 0.02 < (ulps == 1).mean() < 0.5                       # they DO differ (so the goldens had to move), by one ulp, on a minority
+    true = np.exp(x.astype(np.float64))
+    m = np.isfinite(fused) & (true < 3.0e38)
+    assert ulp_err(fused[m], true[m]).max() <= ulp_err(unfused[m], true[m]).max() + 1e-9 < 3
+    edge = np.array([-200, -87.31, -87.3, 88.72, 88.73, 200, np.nan], np.float32)
+    a, b = O.detmath("exp", edge), O.detmath("exp_unfused", edge)
+    assert np.array_equal(a, b, equal_nan=True) and a[0] == 0 and a[1] == 0 and a[2] > 0 and np.isinf(a[4]) and np.isnan(a[6])
+
+
 def test_glsl_min_max_sign_semantics(O):
     # min(x,y) = y < x ? y : x ; max(x,y) = x < y ? y : x  -> a NaN in the SECOND operand is ignored, in the first it wins.
     # checked through pow/exp/log being NaN-propagating and through the traversal tests; here: f2i definedness via tan/div

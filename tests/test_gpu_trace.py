@@ -165,6 +165,10 @@ def test_full_size_bench_config_crops(O, H, scenes, noise):
     {"VXRT_TRACE_VARIANT": "4", "VXRT_TAIL_SPLIT": "0xc", "VXRT_INFLIGHT": "3"},        # ... tail compacted again at segments 2 and 3
     {"VXRT_TRACE_VARIANT": "4", "VXRT_TAIL_FROM": "0"},                                 # ... tail from the first hit: the head casts primary rays only
     {"VXRT_TRACE_VARIANT": "4", "VXRT_TAIL_FROM": "0", "VXRT_INFLIGHT": "3", "VXRT_TAIL_SPLIT": "0x6"},
+    {"VXRT_TRACE_VARIANT": "4", "VXRT_LONG_TILES": "100", "VXRT_INFLIGHT": "2"},        # ... the longest tenth of the tiles as an all-in-one grid on a second stream
+    {"VXRT_TRACE_VARIANT": "4", "VXRT_LONG_TILES": "500", "VXRT_SPREAD": "0", "VXRT_TAIL_CAPACITY": "64"},
+    {"VXRT_TRACE_VARIANT": "4", "VXRT_FUSED_TAIL": "1"},                                # head and tail as one grid of persistent waves (fused_kernel)
+    {"VXRT_TRACE_VARIANT": "4", "VXRT_FUSED_TAIL": "1", "VXRT_INFLIGHT": "3", "VXRT_TAIL_CAPACITY": "64"},   # ... launches in flight, one chunk per shard: most paths stay in the head
     {"VXRT_TRACE_VARIANT": "5"},                                                        # monolithic head + path_kernel (lanes refilled path by path)
     {"VXRT_TRACE_VARIANT": "5", "VXRT_PATH_BLOCKS": "1", "VXRT_INFLIGHT": "2"},         # ... four waves take the whole queue: many refills per lane
     {"VXRT_TRACE_VARIANT": "5", "VXRT_TAIL_FROM": "2", "VXRT_BATCH": "4"},              # ... tail from hit 2 (the API calls here are single frames)
