@@ -514,6 +514,21 @@ def pick_schedule(world, steps, inflight=0, batch=0):
     return inflight, batch
 
 
+def pick_deal(world, steps, inflight=0, batch=0):
+    """How a SHORT block is rendered on `world` ranks, beyond pick_schedule's launches: (band_rows, vxrt_config.tracer).
+    A rank's share of a short block (the driver's --steps 20) on 8 GPUs is 2.5 frames' worth of work wrapped around two chains of
+    lock-step waves: as head + compacted tail the launch is trace_kernel (172-195 us, the chip two thirds idle by its end) followed by
+    bounce_kernel (220-235 us, drained again), 0.41-0.46 ms per block over the ranks; the all-in-one kernel needs 1.3 x the instructions
+    but drains once: 0.37-0.44 ms.  And 8-row bands leave a rank only ~8 bands with geometry (1080 rows, 64-row period): the ranks'
+    blocks differ by 16 %; 4-row bands — whose rows still pair up in the waves of a frame-lane launch (2 rows x 4 frames) — bring them
+    within 4 %: all-in-one + 4-row bands 0.405-0.423 ms for every rank (scripts/r5e.sh, r5j.sh; profiles/r05/short_block.txt).  Two
+    and four ranks, and every steady-state run, keep the default: their launches are long enough for the pair to win."""
+    short = steps < 2 * 16 * (inflight if inflight > 0 else (2 if world == 1 else 3))
+    if short and world >= 8 and inflight <= 0 and batch <= 0:
+        return 4, 1
+    return BAND_ROWS, 0
+
+
 def free_port():
     import socket
     with socket.socket() as s:
@@ -706,7 +721,12 @@ def trace_bench(args):
     world, rank, device, dist, torch, backend = init_dist()
     args.gpus = world          # a launcher's WORLD_SIZE decides (main() starts the ranks itself when there is none)
     red_dev = "cuda" if backend == "nccl" else "cpu"
+    band_rows, deal_tracer = pick_deal(world, args.steps, args.inflight, args.batch)
     args.inflight, args.batch = pick_schedule(world, args.steps, args.inflight, args.batch)
+    if args.tracer == 0:
+        args.tracer = deal_tracer
+    if args.band_rows:
+        band_rows = args.band_rows
     from gpu_voxel_raytracer_amd import Camera, Context, TIMED, TRACE, scenes
 
     pos, mrgb, size = scenes.load_scene(SCENE)
@@ -714,7 +734,7 @@ def trace_bench(args):
     if args.view == "away":   # diagnostic: every primary ray misses (pure G-buffer write traffic)
         cam = (cam[0], -cam[1], cam[2])
 
-    ctx = Context(WIDTH, HEIGHT, device=device, max_bounces=args.bounces, rank=rank, nranks=world, band_rows=BAND_ROWS,
+    ctx = Context(WIDTH, HEIGHT, device=device, max_bounces=args.bounces, rank=rank, nranks=world, band_rows=band_rows,
                   frames_in_flight=args.inflight, frames_per_launch=args.batch, tracer=args.tracer)
     ctx.recreate_octree(pos, mrgb)
     ctx.camera = Camera(*cam)
@@ -828,8 +848,9 @@ def trace_bench(args):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": DATA_LABEL,
             "config": {"workload": f"vox/{SCENE}.vox {WIDTH}x{HEIGHT}, 1 spp, {args.bounces} bounces, trace stage only "
                                    f"(BASELINE configs[1]); camera '{args.view}' of SURVEY §8d; Uniforms::default()",
-                       "parallelism": f"screen bands x{world} ({BAND_ROWS}-row interleave, scene replicated)",
+                       "parallelism": f"screen bands x{world} ({band_rows}-row interleave, scene replicated)",
                        "launches_in_flight": args.inflight, "frames_per_launch": args.batch,
+                       "tracer": {0: "head + compacted tail (trace_kernel + bounce_kernel)", 1: "all-in-one trace_kernel"}.get(args.tracer, str(args.tracer)),
                        "rays_per_frame": rays // args.steps, "rays_per_pixel": round(rays / args.steps / (WIDTH * HEIGHT), 4),
                        "rays_walked_per_frame": rays // args.steps - culled, "primary_rays_answered_by_the_sky_cull_per_frame": culled,
                        "mpixels_per_s": round(WIDTH * HEIGHT * args.steps / elapsed / 1e6, 1)},
@@ -1061,7 +1082,7 @@ def main():
     ap.add_argument("--no-config3", action="store_true", help="skip the extra that times BASELINE configs[2]'s frame loop at 4K")
     ap.add_argument("--pipeline", action="store_true", help="time the whole frame loop with the denoise halo exchange (BASELINE configs[3])")
     ap.add_argument("--radius", type=int, default=8, help="--pipeline: denoise radius")
-    ap.add_argument("--band-rows", type=int, default=0, help="--pipeline: rows per band (default: >= 8 radius, a multiple of 16)")
+    ap.add_argument("--band-rows", type=int, default=0, help="rows per band (trace bench: 8, 4 for a short block from 8 ranks on; --pipeline: >= 8 radius, a multiple of 16)")
     ap.add_argument("--view", default="bench", choices=["bench", "close", "away"])
     ap.add_argument("--bounces", type=int, default=BOUNCES, help="diagnostic only; the benchmark is 4")
     ap.add_argument("--tracer", type=int, default=0, help="diagnostic only (vxrt_config.tracer; 2 / 3 / 5 need the variants build); the benchmark is 0")

@@ -1,6 +1,8 @@
 // api_context.hip — the context of libvxrt (include/vxrt.h): creation, image and queue memory, per-frame parameters, options,
 // outputs and statistics.  Stands where Context::new / create_bindings / resize / update_bindings stand in the reference
 // (src/context.rs:595-660, 936-1016, 1430-1461, 2136-2162); each entry point cites its call site in vxrt.h.
+#include <chrono>
+
 #include "ctx.h"
 
 namespace vxrt {
@@ -151,9 +153,24 @@ int alloc_images(vxrt_ctx* c) {
     return build_tile_rows(c);
 }
 
+// Wait for a stream.  hipStreamSynchronize parks the thread and is woken by an interrupt: 15-25 us after the stream has drained on this
+// stack, which is 5 % of a rank's 20-frame block on 8 GPUs (0.4 ms).  So the first 2 ms are spent polling hipStreamQuery (the
+// stream's last completion signal, ~1 us a look); a wait that lasts longer falls back to the blocking call.
+static int wait_stream(hipStream_t s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; spins++) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return VXRT_OK;
+        if (e != hipErrorNotReady) return hip_fail(e, "hipStreamQuery");
+        if ((spins & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return VXRT_OK;
+}
+
 int sync_all(vxrt_ctx* c) {
-    for (hipStream_t t : c->trace_streams) HIP_TRY(hipStreamSynchronize(t));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (hipStream_t t : c->trace_streams) { if (int rc = wait_stream(t)) return rc; }
+    if (int rc = wait_stream(c->stream)) return rc;
     for (vxrt_ctx::StreamQueues& sq : c->queues)      // fused_kernel's report of the last launch (copied back behind it)
         if (sq.host_ctl != nullptr && sq.host_ctl[2] != 0u) { c->fused_errors++; sq.host_ctl[2] = 0u; }
     if (c->fused_errors != 0) {
@@ -340,14 +357,17 @@ int apply_option(vxrt_ctx* c, uint32_t option, uint32_t value, bool at_create) {
             return VXRT_OK;
         case VXRT_OPT_FUSED_TAIL:
             if (value > 1) { set_error("fused tail must be 0 or 1"); return VXRT_E_INVALID; }
+            if (value == 1 && !needs_variants("the fused head + tail kernel is not in this build of libvxrt (compile with -DVXRT_VARIANTS=1: it measured slower)")) return VXRT_E_INVALID;
             c->fused_tail = int(value);
             return VXRT_OK;
         case VXRT_OPT_LONG_TILES:
             if (value > 500) { set_error("long tiles: 0 (off) .. 500 per mille of the tiles"); return VXRT_E_INVALID; }
+            if (value != 0 && !needs_variants("the split launch of the longest tiles is not in this build of libvxrt (compile with -DVXRT_VARIANTS=1: it measured slower)")) return VXRT_E_INVALID;
             c->long_tiles_permille = value;
             return VXRT_OK;
         case VXRT_OPT_HEAD_STAGGER:
             if (value > 1) { set_error("head stagger must be 0 or 1"); return VXRT_E_INVALID; }
+            if (value != 0 && !needs_variants("the head stagger is not in this build of libvxrt (compile with -DVXRT_VARIANTS=1: it measured slower)")) return VXRT_E_INVALID;
             c->head_stagger = int(value);
             return VXRT_OK;
         default:

@@ -182,6 +182,25 @@ int vxrt_debug_culled_pixels(vxrt_ctx* c, uint64_t* count) try {
     return VXRT_OK;
 } VXRT_CATCH
 
+// Diagnostics of the last fused launch of trace stream 0 (VXRT_OPT_FUSED_TAIL; trace.hip: FusedCtl::prof; every 64th wave reports):
+// out[0] ticks of the 100 MHz clock from the first wave's start to the moment every head block was finished, out[1] ... to the last wave's end, out[2] / out[3] chunks taken
+// before / after that moment, out[4] idle sleeps, out[5] polls for a record's stamp, out[6] head claims, out[7] 0.
+int vxrt_debug_fused_profile(vxrt_ctx* c, uint64_t out[8]) try {
+    if (!valid_ctx(c) || !out) { set_error("null argument"); return VXRT_E_INVALID; }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = vxrt_sync(c)) return rc;
+    memset(out, 0, 8 * sizeof(uint64_t));
+    if (c->queues.empty() || c->queues[0].fused_ctl == nullptr) return VXRT_OK;
+    unsigned long long p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#if VXRT_VARIANTS
+    HIP_TRY(hipMemcpy(p, static_cast<char*>(c->queues[0].fused_ctl) + fused_ctl_profile_offset(), sizeof p, hipMemcpyDeviceToHost));
+#endif
+    const unsigned long long t0 = ~p[0];
+    out[0] = p[1] > t0 ? p[1] - t0 : 0; out[1] = p[2] > t0 ? p[2] - t0 : 0;
+    out[2] = p[3]; out[3] = p[4]; out[4] = p[5]; out[5] = p[6]; out[6] = p[7];
+    return VXRT_OK;
+} VXRT_CATCH
+
 // device-vs-host bit equality probe of include/vxrt_detmath.h (test hook; host arrays in and out)
 int vxrt_detmath_probe(int32_t device, int32_t fn, const float* x, const float* y, float* out, size_t n) try {
     if (!x || !y || !out) { set_error("null argument"); return VXRT_E_INVALID; }

@@ -237,18 +237,22 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
                 a.tail_from = c->tail_from;
                 // head stagger (VXRT_OPT_HEAD_STAGGER): this launch's head starts when the previous launch's head (another stream) has
                 // finished, so that a head runs beside the previous launch's tail instead of beside its head
+#if VXRT_VARIANTS
                 if (c->head_stagger && c->last_head_lane >= 0 && size_t(c->last_head_lane) != lane)
                     HIP_TRY(hipStreamWaitEvent(ts, c->head_events[size_t(c->last_head_lane)], 0));
+#endif
                 // Fused head + tail (VXRT_OPT_FUSED_TAIL): one grid of persistent waves takes the launch's blocks and then its queued
                 // paths, chunk by chunk as they become complete (trace.hip: fused_kernel).  For tails of ONE launch (the 4-bounce
                 // benchmark; a tail that compacts again keeps its launches), the 8-byte records, scenes in cache.
-                bool one_tail_launch = true, fused_done = false;
+                bool fused_done = false;
+#if VXRT_VARIANTS
+                bool one_tail_launch = true;
                 for (int k = c->tail_from + 1; k < int(c->cfg.max_bounces); k++)
                     if (sq.hitq[1] && ((c->tail_split >> k) & 1u)) one_tail_launch = false;
                 if (c->fused_tail && c->trace_variant == 4 && one_tail_launch && !use_wide(c) && scene_bytes <= (size_t(256) << 20) && c->tail_from < int(c->cfg.max_bounces)) {
                     if (sq.fused_ctl == nullptr) {
                         HIP_TRY(hipMalloc(&sq.fused_ctl, fused_ctl_bytes()));
-                        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sq.host_ctl), 64, hipHostMallocDefault));
+                        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sq.host_ctl), 64, hipHostMallocDefault));    // word 2: the kernel's error word
                         memset(sq.host_ctl, 0, 64);
                     }
                     if (!sq.stamps_clean) {   // once per allocation of the queue: every slot's stamp must read 0
@@ -258,26 +262,29 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
                     HIP_TRY(hipMemsetAsync(sq.fused_ctl, 0, fused_ctl_bytes(), ts));
                     const uint32_t stamp = (sq.fused_launches++ % 65535u) + 1u;
                     const unsigned all_blocks = trace_tile_count(c->band.width, c->band.local_rows) * g;
-                    HIP_TRY(launch_fused(a, sq.fused_ctl, c->wave_slots < all_blocks ? c->wave_slots : all_blocks, stamp, ts));
+                    const unsigned fused_slots = c->wave_slots / 5u * 4u;      // fused_kernel is compiled for 4 waves per SIMD (trace.hip: VXRT_FUSED_WAVES)
+                    HIP_TRY(launch_fused(a, sq.fused_ctl, fused_slots < all_blocks ? fused_slots : all_blocks, a.tile_order ? sched.scratch : nullptr, stamp, ts));
                     if (a.frame_lanes) c->frame_lane_launches++;
                     sq.launches = J + 1;          // one kernel: it wrote set (J + 1) % 3 and cleared (J + 2) % 3, which the next launch writes
                     if (!sq.counts_pending) {
                         HIP_TRY(hipMemcpyAsync(sq.host_counts, sets[(J + 1) % 3], 64 * 64, hipMemcpyDeviceToHost, ts));
-                        HIP_TRY(hipMemcpyAsync(sq.host_ctl, sq.fused_ctl, 16, hipMemcpyDeviceToHost, ts));
+                        HIP_TRY(hipMemcpyAsync(sq.host_ctl + 2, static_cast<char*>(sq.fused_ctl) + fused_ctl_error_offset(), 4, hipMemcpyDeviceToHost, ts));
                         HIP_TRY(hipEventRecord(sq.counts_ready, ts));
                         sq.counts_pending = true;
                         sq.counts_capacity = c->shard_capacity;
                     }
                     fused_done = true;
                 }
+#endif
                 if (!fused_done) {
-                // The longest tiles apart (VXRT_OPT_LONG_TILES, per mille of the tiles): the first tiles of the launch order — the
+                // (-DVXRT_VARIANTS=1 only: measured slower — the rest of the tiles are as chain-bound as the longest.)  The longest tiles apart (VXRT_OPT_LONG_TILES, per mille of the tiles): the first tiles of the launch order — the
                 // longest chains of the last frames — run as an all-in-one grid of their own on a second stream (no hand-over: a
                 // path's whole chain in ONE wave, begun at the launch's start), beside the head + tail pair of all other tiles.  A
                 // launch that is little more than its chains (a rank's share of a short block on 8 GPUs) is two chains long as head +
                 // tail and one as the all-in-one kernel, which in turn needs 1.3 x the instructions: this takes the one chain where
                 // it matters and the cheaper instructions everywhere else.  Same pixels, same arithmetic, either way.
                 unsigned long_blocks = 0;
+#if VXRT_VARIANTS
                 if (c->long_tiles_permille > 0 && a.tile_order != nullptr && c->trace_variant == 4 && !use_wide(c) && scene_bytes <= (size_t(256) << 20)) {
                     const unsigned tiles = trace_tile_count(c->band.width, c->band.local_rows);
                     unsigned n = unsigned((unsigned long long)tiles * c->long_tiles_permille / 1000u);
@@ -298,11 +305,14 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
                     HIP_TRY(launch_trace(al, false, false, c->aux_streams[lane], 0u, long_blocks));
                     HIP_TRY(hipEventRecord(c->aux_join[lane], c->aux_streams[lane]));
                 }
+#endif
                 HIP_TRY(launch_trace(a, use_wide(c) && c->trace_variant == 4, scene_bytes > (size_t(256) << 20), ts, long_blocks, 0u));
+#if VXRT_VARIANTS
                 if (c->head_stagger) {
                     HIP_TRY(hipEventRecord(c->head_events[lane], ts));
                     c->last_head_lane = int(lane);
                 }
+#endif
                 if (a.frame_lanes && !(use_wide(c) && c->trace_variant == 4) && scene_bytes <= (size_t(256) << 20)) c->frame_lane_launches++;
                 sq.launches = J + 1;
                 // how much room this launch wanted: its counter set, copied back for grow_tail_queues.  The set stays untouched until

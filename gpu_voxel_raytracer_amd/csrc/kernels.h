@@ -216,7 +216,9 @@ struct RayQueue {
 // hbm_scene: the kernel compiled for one more wave per SIMD (a scene beyond the Infinity Cache)
 // head and compacted tail of a launch as one grid of `waves` persistent waves (trace.hip: fused_kernel); ctl: fused_ctl_bytes() of zeros
 size_t fused_ctl_bytes();
-hipError_t launch_fused(const TraceArgs& a, void* ctl, unsigned waves, uint32_t stamp, hipStream_t s);
+size_t fused_ctl_error_offset();
+size_t fused_ctl_profile_offset();
+hipError_t launch_fused(const TraceArgs& a, void* ctl, unsigned waves, const uint32_t* sort_scratch, uint32_t stamp, hipStream_t s);
 // blocks [block_first, block_first + block_count) of the launch's tiles x frames; block_count 0: all of them
 hipError_t launch_trace(const TraceArgs& a, bool wide, bool hbm_scene, hipStream_t s, unsigned block_first = 0, unsigned block_count = 0);
 // test hook: the walk (cast_ray) for caller-given rays; out = 8 floats per ray (hit, time, bits(leaf word), normal, 0, 0)

@@ -318,7 +318,12 @@ __global__ __launch_bounds__(kTB, kWaves) void trace_kernel(const TraceArgs a) {
 }
 
 
-// ---- fused_kernel: head and compacted tail of a launch in ONE grid of persistent waves (VXRT_OPT_FUSED_TAIL) ----------------------------
+#if VXRT_VARIANTS
+// ---- fused_kernel: head and compacted tail of a launch in ONE grid of persistent waves (VXRT_OPT_FUSED_TAIL; -DVXRT_VARIANTS=1 only) --------
+// MEASURED SLOWER (round 5; HISTORY.md section 11): bit-identical images, 0.53 ms against 0.41 (two kernels) and 0.375 (all-in-one) for a
+// rank of 8's 20-frame block.  A software scheduler pays for every decision with round trips through device-scope memory (2-5 us each:
+// a claim, a look at the shard counters, a flag) where the hardware's dispatcher starts the next wave for nothing; 51 % of its
+// wave-cycles are s_waitcnt.  Kept beside tracers 2, 3 and 5 as the record of the attempt, with its parity cases.
 // A launch that is little more than its longest chains — a rank's share of a short block on many GPUs: 20 frames of an eighth of the
 // rows — spends its time DRAINING: trace_kernel ends when its longest wave ends (the chip two thirds idle by then), and only then may
 // bounce_kernel start, which drains again.  Two chains end to end, at 83 % and 64 % of the instruction rate the same kernels reach in
@@ -327,105 +332,240 @@ __global__ __launch_bounds__(kTB, kWaves) void trace_kernel(const TraceArgs a) {
 // as soon as a chunk is complete — the tail of the paths handed over early runs beside the long head chains, and nothing waits for a
 // kernel boundary.  Same records, same per-path operations (trace_block, bounce_path): same image.
 //
-// Protocol.  A head lane reserves its record slot with the shard's counter (queue_reserve, as before) and stores the record with
-// queue_store_fused: seven 8-byte stores at agent scope (write-through, visible to every XCD), s_waitcnt, then the eighth, which holds
-// the launch's 16-bit stamp in the unused top of normal_ambient.  A consumer lane polls that word (agent scope: served from memory,
-// not from its XCD's L2) until the stamp is there, then reads the rest and writes the word back with stamp 0.  After its last block
-// a wave adds to `blocks_done`; when that reaches the total every shard counter is final and what is left (part-filled last chunks)
-// is taken too.  Waiting is bounded in three ways: a wave only waits for work that resident, running waves are producing (a block is
-// claimed by a wave that is already running, so no wave ever waits for one that has no slot); every spin sleeps; and a spin that lasts
-// ~2^20 polls sets ctl->error and gives up (the frame is then wrong and vxrt_sync reports it, but the grid drains).
+// Hot words.  One memory channel takes ~90 atomics (or agent-scope loads) per microsecond — the ray counters taught that in round 1, and
+// the first version of this kernel, with one cursor block of 1 KB and every idle wave polling the same three words, spent 76 % of its
+// wave-cycles in s_waitcnt (profiles/r05/fused_kernel_counters.txt).  So: kCursors head cursors 256 bytes apart, cursor k over the
+// blocks k, k + kCursors, ... (the launch order survives in each); a wave starts at its own and goes round when that is dry; ONE block
+// per claim among the tiles that walk (the front of the order), four among the tiles of sky.  A wave that leaves the head phase adds
+// its blocks to one counter (one atomic per wave); the wave that completes the total raises kFlags copies of a flag, and an idle
+// wave looks only at its own copy, at the four shard counters of its own group and at their four chunk cursors, every ~14 us.
+//
+// Hand-over.  A head lane reserves its record slot with the shard's counter as before and stores the record with queue_store_fused:
+// seven 8-byte stores at agent scope (write-through, visible to every XCD), s_waitcnt, then the eighth, which holds the launch's
+// 16-bit stamp in the unused top of normal_ambient.  A consumer lane polls that word (agent scope) until the stamp is there, reads
+// the rest and writes the word back with stamp 0.  Before the heads are done only chunks whose 64 slots are all reserved are taken;
+// afterwards every shard counter is final and the part-filled last chunks go too.
+//
+// Waiting is bounded in three ways: a wave only waits for work that resident, running waves are producing (a block is claimed by a
+// wave that is already running, so no wave ever waits for one that has no slot); every spin sleeps; a spin that lasts longer than
+// any legitimate wait (tens of milliseconds) sets ctl->error and gives up — the frame is then wrong and vxrt_sync reports it, but
+// the grid drains.
+constexpr unsigned kCursors = 64, kFlags = 64, kHotStride = 64;   // uints: 256 bytes between hot words
 struct FusedCtl {
-    unsigned next_block;   // head work cursor
-    unsigned blocks_done;  // head blocks finished (their records stored and stamped)
-    unsigned error;        // a bounded wait ran out
-    unsigned pad[13];
-    unsigned next_chunk[kShards * kCountStride];   // per shard: the next chunk nobody has claimed yet (one 64-byte line each)
+    unsigned cursor[kCursors * kHotStride];        // head work cursors (local block index of cursor k)
+    unsigned done_flag[kFlags * kHotStride];       // copies of "every head block is finished"
+    unsigned heavy_flag[kFlags * kHotStride];      // copies of "every block of a tile that walked last time is finished": part-filled chunks may be closed
+    unsigned blocks_done[kHotStride];              // head blocks finished (their records stored and stamped), added wave by wave
+    unsigned heavy_done[kHotStride];               // ... of those, blocks before heavy_blocks
+    unsigned error[kHotStride];                    // a bounded wait ran out
+    unsigned next_chunk[kShards * kCountStride];   // per shard: the next chunk nobody has claimed yet
+    // diagnostics (vxrt_debug_fused_profile): shader clock ~earliest wave start (stored inverted), the clock when the done flags went
+    // up, the latest wave end; chunks taken before / after the flags; idle sleeps; stamp polls; head claims
+    unsigned long long prof[8];
 };
 
 __device__ __forceinline__ unsigned agent_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+#ifndef VXRT_FUSED_WAVES
+#define VXRT_FUSED_WAVES 4   // waves per SIMD of fused_kernel: 128 VGPRs — at 5 (96) the persistent state spills into the walk's loops
+#endif
 template <int kF>
-__global__ __launch_bounds__(kTB, VXRT_TRACE_WAVES) void fused_kernel(const TraceArgs a, FusedCtl* ctl, const unsigned total_blocks, const uint32_t stamp,
-                                                                      const int first_bounce) {
-    static_assert(kTB == 64, "one wave per block");
+__global__ __launch_bounds__(kTB, VXRT_FUSED_WAVES) void fused_kernel(const TraceArgs a, FusedCtl* ctl, const unsigned total_blocks, const uint32_t* sort_info,
+                                                                      const uint32_t stamp, const int first_bounce) {
+    static_assert(kTB == 64 && kCursors == 64, "one wave per block; lane c reads cursor c");
     extern __shared__ uint4 lds_stack[];
     const int lane = threadIdx.x & 63;
     zero_counts(a.tail_zero, threadIdx.x);
-    // ---- head phase: the launch's blocks, in launch order
-    for (;;) {
-        unsigned b = 0;
-        if (lane == 0) b = atomicAdd(&ctl->next_block, 1u);
-        b = __builtin_amdgcn_readfirstlane(b);
-        if (b >= total_blocks) break;
-        trace_block<false, kF, true>(a, b, lds_stack, stamp);
-        __builtin_amdgcn_s_waitcnt(0);             // this wave's record stores (and their stamps) have been written through
-        if (lane == 0) atomicAdd(&ctl->blocks_done, 1u);
+    const bool prof_wave = lane == 0 && blockIdx.x % 64u == 0u;    // every 64th wave reports (the counter line takes ~90 atomics per us)
+    if (prof_wave) atomicMax(&ctl->prof[0], ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+    unsigned prof_claims = 0, prof_idle = 0, prof_polls = 0, prof_before = 0, prof_after = 0;
+    // where the tiles that walk end in the launch order (tile_scan_kernel left the count and the spread beside the sort's histogram;
+    // spread_position puts them at the front, each followed by k tiles of sky): unknown (the stream's first launch) -> 0
+    unsigned heavy_blocks = 0;
+    if (sort_info != nullptr && a.tile_order != nullptr) {
+        const unsigned tiles = total_blocks / unsigned(a.batch), nh = sort_info[0], nl = tiles - (nh < tiles ? nh : tiles);
+        const unsigned k = nh ? unsigned((unsigned long long)nl * sort_info[1] / 256u / nh) & ~1u : 0u;
+        const unsigned long long hb = (unsigned long long)(nh < tiles ? nh : tiles) * (k + 1u) * unsigned(a.batch);
+        heavy_blocks = hb > total_blocks ? total_blocks : unsigned(hb);
     }
-    // ---- tail phase: chunks of 64 records, shard by shard starting at this wave's own
+    // ---- one loop, three kinds of work, in this order of preference:
+    //   1. a block of a tile that WALKS (the front of the launch order): the launch's critical path — claimed one at a time, run at
+    //      the highest priority;
+    //   2. a chunk of 64 queued paths that is complete (its tail is the second half of the critical path);
+    //   3. blocks of SKY, four per claim: filler, 5 us each, which nothing waits for.
+    // (The first version ran all of 1 and 3 before any of 2: the blocks of sky at the end of the order kept every wave in the head
+    // phase until it was over, and the "fused" launch was two phases again: 324 us to the last head block, 230 us of tail behind it.)
     const Caster<false> caster(a, lds_stack, int(threadIdx.x));
     const f3 sun_dir = ld3(a.sun_dir), sun_color = ld3(a.sun_color), sky = ld3(a.sky_color);
     const PathQueue none{nullptr, nullptr, 0u};
     uint32_t rays = 0;
-    unsigned shard = blockIdx.x % kShards;
-    unsigned idle_polls = 0;
-    for (;;) {
-        const bool heads_done = agent_load(&ctl->blocks_done) >= total_blocks;     // read BEFORE the counters: then they are final
-        bool got = false;
-        unsigned chunk = 0, reserved = 0;
-        for (unsigned t = 0; t < kShards && !got; t++) {                           // uniform: every lane sees the same values
-            const unsigned q = (shard + t) % kShards;
-            unsigned n = agent_load(a.tail.counts + q * kCountStride);
-            n = n < a.tail.shard_capacity ? n : a.tail.shard_capacity;
-            const unsigned next = agent_load(&ctl->next_chunk[q * kCountStride]);
-            // a whole chunk is reserved (its records are there or on their way), or the shard is final and holds a part-filled one
-            if ((next + 1u) * 64u <= n || (heads_done && next * 64u < n)) {
-                unsigned c = 0;
-                if (lane == 0) c = atomicAdd(&ctl->next_chunk[q * kCountStride], 1u);
-                c = __builtin_amdgcn_readfirstlane(c);
-                if ((c + 1u) * 64u <= n || (heads_done && c * 64u < n)) { got = true; chunk = c; reserved = n; shard = q; }
-                // else: another wave took it between the look and the claim; the cursor has moved past what exists, which is harmless
-                // for whole chunks (nobody claims beyond the counter) — but a claim beyond a part-filled shard's end must not be lost:
-                else if (c * 64u < n || !heads_done) {
-                    // c is a chunk that is (or may still become) real but is not complete yet: keep it and wait for it below
-                    got = true; chunk = c; reserved = n; shard = q;
-                }
+    const unsigned group = blockIdx.x % 16u;       // before part-filled chunks may be taken this wave serves the shards group, group + 16, + 32, + 48
+    const unsigned home = blockIdx.x % kShards;
+    const unsigned* my_flag = &ctl->done_flag[(blockIdx.x % kFlags) * kHotStride];
+    const unsigned* my_heavy_flag = &ctl->heavy_flag[(blockIdx.x % kFlags) * kHotStride];
+    unsigned my_blocks = 0, my_heavy = 0, idle = 0;
+    unsigned k = blockIdx.x % kCursors, last = 0;  // the head cursor this wave claims from, and where it stood at the wave's last claim
+    bool head_dry = total_blocks == 0u;
+    auto report_heavy = [&]() {   // this wave's finished blocks of walking tiles -> the counter; the wave that completes it raises the flags
+        if (my_heavy == 0u) return;
+        __builtin_amdgcn_s_waitcnt(0);             // their records are written through
+        if (lane == 0) {
+            const unsigned before = atomicAdd(&ctl->heavy_done[0], my_heavy);
+            if (before + my_heavy >= heavy_blocks)
+                for (unsigned f = 0; f < kFlags; f++) __hip_atomic_store(&ctl->heavy_flag[f * kHotStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        my_heavy = 0;
+    };
+    auto report_blocks = [&]() {  // ... and all its finished blocks, once, when the cursors are dry
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0 && my_blocks != 0u) {
+            const unsigned before = atomicAdd(&ctl->blocks_done[0], my_blocks);
+            if (before + my_blocks >= total_blocks) {  // the last head wave: every record is stored, every shard counter final
+                for (unsigned f = 0; f < kFlags; f++) __hip_atomic_store(&ctl->done_flag[f * kHotStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ctl->prof[1] = __builtin_amdgcn_s_memrealtime();
             }
         }
-        if (!got) {
-            if (heads_done) break;                 // every counter was final and every chunk is claimed: done
-            __builtin_amdgcn_s_sleep(64);
-            if (++idle_polls > (1u << 22)) { if (lane == 0) atomicOr(&ctl->error, 1u); break; }
+        my_blocks = 0;
+    };
+    // claims `step` blocks of cursor k; false: k is dry — then k moves to a cursor that is not, or head_dry is set
+    unsigned first_j = 0, count_j = 0;
+    auto claim_head = [&](unsigned step) -> bool {
+        for (;;) {
+            const unsigned per_cursor = total_blocks > k ? (total_blocks - k + kCursors - 1u) / kCursors : 0u;   // blocks k, k + kCursors, ... < total_blocks
+            unsigned i = 0;
+            if (lane == 0) i = atomicAdd(&ctl->cursor[k * kHotStride], step);
+            i = __builtin_amdgcn_readfirstlane(i);
+            prof_claims++;
+            if (i < per_cursor) { first_j = i; count_j = i + step <= per_cursor ? step : per_cursor - i; last = i + step; return true; }
+            // this cursor is dry for good.  ONE look at all of them (lane c reads cursor c) instead of 63 more failed claims — which is
+            // what every wave did at first, 330 000 atomics per launch on 64 lines — then on to the first after this one that is not
+            const unsigned c = unsigned(lane) % kCursors;
+            const unsigned per_c = total_blocks > c ? (total_blocks - c + kCursors - 1u) / kCursors : 0u;
+            unsigned long long m = __ballot(agent_load(&ctl->cursor[c * kHotStride]) < per_c);
+            if (m == 0ull) { head_dry = true; return false; }                                // every block is taken
+            const unsigned r = (k + 1u) % kCursors;
+            m = r == 0u ? m : (m >> r | m << (64u - r));
+            k = (r + unsigned(__ffsll((long long)m) - 1)) % kCursors;
+            last = 0xffffffffu / kCursors;                                                   // its front is gone by now
+            step = 4u;
+        }
+    };
+    for (;;) {
+        // ---- what next?
+        bool do_head = false, do_chunk = false;
+        unsigned shard = 0, chunk = 0, n_s = 0;
+        bool heads_done = false;
+        if (head_dry && my_blocks != 0u) { report_heavy(); report_blocks(); }                // the cursors are dry: this wave's blocks count now
+        if (!head_dry && last * kCursors + k < heavy_blocks) do_head = claim_head(1u);       // 1. a walking tile
+        if (!do_head) {                                                                      // 2. a chunk
+            heads_done = agent_load(my_flag) != 0u;                                          // read BEFORE the counters: then they are final
+            // once the tiles that walked last time are through, a part-filled chunk is worth taking: whoever takes it closes it
+            const bool closing = heads_done || (heavy_blocks != 0u && agent_load(my_heavy_flag) != 0u);
+            const unsigned q = unsigned(lane);      // lane q looks at shard q — before `closing` only the four lanes of this wave's group do
+            const bool mine = closing || (q % 16u) == group;
+            unsigned n = 0, next = 0;
+            if (mine) {
+                n = agent_load(a.tail.counts + q * kCountStride);
+                n = n < a.tail.shard_capacity ? n : a.tail.shard_capacity;
+                next = agent_load(&ctl->next_chunk[q * kCountStride]);
+            }
+            const bool open = mine && ((next + 1u) * 64u <= n || (closing && next * 64u < n));
+            unsigned long long m = __ballot(open);
+            m = home == 0u ? m : (m >> home | m << (64u - home));                           // rotate: bit 0 = the wave's own shard
+            if (m != 0ull) {
+                shard = (home + unsigned(__ffsll((long long)m) - 1)) % kShards;
+                n_s = __shfl(n, int(shard), 64);
+                if (lane == 0) chunk = atomicAdd(&ctl->next_chunk[shard * kCountStride], 1u);
+                chunk = __builtin_amdgcn_readfirstlane(chunk);
+                do_chunk = !(heads_done && chunk * 64u >= n_s);                              // (somebody else took the shard's last chunk)
+                if (!do_chunk) continue;
+            }
+        }
+        if (!do_head && !do_chunk && !head_dry) do_head = claim_head(4u);                    // 3. sky
+        if (!do_head && !do_chunk) {
+            if (heads_done) break;                 // every counter is final and every chunk is claimed: done
+            idle++;
+            prof_idle++;
+            for (unsigned z = 0; z < 4u; z++) __builtin_amdgcn_s_sleep(127);               // ~14 us
+            if (idle > (1u << 13)) { if (lane == 0) atomicOr(&ctl->error[0], 1u); break; }  // > 0.1 s of nothing: give up
             continue;
         }
-        // lane i takes record 64 chunk + i: wait for its stamp (it may not even be reserved yet when the chunk was claimed early)
+        idle = 0;
+        if (do_head) {
+            for (unsigned j = first_j; j < first_j + count_j; j++) {
+                const unsigned b = j * kCursors + k;
+                // a walking tile's chain is the launch's critical path, and here it shares its SIMD with chunks and blocks of sky
+                if (b < heavy_blocks) __builtin_amdgcn_s_setprio(3);
+                trace_block<false, kF, true>(a, b, lds_stack, stamp);
+                __builtin_amdgcn_s_setprio(0);
+                my_blocks++;
+                if (b < heavy_blocks) my_heavy++;
+            }
+            if (my_heavy != 0u && last * kCursors + k >= heavy_blocks) report_heavy();       // this wave has left the front of the order
+            continue;
+        }
+        // ---- a chunk.  Which of its 64 slots hold (or will hold) a record: all of them if the chunk is full; for a part-filled chunk,
+        // wait until it fills, or — once part-filled chunks may be taken — CLOSE it: the shard's counter jumps from n to the chunk's
+        // end, so that later records start the next chunk, and the slots from n on stay empty.  Wave-uniform.
+        __builtin_amdgcn_s_setprio(1);             // a chunk is a chain too: ahead of the blocks of sky, behind the walking tiles
+        const unsigned chunk_end = (chunk + 1u) * 64u < a.tail.shard_capacity ? (chunk + 1u) * 64u : a.tail.shard_capacity;
+        unsigned limit = chunk_end;
+        if (n_s < chunk_end) {
+            report_heavy();                        // this wait may depend on the flags: nothing this wave has finished may be missing from them
+            report_blocks();
+            for (unsigned tries = 0;; tries++) {
+                const bool done_now = agent_load(my_flag) != 0u;                            // before the counter: then it is final
+                const unsigned cnt = agent_load(a.tail.counts + shard * kCountStride);
+                if (cnt >= chunk_end) break;                                                // filled meanwhile
+                if (done_now) { limit = cnt > chunk * 64u ? cnt : chunk * 64u; break; }     // final: what is there is all there will be
+                // (only the chunk at the shard's fill front is closed — cnt > chunk * 64: a jump over an earlier chunk's free slots would
+                // make its owner wait for records that never come)
+                if (heavy_blocks != 0u && cnt > chunk * 64u && agent_load(my_heavy_flag) != 0u && chunk_end == (chunk + 1u) * 64u) {
+                    unsigned old = 0;
+                    if (lane == 0) old = atomicCAS(a.tail.counts + shard * kCountStride, cnt, chunk_end);
+                    old = __builtin_amdgcn_readfirstlane(old);
+                    if (old == cnt) { limit = cnt; break; }                                  // closed with cnt records
+                    continue;                                                               // the counter moved: look again
+                }
+                __builtin_amdgcn_s_sleep(100);
+                if (tries > (1u << 15)) { if (lane == 0) atomicOr(&ctl->error[0], 8u); limit = chunk * 64u; break; }
+            }
+        }
+        if (heads_done) prof_after++; else prof_before++;
         const unsigned entry = chunk * 64u + unsigned(lane);
-        unsigned long long* word = reinterpret_cast<unsigned long long*>(a.tail.recs + (size_t(shard) * a.tail.shard_capacity + entry) * 4u) + 3;  // dir.z | normal_ambient
+        const bool in_queue = entry < limit;
+        float4* slot = a.tail.recs + (size_t(shard) * a.tail.shard_capacity + (in_queue ? entry : 0u)) * 4u;
+        unsigned long long* word = reinterpret_cast<unsigned long long*>(slot) + 3;          // dir.z | normal_ambient, stamp on top
         bool valid = false;
         unsigned long long w3 = 0ull;
-        if (entry < a.tail.shard_capacity) {
+        if (in_queue) {   // reserved: the record is there or on its way
             for (unsigned polls = 0;; polls++) {
                 w3 = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (unsigned(w3 >> 48) == stamp) { valid = true; break; }
-                // not there: it is coming if it is reserved; if the heads are done and the final counter does not reach it, it never will
-                if (agent_load(&ctl->blocks_done) >= total_blocks) {
-                    unsigned n = agent_load(a.tail.counts + shard * kCountStride);
-                    n = n < a.tail.shard_capacity ? n : a.tail.shard_capacity;
-                    if (entry >= n) break;
-                }
-                __builtin_amdgcn_s_sleep(16);
-                if (polls > (1u << 20)) { atomicOr(&ctl->error, 2u); break; }
+                if (lane == 0) prof_polls++;
+                if (polls < 16u) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(64);
+                if (polls > (1u << 14)) { atomicOr(&ctl->error[0], 2u); break; }
             }
         }
-        (void)reserved;
         if (valid) {
-            PathRec rec = load_rec_fused(a.tail.recs + (size_t(shard) * a.tail.shard_capacity + entry) * 4u, w3);
+            const PathRec rec = load_rec_fused(slot, w3);
             __hip_atomic_store(word, w3 & 0x0000ffffffffffffull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // stamp 0: the slot is free for the next launch
             bounce_path<false>(a, caster, rec, none, shard, first_bounce, a.max_bounces, sun_dir, sun_color, sky, rays);
         }
+        __builtin_amdgcn_s_setprio(0);
     }
     count_rays(a.ray_counter, rays, lane);
+    if (prof_wave) {
+        atomicMax(&ctl->prof[2], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+        atomicAdd(&ctl->prof[3], (unsigned long long)prof_before);
+        atomicAdd(&ctl->prof[4], (unsigned long long)prof_after);
+        atomicAdd(&ctl->prof[5], (unsigned long long)prof_idle);
+        atomicAdd(&ctl->prof[6], (unsigned long long)prof_polls);
+        atomicAdd(&ctl->prof[7], (unsigned long long)prof_claims);
+    }
 }
+
+#endif  // VXRT_VARIANTS
 
 // Counting sort of the tiles by descending cost (key = log2 of the cost with two mantissa bits: 128 bins) in three small launches:
 // per-block histograms over contiguous tile ranges (coalesced reads) -> one block turns them into (key, block) offsets -> each block
@@ -685,23 +825,33 @@ hipError_t launch_trace(const TraceArgs& args, bool wide, bool hbm_scene, hipStr
 }
 
 
+#if VXRT_VARIANTS
 size_t fused_ctl_bytes() { return sizeof(FusedCtl); }
 
 // One grid of persistent one-wave blocks for the whole launch (fused_kernel).  ctl: device memory of fused_ctl_bytes(), zeroed on the
-// stream before this call.  stamp: 1 .. 65535, different from the previous launch's on the same queue.
-hipError_t launch_fused(const TraceArgs& args, void* ctl, unsigned waves, uint32_t stamp, hipStream_t s) {
+// stream before this call.  sort_scratch: the tile sort's scratch of the order in a.tile_order (null: none yet — every block is claimed in fours).
+// stamp: 1 .. 65535, different from the previous launch's on the same queue.
+hipError_t launch_fused(const TraceArgs& args, void* ctl, unsigned waves, const uint32_t* sort_scratch, uint32_t stamp, hipStream_t s) {
     TraceArgs a = args;
     a.block_first = 0;
     if (kTB != 64) return hipErrorInvalidValue;
     const unsigned all_blocks = trace_tile_count(a.band.width, a.band.local_rows) * unsigned(a.batch);
+    const uint32_t* sort_info = sort_scratch ? sort_scratch + kSortBins * kSortBlocks : nullptr;
     const size_t lds = caster_lds_bytes(a, false, kTB);
     dim3 grid(waves < 1u ? 1u : waves);
+    FusedCtl* fc = static_cast<FusedCtl*>(ctl);
     constexpr int kF8 = kTB == 64 ? 8 : 1, kF4 = kTB == 64 ? 4 : 1;
-    if (a.frame_lanes == 8) hipLaunchKernelGGL((fused_kernel<kF8>), grid, dim3(kTB), lds, s, a, static_cast<FusedCtl*>(ctl), all_blocks, stamp, a.tail_from);
-    else if (a.frame_lanes == 4) hipLaunchKernelGGL((fused_kernel<kF4>), grid, dim3(kTB), lds, s, a, static_cast<FusedCtl*>(ctl), all_blocks, stamp, a.tail_from);
-    else hipLaunchKernelGGL((fused_kernel<1>), grid, dim3(kTB), lds, s, a, static_cast<FusedCtl*>(ctl), all_blocks, stamp, a.tail_from);
+    if (a.frame_lanes == 8) hipLaunchKernelGGL((fused_kernel<kF8>), grid, dim3(kTB), lds, s, a, fc, all_blocks, sort_info, stamp, a.tail_from);
+    else if (a.frame_lanes == 4) hipLaunchKernelGGL((fused_kernel<kF4>), grid, dim3(kTB), lds, s, a, fc, all_blocks, sort_info, stamp, a.tail_from);
+    else hipLaunchKernelGGL((fused_kernel<1>), grid, dim3(kTB), lds, s, a, fc, all_blocks, sort_info, stamp, a.tail_from);
     return hipGetLastError();
 }
+
+// byte offset of the error word in the control block (the host copies the block's head back after a launch)
+size_t fused_ctl_error_offset() { return offsetof(FusedCtl, error); }
+size_t fused_ctl_profile_offset() { return offsetof(FusedCtl, prof); }
+
+#endif  // VXRT_VARIANTS
 
 hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t* last_cost, uint32_t* scratch, unsigned tiles, unsigned waves_x_launches,
                              unsigned wave_slots, int spread_override, hipStream_t s) {

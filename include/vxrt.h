@@ -93,13 +93,15 @@ typedef struct vxrt_config {
     uint32_t noise_seed;      /* seed of the generated noise table when `noise` is NULL                 */
     const float* noise;       /* optional 512*128*128 floats in [0,1) (layout of shaders/voxels.comp:65-71) */
     uint32_t rank, nranks;    /* this context renders the row bands b with b % nranks == rank ...       */
-    uint32_t band_rows;       /* ... where band b = rows [b*band_rows, (b+1)*band_rows); 0 -> 16.  A multiple of 8;
-                               * of 16 if the denoise stage runs with radius > 0 (its tiles are 16 rows).
-                               * That holds for the whole ROUNDS of nranks bands; the rows left below them (fewer
-                               * than nranks * band_rows) are dealt as one more round of lower bands — the smallest
-                               * multiple of the tile height (16, or 8 for 8-row bands) that covers them in nranks
-                               * bands — so that every rank owns within one tile row of height / nranks rows.
-                               * vxrt_local_rows lists a context's rows; distributed.BandLayout states the rule.     */
+    uint32_t band_rows;       /* ... where band b = rows [b*band_rows, (b+1)*band_rows); 0 -> 16.  2, 4 or a multiple of 8
+                               * (8 = the tracer's tile height: what launches of single frames want; 2 and 4 suit launches of
+                               * frame groups, whose waves hold 1 or 2 rows — the finer the interleave the more alike the ranks'
+                               * shares); a multiple of 16 if the denoise stage runs with radius > 0 (its tiles are 16 rows).
+                               * That holds for the whole ROUNDS of nranks bands; when the frame is not a whole number of
+                               * rounds the LAST round takes the remainder as well, in taller bands — the smallest multiple
+                               * of the tile height (16, 8 or band_rows) that covers it in nranks bands — so that every rank
+                               * owns within one tile row of height / nranks rows and no band with a band below it is lower
+                               * than band_rows.  vxrt_local_rows lists a context's rows; distributed.BandLayout states the rule. */
                               /* nranks = 0 or 1 -> the whole frame                                     */
     uint32_t frames_in_flight;/* 0/1: every stage of a frame runs in submission order on one stream (the
                                  reference's single queue).  F = 2..16: the TRACE stage of up to F consecutive
@@ -220,15 +222,17 @@ typedef struct vxrt_stats {
  *                          contiguous: same image, same walk code.  vxrt_stats.node_order reads what the scene in place has.
  *   VXRT_OPT_HEAD_STAGGER  1: with several trace launches in flight (one stream each), a launch's trace_kernel starts only when the previous
  *                          launch's trace_kernel has finished, so that it runs beside that launch's bounce_kernel (a short block of few
- *                          launches: the heads do not drain together).  0 (default): launches overlap freely.
+ *                          launches: the heads do not drain together).  Measured slower (-DVXRT_VARIANTS=1 builds only).  0 (default).
  *   VXRT_OPT_FUSED_TAIL    1: head and compacted tail of a trace launch run as ONE grid of persistent waves that take the launch's tiles
  *                          from a cursor and then its queued paths, chunk by chunk as they become complete — for launches that are
  *                          little more than their longest chains (a rank's share of a short block on many GPUs); 4-bounce tails,
- *                          8-byte records, scenes in cache.  Same image.  0 (default): trace_kernel, then bounce_kernel.
+ *                          8-byte records, scenes in cache.  Same image — and measured SLOWER (a scheduler in software pays for every
+ *                          decision with device-scope memory round trips): -DVXRT_VARIANTS=1 builds only.  0 (default): trace_kernel,
+ *                          then bounce_kernel.
  *   VXRT_OPT_LONG_TILES    per mille (0 = off .. 500) of a trace launch's tiles — the first of its longest-first order — that run as an
  *                          all-in-one grid on a second stream (a path's whole chain in one wave, begun when the launch begins) beside
  *                          the head + compacted tail of the others: for launches that are little more than their longest chains
- *                          (a rank's share of a short block on many GPUs).  Same image.
+ *                          (a rank's share of a short block on many GPUs).  Same image; measured slower (-DVXRT_VARIANTS=1 builds only).
  *   VXRT_OPT_TRACER_OVERRIDE   create: the internal schedule past vxrt_config.tracer's automatic choice: 0 all-in-one kernel, 4 head +
  *                          compacted tail; 2 / 3 / 5 (-DVXRT_VARIANTS=1 builds) wavefront, ray queues, path kernel.
  *   VXRT_OPT_TRACE_SPLIT / PATH_BLOCKS / SHADE_BLOCKS / RAYS_PER_WAVE   create: launch shapes of tracers 2, 3 and 5.                    */
@@ -440,6 +444,9 @@ int vxrt_debug_tile_order(vxrt_ctx* ctx, uint32_t* order, uint32_t* cost, size_t
  * test instead of walking the octree.  They are counted in vxrt_stats.rays (each is one cast_bounded_ray of voxels.comp:134-247,
  * answered without a walk); for a camera at rest, rays per frame minus this = the rays that walked. */
 int vxrt_debug_culled_pixels(vxrt_ctx* ctx, uint64_t* count);
+/* Diagnostics of trace stream 0's last fused launch (VXRT_OPT_FUSED_TAIL): shader clocks to "every head block finished" and to the last
+ * wave's end, chunks taken before / after that moment, idle sleeps, stamp polls, head claims, 0. */
+int vxrt_debug_fused_profile(vxrt_ctx* ctx, uint64_t out[8]);
 
 const char* vxrt_status_string(int status);
 const char* vxrt_last_error(void);               /* thread-local detail of the last failing call */

@@ -52,7 +52,7 @@ def require_variants(H, env=None, tracer=None, wide=None):
     only with -DVXRT_VARIANTS=1) runs in libvxrt_variants.so, loaded beside the product for the length of the test (round 5; until
     then these cases were skipped unless VXRT_LIB pointed at that build).  The autouse fixture below switches back."""
     env = env or {}
-    needs = (str(env.get("VXRT_TRACE_VARIANT", "")) in ("2", "3", "5") or str(env.get("VXRT_WIDE", "")) == "1" or
+    needs = (str(env.get("VXRT_TRACE_VARIANT", "")) in ("2", "3", "5") or str(env.get("VXRT_WIDE", "")) == "1" or str(env.get("VXRT_FUSED_TAIL", "")) == "1" or str(env.get("VXRT_LONG_TILES", "0")) != "0" or
              str(tracer) in ("2", "3", "5") or str(wide) in ("1", "True", "wide"))
     if needs and not H.has_variants():
         H.use_library(H.variants_library())

@@ -211,9 +211,9 @@ def test_band_layout_folds_the_remainder_into_a_taller_last_round():
     deep at EVERY band edge (round 4 dealt the remainder as an extra round of lower bands and capped the whole frame's halo at them)."""
     from gpu_voxel_raytracer_amd import distributed as D
     for h, n, band in ((2160, 8, 48), (2160, 8, 64), (2160, 4, 64), (2160, 3, 48), (200, 2, 16), (1080, 8, 8), (1080, 5, 32), (50, 2, 16), (4320, 8, 64), (37, 3, 16),
-                       (304, 4, 32), (2160, 8, 16), (1080, 2, 8)):
+                       (304, 4, 32), (2160, 8, 16), (1080, 2, 8), (1080, 8, 4), (1080, 8, 2), (150, 8, 2)):
         L = D.BandLayout(7, h, n, band, radius=0 if band % 16 else None)
-        tile = 16 if band % 16 == 0 else 8
+        tile = 16 if band % 16 == 0 else (8 if band % 8 == 0 else band)
         rows = [L.rows(r) for r in range(n)]
         assert sorted(np.concatenate(rows).tolist()) == list(range(h))
         counts = [len(r) for r in rows]

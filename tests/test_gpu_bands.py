@@ -120,10 +120,12 @@ def test_multirank_denoise_without_halo_is_refused(H, scenes, noise):
         Context(64, 64, rank=0, nranks=2, band_rows=12)          # a multiple of 8 (the tracer's tiles); 16 for a denoise window
 
 
-@pytest.mark.parametrize("nranks,w,h", [(8, 96, 136), (3, 64, 100)])
-def test_eight_row_bands_without_denoise_window(H, scenes, noise, nranks, w, h):
-    """band_rows = 8 (bench.py's deal at N > 1: the tracer's tile height) through trace, temporal and the radius-0 denoise equals the
-    single-context frame; a denoise radius > 0 is refused for such bands (its 16-row tiles would straddle two of them)."""
+@pytest.mark.parametrize("nranks,w,h,band", [(8, 96, 136, 8), (3, 64, 100, 8), (8, 96, 136, 4), (8, 72, 150, 2), (3, 64, 100, 4)])
+def test_eight_row_bands_without_denoise_window(H, scenes, noise, nranks, w, h, band):
+    """band_rows = 8 (bench.py's deal at N > 1: the tracer's tile height), and 4 or 2 (round 5: the finer interleave bench.py takes for a
+    short block from 8 ranks on — a tile of 8 local rows then spans two or four bands, each lane finds its own frame row), through
+    trace, temporal and the radius-0 denoise equals the single-context frame; a denoise radius > 0 is refused for such bands (its
+    16-row tiles would straddle two of them)."""
     from gpu_voxel_raytracer_amd import ALL, DENOISE, TEMPORAL, TRACE, Camera, Context
     from gpu_voxel_raytracer_amd.host import VxrtError
     pos, mrgb, size = scenes.load_scene("castle")
@@ -131,7 +133,7 @@ def test_eight_row_bands_without_denoise_window(H, scenes, noise, nranks, w, h):
     with Context(w, h, max_bounces=3, noise=noise) as single:
         single.recreate_octree(pos, mrgb)
         single.camera = cam
-        ctxs = [Context(w, h, max_bounces=3, noise=noise, rank=r, nranks=nranks, band_rows=8, frames_per_launch=2) for r in range(nranks)]
+        ctxs = [Context(w, h, max_bounces=3, noise=noise, rank=r, nranks=nranks, band_rows=band, frames_per_launch=2) for r in range(nranks)]
         try:
             rows = []
             for c in ctxs:
@@ -139,7 +141,10 @@ def test_eight_row_bands_without_denoise_window(H, scenes, noise, nranks, w, h):
                 c.camera = cam
                 rows.append(c.local_rows())
             assert sorted(np.concatenate(rows).tolist()) == list(range(h))
-            assert rows[1][:8].tolist() == list(range(8, 16))
+            assert rows[1][:band].tolist() == list(range(band, 2 * band))
+            from gpu_voxel_raytracer_amd.distributed import BandLayout
+            for r in range(nranks):
+                assert np.array_equal(rows[r], BandLayout(w, h, nranks, band, radius=0).rows(r))
             for frame in range(3):
                 single.render(ALL)
                 for c in ctxs:
@@ -277,3 +282,45 @@ def test_fast_pan_keeps_its_history_on_every_band_edge_when_the_frame_is_not_who
         finally:
             for c in ctxs:
                 c.close()
+
+
+def test_short_block_deal_of_eight_ranks_equals_one_context(H, scenes, noise):
+    """bench.py's deal of the driver's 20-frame block on 8 ranks (pick_deal: 4-row bands, the all-in-one kernel, all 20 frames in ONE
+    launch — frame lanes of 2 rows x 4 frames) against one context that renders the same 20 frames the default way (8 + 8 + 4 frames
+    on three streams, head + compacted tail): the last frame of the block, stitched from the 8 band sets, bit for bit — colour,
+    normal / depth, albedo / node — and the ray totals.  (the new deal's frames against the single-launch frames.)"""
+    import importlib.util, os
+    from conftest import ROOT
+    from gpu_voxel_raytracer_amd import TRACE, Camera, Context
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    band, tracer = bench.pick_deal(8, 20)
+    inflight, batch = bench.pick_schedule(8, 20)
+    assert (band, tracer, inflight, batch) == (4, 1, 1, 20)
+    w, h, nranks, frames = 1920, 1080, 8, 20
+    pos, mrgb, size = scenes.load_scene("menger")
+    cam = Camera(*scenes.bench_camera(size))
+    i1, b1 = bench.pick_schedule(1, 20)
+    with Context(w, h, max_bounces=4, noise=noise, frames_in_flight=i1, frames_per_launch=b1) as single:
+        single.recreate_octree(pos, mrgb)
+        single.camera = cam
+        single.render_frames(TRACE, frames)
+        want = [single.read(i) for i in range(3)]
+        want_rays = single.stats().rays
+    got = [np.zeros_like(x) for x in want]
+    rays = 0
+    for r in range(nranks):
+        with Context(w, h, max_bounces=4, noise=noise, rank=r, nranks=nranks, band_rows=band, frames_in_flight=inflight, frames_per_launch=batch, tracer=tracer) as c:
+            c.recreate_octree(pos, mrgb)
+            c.camera = cam
+            c.render_frames(TRACE, frames)
+            rows = c.local_rows()
+            assert abs(len(rows) - h / nranks) <= 4
+            for i in range(3):
+                got[i][rows] = c.read(i)
+            rays += c.stats().rays
+            assert c.stats().frame_lane_launches == 1          # the one launch of 20 frames held 4 frames of 2 rows per wave
+    for i, label in enumerate(("colour", "normal/depth", "albedo/node")):
+        assert_bits_equal(got[i], want[i], f"frame 20 of the block, {label}: 8 ranks' deal against one context")
+    assert rays == want_rays
