@@ -316,7 +316,7 @@ def test_short_block_deal_of_eight_ranks_equals_one_context(H, scenes, noise):
             c.camera = cam
             c.render_frames(TRACE, frames)
             rows = c.local_rows()
-            assert abs(len(rows) - h / nranks) <= 4
+            assert len(rows) - h / nranks < 4                   # the busiest rank within a tile row of an even share (one rank takes what is left: 128 rows)
             for i in range(3):
                 got[i][rows] = c.read(i)
             rays += c.stats().rays

@@ -198,6 +198,8 @@ int main(int argc, char** argv) {
                     if (a != b) { (void)hipSetDevice(a); (void)hipDeviceEnablePeerAccess(b, 0); }
 
         Barrier barrier(n);
+        std::mutex abort_mutex;
+        bool aborted = false;
         auto run = [&](int r) {
             Rank& me = ranks[size_t(r)];
             try {
@@ -299,12 +301,22 @@ int main(int argc, char** argv) {
             } catch (const std::exception& ex) {
                 me.error = ex.what();
                 barrier.fail();
+                // Over RCCL the peers do not meet at the barrier every frame: they may be inside ncclGroupEnd, or their streams may be
+                // waiting on sends and receives this rank will never post.  Abort every communicator so that they come out (with an
+                // error of their own) instead of sitting there until somebody's timeout; the process then exits 1.
+                if (o.rccl) {
+                    std::lock_guard<std::mutex> l(abort_mutex);
+                    if (!aborted) {
+                        aborted = true;
+                        for (ncclComm_t cm : comms) if (cm) (void)ncclCommAbort(cm);      // (an aborted communicator is not destroyed again below)
+                    }
+                }
             }
         };
         std::vector<std::thread> threads;
         for (int r = 0; r < n; r++) threads.emplace_back(run, r);
         for (std::thread& t : threads) t.join();
-        if (o.rccl) for (ncclComm_t c : comms) if (c) (void)ncclCommDestroy(c);
+        if (o.rccl && !aborted) for (ncclComm_t c : comms) if (c) (void)ncclCommDestroy(c);
         for (int r = 0; r < n; r++)
             if (!ranks[size_t(r)].error.empty()) throw std::runtime_error("rank " + std::to_string(r) + ": " + ranks[size_t(r)].error);
 
