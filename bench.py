@@ -792,7 +792,8 @@ def trace_bench(args):
             # what the profile shows: VALU issue, not bandwidth, limits this stage (the `valu` object below).  The HBM
             # figures stay because the path is nominally HBM-bound work (no contraction, no MFMA): achieved = algorithmic bytes of
             # the K steps / the block's wall time; frac follows from wall time and nothing else.
-            "bound": "hbm", "limited_by": "valu issue (see valu)", "kernel": "trace_kernel + bounce_kernel (one trace stage)",
+            "bound": "hbm", "limited_by": "valu issue (see valu)",
+            "kernel": "trace_kernel, all-in-one (one trace stage)" if args.tracer == 1 else "trace_kernel + bounce_kernel (one trace stage)",
             "achieved": round(wall, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(wall / HBM_PEAK_GBS, 5),
             "algorithmic_bytes_per_step": int(alg),
             "traffic": None, "traffic_source": None,
