@@ -171,11 +171,13 @@ static int wait_stream(hipStream_t s) {
 int sync_all(vxrt_ctx* c) {
     for (hipStream_t t : c->trace_streams) { if (int rc = wait_stream(t)) return rc; }
     if (int rc = wait_stream(c->stream)) return rc;
+    unsigned fused_bits = 0;
     for (vxrt_ctx::StreamQueues& sq : c->queues)      // fused_kernel's report of the last launch (copied back behind it)
-        if (sq.host_ctl != nullptr && sq.host_ctl[2] != 0u) { c->fused_errors++; sq.host_ctl[2] = 0u; }
+        if (sq.host_ctl != nullptr && sq.host_ctl[2] != 0u) { c->fused_errors++; fused_bits |= sq.host_ctl[2]; sq.host_ctl[2] = 0u; }
     if (c->fused_errors != 0) {
         c->fused_errors = 0;
-        set_error("fused head + tail: a bounded wait of fused_kernel ran out (frames of the last launches are incomplete)");
+        set_error(("fused head + tail: a bounded wait of fused_kernel ran out (frames of the last launches are incomplete); bits " + std::to_string(fused_bits) +
+                   ": 1 idle, 2 a record's stamp, 4 -, 8 a part-filled chunk").c_str());
         return VXRT_E_DEVICE;
     }
     return VXRT_OK;

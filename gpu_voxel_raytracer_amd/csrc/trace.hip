@@ -320,10 +320,11 @@ __global__ __launch_bounds__(kTB, kWaves) void trace_kernel(const TraceArgs a) {
 
 #if VXRT_VARIANTS
 // ---- fused_kernel: head and compacted tail of a launch in ONE grid of persistent waves (VXRT_OPT_FUSED_TAIL; -DVXRT_VARIANTS=1 only) --------
-// MEASURED SLOWER (round 5; HISTORY.md section 11): bit-identical images, 0.53 ms against 0.41 (two kernels) and 0.375 (all-in-one) for a
+// MEASURED SLOWER (round 5; HISTORY.md section 11): bit-identical images, 0.50 ms against 0.41 (two kernels) and 0.375 (all-in-one) for a
 // rank of 8's 20-frame block.  A software scheduler pays for every decision with round trips through device-scope memory (2-5 us each:
-// a claim, a look at the shard counters, a flag) where the hardware's dispatcher starts the next wave for nothing; 51 % of its
-// wave-cycles are s_waitcnt.  Kept beside tracers 2, 3 and 5 as the record of the attempt, with its parity cases.
+// a claim, a look at the shard counters, a flag) where the hardware's dispatcher starts the next wave for nothing, and it holds both
+// kernels' bodies (4 waves per SIMD) in waves that sleep in their slots when they have nothing to do.  Kept beside tracers 2, 3 and 5
+// as the record of the attempt, with its parity cases.
 // A launch that is little more than its longest chains — a rank's share of a short block on many GPUs: 20 frames of an eighth of the
 // rows — spends its time DRAINING: trace_kernel ends when its longest wave ends (the chip two thirds idle by then), and only then may
 // bounce_kernel start, which drains again.  Two chains end to end, at 83 % and 64 % of the instruction rate the same kernels reach in
@@ -365,6 +366,13 @@ struct FusedCtl {
 };
 
 __device__ __forceinline__ unsigned agent_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// ... and one that has RETURNED before anything after it is issued: two loads sent off back to back may be sampled in either order, and
+// "the flag is up, so the counter I read is final" needs the flag sampled first
+__device__ __forceinline__ unsigned agent_load_first(const unsigned* p) {
+    const unsigned v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return v;
+}
 
 #ifndef VXRT_FUSED_WAVES
 #define VXRT_FUSED_WAVES 4   // waves per SIMD of fused_kernel: 128 VGPRs — at 5 (96) the persistent state spills into the walk's loops
@@ -429,6 +437,13 @@ __global__ __launch_bounds__(kTB, VXRT_FUSED_WAVES) void fused_kernel(const Trac
     };
     // claims `step` blocks of cursor k; false: k is dry — then k moves to a cursor that is not, or head_dry is set
     unsigned first_j = 0, count_j = 0;
+    // what was asked for before the last blocks of sky ran: a claim of four more (lane 0 holds the answer), and a look at the chunks
+    bool sky_pending = false, pf = false, pf_mine = false, closing_seen = false;
+    // a chunk that was claimed part-filled while a claim of sky is in hand: waiting for it may mean waiting for the done flag, i.e. for
+    // this wave's own unrun blocks — so it is set aside until they have run
+    bool held = false;
+    unsigned held_shard = 0, held_chunk = 0, held_ns = 0;
+    unsigned pf_sky_i = 0, pf_k = 0, pf_done = 0, pf_hv = 0, pf_n = 0, pf_next = 0;
     auto claim_head = [&](unsigned step) -> bool {
         for (;;) {
             const unsigned per_cursor = total_blocks > k ? (total_blocks - k + kCursors - 1u) / kCursors : 0u;   // blocks k, k + kCursors, ... < total_blocks
@@ -455,33 +470,55 @@ __global__ __launch_bounds__(kTB, VXRT_FUSED_WAVES) void fused_kernel(const Trac
         bool do_head = false, do_chunk = false;
         unsigned shard = 0, chunk = 0, n_s = 0;
         bool heads_done = false;
-        if (head_dry && my_blocks != 0u) { report_heavy(); report_blocks(); }                // the cursors are dry: this wave's blocks count now
-        if (!head_dry && last * kCursors + k < heavy_blocks) do_head = claim_head(1u);       // 1. a walking tile
-        if (!do_head) {                                                                      // 2. a chunk
-            heads_done = agent_load(my_flag) != 0u;                                          // read BEFORE the counters: then they are final
-            // once the tiles that walked last time are through, a part-filled chunk is worth taking: whoever takes it closes it
-            const bool closing = heads_done || (heavy_blocks != 0u && agent_load(my_heavy_flag) != 0u);
+        if (head_dry && my_blocks != 0u && !sky_pending) { report_heavy(); report_blocks(); }   // the cursors are dry: this wave's blocks count now
+        if (!head_dry && !sky_pending && last * kCursors + k < heavy_blocks) do_head = claim_head(1u);   // 1. a walking tile
+        // 2. a chunk — from the look that was sent off BEFORE the last blocks of sky ran (pf), or from a look made now.  (With a claim
+        // of sky in hand and no look, the blocks go first: they send the next look off.)
+        if (!do_head && held && !sky_pending) { do_chunk = true; shard = held_shard; chunk = held_chunk; n_s = held_ns; held = false; pf = false; }
+        if (!do_head && !do_chunk && !held && (pf || !sky_pending)) {
             const unsigned q = unsigned(lane);      // lane q looks at shard q — before `closing` only the four lanes of this wave's group do
-            const bool mine = closing || (q % 16u) == group;
-            unsigned n = 0, next = 0;
-            if (mine) {
-                n = agent_load(a.tail.counts + q * kCountStride);
+            // The look that travelled while the blocks ran is good for ONE thing: "a whole chunk is reserved" (a counter only grows,
+            // and the claim below is checked against it).  Its flags and its counters were sampled in no particular order, so
+            // whatever depends on the flags — taking a part-filled chunk, deciding that nothing is left — is decided by a look made
+            // now, flag first.
+            for (bool fresh = !pf;; fresh = true) {
+                unsigned n = 0, next = 0;
+                bool mine, closing = false;
+                if (!fresh) {
+                    mine = pf_mine; n = pf_n; next = pf_next;
+                    pf = false;
+                } else {
+                    heads_done = agent_load_first(my_flag) != 0u;                            // sampled BEFORE the counters: then they are final
+                    // once the tiles that walked last time are through, a part-filled chunk is worth taking: whoever takes it closes it
+                    closing = closing_seen = heads_done || (heavy_blocks != 0u && agent_load(my_heavy_flag) != 0u);
+                    mine = closing || (q % 16u) == group;
+                    if (mine) {
+                        n = agent_load(a.tail.counts + q * kCountStride);
+                        next = agent_load(&ctl->next_chunk[q * kCountStride]);
+                    }
+                }
                 n = n < a.tail.shard_capacity ? n : a.tail.shard_capacity;
-                next = agent_load(&ctl->next_chunk[q * kCountStride]);
-            }
-            const bool open = mine && ((next + 1u) * 64u <= n || (closing && next * 64u < n));
-            unsigned long long m = __ballot(open);
-            m = home == 0u ? m : (m >> home | m << (64u - home));                           // rotate: bit 0 = the wave's own shard
-            if (m != 0ull) {
-                shard = (home + unsigned(__ffsll((long long)m) - 1)) % kShards;
-                n_s = __shfl(n, int(shard), 64);
-                if (lane == 0) chunk = atomicAdd(&ctl->next_chunk[shard * kCountStride], 1u);
-                chunk = __builtin_amdgcn_readfirstlane(chunk);
-                do_chunk = !(heads_done && chunk * 64u >= n_s);                              // (somebody else took the shard's last chunk)
-                if (!do_chunk) continue;
+                const bool open = mine && ((next + 1u) * 64u <= n || (closing && next * 64u < n));
+                unsigned long long m = __ballot(open);
+                m = home == 0u ? m : (m >> home | m << (64u - home));                       // rotate: bit 0 = the wave's own shard
+                if (m != 0ull) {
+                    shard = (home + unsigned(__ffsll((long long)m) - 1)) % kShards;
+                    n_s = __shfl(n, int(shard), 64);
+                    if (lane == 0) chunk = atomicAdd(&ctl->next_chunk[shard * kCountStride], 1u);
+                    chunk = __builtin_amdgcn_readfirstlane(chunk);
+                    do_chunk = !(heads_done && chunk * 64u >= n_s);                          // (somebody else took the shard's last chunk)
+                    break;
+                }
+                if (fresh || (pf_done | pf_hv) == 0u) break;                                 // nothing; or the old look's flags say: look properly
             }
         }
-        if (!do_head && !do_chunk && !head_dry) do_head = claim_head(4u);                    // 3. sky
+        if (!do_head && !do_chunk && sky_pending) {                                          // 3. sky: the claim sent off before the last blocks ran
+            sky_pending = false;
+            const unsigned i = __builtin_amdgcn_readfirstlane(pf_sky_i);
+            const unsigned per_cursor = total_blocks > pf_k ? (total_blocks - pf_k + kCursors - 1u) / kCursors : 0u;
+            if (i < per_cursor) { k = pf_k; first_j = i; count_j = i + 4u <= per_cursor ? 4u : per_cursor - i; last = i + 4u; do_head = true; }
+        }
+        if (!do_head && !do_chunk && !head_dry) do_head = claim_head(4u);                    //    ... or a claim made now
         if (!do_head && !do_chunk) {
             if (heads_done) break;                 // every counter is final and every chunk is claimed: done
             idle++;
@@ -492,6 +529,26 @@ __global__ __launch_bounds__(kTB, VXRT_FUSED_WAVES) void fused_kernel(const Trac
         }
         idle = 0;
         if (do_head) {
+            if (first_j * kCursors + k >= heavy_blocks && !head_dry && !held) {
+                // Blocks of sky: what the wave will want to know when they are done is asked for NOW — the next claim of four and a
+                // look at the chunks — so that the answers travel while the blocks run.  (Every decision of this scheduler is a round
+                // trip through device-scope memory, 2-5 us; made one after the other they cost more than the 20 us of sky between them.)
+                // Never among the walking tiles: a wave that held two of the longest chains would run them one after the other.
+                pf_k = k;
+                pf_sky_i = 0;
+                if (lane == 0) pf_sky_i = atomicAdd(&ctl->cursor[k * kHotStride], 4u);
+                prof_claims++;
+                sky_pending = true;
+                pf_done = agent_load(my_flag);
+                pf_hv = agent_load(my_heavy_flag);
+                pf_mine = closing_seen || (unsigned(lane) % 16u) == group;
+                pf_n = 0; pf_next = 0;
+                if (pf_mine) {
+                    pf_n = agent_load(a.tail.counts + unsigned(lane) * kCountStride);
+                    pf_next = agent_load(&ctl->next_chunk[unsigned(lane) * kCountStride]);
+                }
+                pf = true;
+            }
             for (unsigned j = first_j; j < first_j + count_j; j++) {
                 const unsigned b = j * kCursors + k;
                 // a walking tile's chain is the launch's critical path, and here it shares its SIMD with chunks and blocks of sky
@@ -510,11 +567,16 @@ __global__ __launch_bounds__(kTB, VXRT_FUSED_WAVES) void fused_kernel(const Trac
         __builtin_amdgcn_s_setprio(1);             // a chunk is a chain too: ahead of the blocks of sky, behind the walking tiles
         const unsigned chunk_end = (chunk + 1u) * 64u < a.tail.shard_capacity ? (chunk + 1u) * 64u : a.tail.shard_capacity;
         unsigned limit = chunk_end;
+        if (n_s < chunk_end && sky_pending) {      // (see `held`)
+            held = true; held_shard = shard; held_chunk = chunk; held_ns = n_s;
+            __builtin_amdgcn_s_setprio(0);
+            continue;
+        }
         if (n_s < chunk_end) {
             report_heavy();                        // this wait may depend on the flags: nothing this wave has finished may be missing from them
             report_blocks();
             for (unsigned tries = 0;; tries++) {
-                const bool done_now = agent_load(my_flag) != 0u;                            // before the counter: then it is final
+                const bool done_now = agent_load_first(my_flag) != 0u;                      // sampled before the counter: then it is final
                 const unsigned cnt = agent_load(a.tail.counts + shard * kCountStride);
                 if (cnt >= chunk_end) break;                                                // filled meanwhile
                 if (done_now) { limit = cnt > chunk * 64u ? cnt : chunk * 64u; break; }     // final: what is there is all there will be
