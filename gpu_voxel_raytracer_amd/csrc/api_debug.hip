@@ -182,6 +182,60 @@ int vxrt_debug_culled_pixels(vxrt_ctx* c, uint64_t* count) try {
     return VXRT_OK;
 } VXRT_CATCH
 
+#if VXRT_VARIANTS
+// PROTOTYPE (round 5, csrc/trace_dda.hip): the same rays through the exact walk (cast_probe_kernel) and through the two-level DDA over a
+// caller-built dense bit grid, both timed with HIP events (second of two launches each).  bricks: 8 words per 8^3 brick; brick_bits:
+// one bit per brick; leaf: one word per cell; levels: log2 of the cells (leaf octants) per axis = the tree's depth + 1.  out_*: 8 floats per ray =
+// hit, time, bits(leaf word), normal xyz, flagged, steps.  ms[0] = walk, ms[1] = DDA.
+int vxrt_debug_dda_rays(vxrt_ctx* c, const uint64_t* bricks, const uint32_t* brick_bits, const int32_t* leaf, int32_t levels, const float* origins,
+                        const float* dirs, size_t n, int32_t certify, float margin_scale, float* out_walk, float* out_dda, double ms[2]) try {
+    if (!valid_ctx(c) || !bricks || !brick_bits || !leaf || !origins || !dirs || !out_walk || !out_dda || !ms) { set_error("null argument"); return VXRT_E_INVALID; }
+    if (!c->has_scene) { set_error("no scene set"); return VXRT_E_NOSCENE; }
+    if (levels < 3 || levels > 9 || uint32_t(levels) != c->depth + 1u) { set_error("levels must be the tree's depth + 1 (3..9): the leaf octants per axis are 2 << depth"); return VXRT_E_INVALID; }
+    if (n == 0) return VXRT_OK;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = vxrt_sync(c)) return rc;
+    const size_t cells = size_t(1) << (3 * levels), nbricks = cells >> 9;
+    ScratchBuffer b_o, b_d, b_w, b_x, b_br, b_bb, b_lf;
+    HIP_TRY(b_o.alloc(n * 12)); HIP_TRY(b_d.alloc(n * 12)); HIP_TRY(b_w.alloc(n * 32)); HIP_TRY(b_x.alloc(n * 32));
+    HIP_TRY(b_br.alloc(nbricks * 64)); HIP_TRY(b_bb.alloc((nbricks + 31) / 32 * 4)); HIP_TRY(b_lf.alloc(cells * 4));
+    HIP_TRY(hipMemcpy(b_o.as<float>(), origins, n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b_d.as<float>(), dirs, n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b_br.as<char>(), bricks, nbricks * 64, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b_bb.as<char>(), brick_bits, (nbricks + 31) / 32 * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b_lf.as<char>(), leaf, cells * 4, hipMemcpyHostToDevice));
+    TraceArgs a{};
+    a.svo = c->d_svo; a.leaves = c->d_leaves;
+    a.root_rec = c->root_rec;
+    a.node_levels = int(c->depth) + 1;
+    memcpy(a.root_center, c->root_center, sizeof a.root_center);
+    a.root_size = c->root_size;
+    a.stack_levels = c->depth < 1 ? 1 : int(c->depth);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    float t = 0.0f;
+    for (int rep = 0; rep < 2; rep++) {
+        HIP_TRY(hipEventRecord(e0, c->stream));
+        HIP_TRY(launch_cast_probe(a, false, b_o.as<float>(), b_d.as<float>(), b_w.as<float>(), unsigned(n), c->stream));
+        HIP_TRY(hipEventRecord(e1, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+        ms[0] = double(t);
+        HIP_TRY(hipEventRecord(e0, c->stream));
+        HIP_TRY(launch_dda_probe(a, b_br.as<char>(), b_bb.as<char>(), b_lf.as<char>(), levels, b_o.as<float>(), b_d.as<float>(), b_x.as<float>(), unsigned(n), certify,
+                                 margin_scale, c->stream));
+        HIP_TRY(hipEventRecord(e1, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+        ms[1] = double(t);
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    HIP_TRY(hipMemcpy(out_walk, b_w.as<float>(), n * 32, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_dda, b_x.as<float>(), n * 32, hipMemcpyDeviceToHost));
+    return VXRT_OK;
+} VXRT_CATCH
+#endif
+
 // Diagnostics of the last fused launch of trace stream 0 (VXRT_OPT_FUSED_TAIL; trace.hip: FusedCtl::prof; every 64th wave reports):
 // out[0] ticks of the 100 MHz clock from the first wave's start to the moment every head block was finished, out[1] ... to the last wave's end, out[2] / out[3] chunks taken
 // before / after that moment, out[4] idle sleeps, out[5] polls for a record's stamp, out[6] head claims, out[7] 0.

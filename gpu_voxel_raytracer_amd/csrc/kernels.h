@@ -216,6 +216,8 @@ struct RayQueue {
 // hbm_scene: the kernel compiled for one more wave per SIMD (a scene beyond the Infinity Cache)
 // head and compacted tail of a launch as one grid of `waves` persistent waves (trace.hip: fused_kernel); ctl: fused_ctl_bytes() of zeros
 size_t fused_ctl_bytes();
+hipError_t launch_dda_probe(const TraceArgs& a, const void* bricks, const void* brick_bits, const void* leaf, int levels, const float* origins,
+                            const float* dirs, float* out, unsigned n, int certify, float margin_scale, hipStream_t s);   // trace_dda.hip (variants build)
 size_t fused_ctl_error_offset();
 size_t fused_ctl_profile_offset();
 hipError_t launch_fused(const TraceArgs& a, void* ctl, unsigned waves, const uint32_t* sort_scratch, uint32_t stamp, hipStream_t s);
