@@ -129,7 +129,16 @@ __device__ __forceinline__ void trace_block(const TraceArgs& a, const unsigned b
     // the shard of the tail queue this wave appends to: the top bits of a multiplicative hash of the wave's index, because the waves
     // that append (tiles that see geometry) can sit at regular distances in the launch order (tile_scatter_kernel)
     static_assert(kShards == 64, "6 hash bits");
+#ifndef VXRT_TAIL_SHARD
+#define VXRT_TAIL_SHARD 0   // 1: by tile (all frames of a tile to one shard: chunks of neighbours in space); 2: by tile, hashed.  A/B only (round 5)
+#endif
+#if VXRT_TAIL_SHARD == 1
+    const unsigned tail_shard = ord % kShards;
+#elif VXRT_TAIL_SHARD == 2
+    const unsigned tail_shard = (ord * 0x9E3779B1u) >> 26;
+#else
     const unsigned tail_shard = ((bid * unsigned(kTB / 64) + unsigned(wave)) * 0x9E3779B1u) >> 26;
+#endif
     if (!kFused && a.tail.recs != nullptr) zero_counts(a.tail_zero, tid);
     bool walk = active;
     if (active) {   // the sky cull: a pixel whose primary ray certainly misses needs no walk
