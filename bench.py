@@ -645,16 +645,20 @@ def init_dist(need_gpu=True):
             try:
                 if os.environ.get("VXRT_BENCH_FAIL_NCCL") == "1" or os.environ.get("VXRT_BENCH_FAIL_NCCL_RANK") == str(rank):      # test hooks of the fall-back
                     raise RuntimeError("VXRT_BENCH_FAIL_NCCL=1")
+                if os.environ.get("VXRT_BENCH_FAKE_NCCL_OK_RANK") == str(rank):   # test hook: this rank claims its RCCL came up (a mixed outcome)
+                    raise StopIteration
                 # (no device_id: with it the communicator is made inside init_process_group, and one that fails there — two ranks on
                 # one GPU — leaves a half-made group that nobody can destroy and that warns about it at exit; made by the first
                 # collective instead, it fails inside a registered group, which destroy_process_group below shuts down.  The device is
                 # set above, so the collectives know where they run.)
-                dist.init_process_group("nccl", timeout=datetime.timedelta(seconds=120))
+                dist.init_process_group("nccl", timeout=datetime.timedelta(seconds=float(os.environ.get("VXRT_BENCH_NCCL_TIMEOUT", "120"))))
                 probe = torch.ones(1, device="cuda")
                 dist.all_reduce(probe)
                 torch.cuda.synchronize()
                 if int(probe.item()) != world:
                     raise RuntimeError(f"all_reduce over RCCL returned {probe.item()} for a world of {world}")
+            except StopIteration:
+                pass
             except Exception as e:  # noqa: BLE001
                 err = e
                 print(f"bench.py rank {rank}: RCCL did not come up ({e!r})", file=sys.stderr, flush=True)

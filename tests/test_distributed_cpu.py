@@ -240,6 +240,22 @@ def test_band_layout_folds_the_remainder_into_a_taller_last_round():
     assert L.halo_rows(8, 40) == 40            # a 38-row pan keeps its history on every edge (round 4: capped at 16 rows)
 
 
+def test_bench_ranks_agree_on_the_fall_back_before_anyone_switches():
+    """if RCCL fails on some ranks only, the ones that failed must not wait in a gloo rendezvous while the others sit in an
+    RCCL collective.  Every rank publishes ok / failed on a second TCP store (port chosen by the parent) and reads every rank's word.
+    Here, without a GPU: the default backend cannot come up on any rank -> all agree -> gloo over that same store, and the line says
+    so; with one rank claiming success (test hook) -> every rank sees the mixed outcome -> the job ends with status 3, nothing hangs."""
+    import json
+    out = _bench(["--gpus", "2", "--steps", "20", "--warmup", "5"], {"VXRT_BENCH_DRY": "1"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["rccl"]["backend"] == "gloo" and d["rccl"]["world_size"] == 2
+    assert out.stderr.count("every rank failed to bring RCCL up; falling back to gloo") == 2
+    out = _bench(["--gpus", "3", "--steps", "20", "--warmup", "5"], {"VXRT_BENCH_DRY": "1", "VXRT_BENCH_FAKE_NCCL_OK_RANK": "1", "VXRT_BENCH_NCCL_TIMEOUT": "8"})
+    assert out.returncode == 3, (out.returncode, out.stderr[-2000:])
+    assert out.stderr.count("the ranks disagree about RCCL") == 3 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
 def _bench(args, env):
     import subprocess
     import sys
