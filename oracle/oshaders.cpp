@@ -161,7 +161,7 @@ bool cast_bounded_ray(const Scene& sc, V3 ray_origin, V3 ray_dir, float max_dist
         uint32_t next_octant = octant ^ transition;
         bool has_next = next_time <= exit && transition != 0 && (directional_octant & transition) == 0;
 
-        log_branch(value > 0 ? 1 : (has_next ? 0 : 2));
+        log_branch((uint8_t)((value > 0 ? 1 : (has_next ? 0 : 2)) | (top << 2)));   // bits 2..: the node's level (pushes so far)
         if (value > 0) {
             if (top >= MAX_DEPTH) return false;  // GLSL would write out of bounds; cannot happen for depth <= 15
             stack[top].node = has_next ? node : -1;
@@ -449,7 +449,7 @@ void orc_trace_steps(const int32_t* octree, const float* noise, const OrcUniform
 }
 
 // Diagnostic (tests/sim_schedule.py: branch_coherence): the branch every trip of every ray of a pixel takes, one byte per trip
-// (0 advance, 1 descend, 2 pop, 3 the trip that ends the ray), the pixel's rays one after another: pixel (x, y) writes its
+// (bits 0-1: 0 advance, 1 descend, 2 pop, 3 the trip that ends the ray; bits 2-7: the level of the node the trip is in), the pixel's rays one after another: pixel (x, y) writes its
 // orc_trace_steps total (row[0]) bytes at flat + offsets[pixel].
 void orc_trace_branches(const int32_t* octree, const float* noise, const OrcUniforms* u, int max_bounces, int x0, int y0, int x1, int y1,
                         const int64_t* offsets, uint8_t* flat, int nthreads) {

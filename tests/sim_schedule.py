@@ -346,7 +346,7 @@ def branch_coherence(view="bench", split_round=3, frames=2, w=1920, h=1080, boun
             ln = rays[alive, split_round + r]
             idx = start[:, None] + np.arange(L)[None, :]
             ok = np.arange(L)[None, :] < ln[:, None]
-            seq[:, r, :][ok] = flat[idx[ok]]
+            seq[:, r, :][ok] = flat[idx[ok]] & 3            # (bits 2..: the node's level, see level_profile)
             start = start + ln
         # where and on which face each path is handed over: the origin of its first tail ray (hit + 1e-5 normal) from the oracle's ray log
         ys, xs = np.divmod(alive, w)
@@ -411,3 +411,46 @@ def price_padded(seq_pad, order, nr, L, b_adv, b_desc, b_pop):
     cost = (32.0 * live + b_adv * (s == 0).any(1) + b_desc * (s == 1).any(1) + b_pop * (s == 2).any(1)).sum()
     trips = int(live.sum())
     return cost + live.any(2).sum() * C_SHADE, trips, cost / max(trips, 1)
+
+
+def level_profile(view="bench", w=1920, h=1080, bounces=4):
+    """Round 5: where in the tree do the walk's trips happen?  Per node level (0 = the root) the advance / descend / pop trips of every ray of
+    the bench frame, and what share of the walk's lane-level VALU cost (32 + 3 / 57 / 53 per trip) falls into the bottom two node levels —
+    the part a 4^3 bit-mask brick with a unit-step DDA would replace (HISTORY section 11: the traversal structure is free, only plane times
+    and the descend's position test are contract)."""
+    import ctypes as C
+    pos, mrgb, size = scenes.load_scene("menger")
+    cam = scenes.bench_camera(size) if view == "bench" else scenes.close_camera(size)
+    octree = O.create_octree(pos, mrgb)
+    depth = O.voxel_depth(pos)
+    noise = O.noise_table()
+    u = O.Uniforms.default()
+    u.set_camera(cam[0], O.camera_axis_scaled(cam[0], cam[1], cam[2], w, h))
+    u.frame_number = 1
+    st = np.zeros((h, w, 17), np.int32)
+    O.lib().orc_trace_steps(O._p(octree), O._p(noise), C.byref(u), C.c_int(bounces), C.c_int(0), C.c_int(0), C.c_int(w), C.c_int(h), O._p(st), C.c_int(os.cpu_count()))
+    tot = st[..., 0].reshape(-1).astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(tot)[:-1]]).astype(np.int64)
+    flat = np.zeros(int(tot.sum()) + 16, np.uint8)
+    O.lib().orc_trace_branches(O._p(octree), O._p(noise), C.byref(u), C.c_int(bounces), C.c_int(0), C.c_int(0), C.c_int(w), C.c_int(h), O._p(offs), O._p(flat),
+                               C.c_int(os.cpu_count()))
+    flat = flat[:int(tot.sum())]
+    kind, level = flat & 3, flat >> 2
+    cost = np.array([35.0, 89.0, 85.0, 32.0])
+    total = cost[kind].sum()
+    print(f"view {view}: {len(flat)} lane-trips, tree depth {depth} (node levels 0..{depth}); lane-level cost {total / 1e6:.1f} M VALU")
+    print("level: advance  descend  pop   (share of the cost)")
+    for l in range(depth + 1):
+        m = (level == l) & (kind < 3)
+        if not m.any():
+            continue
+        a, d, p = (int(((kind == k) & m).sum()) for k in (0, 1, 2))
+        print(f"  {l}: {a:9d} {d:9d} {p:9d}   {cost[kind[m]].sum() / total * 100:5.1f} %")
+    bottom = (level >= depth - 1) & (kind < 3)
+    print(f"bottom two node levels ({depth - 1}, {depth}): {cost[kind[bottom]].sum() / total * 100:.1f} % of the cost, {bottom.mean() * 100:.1f} % of the trips; "
+          f"of it descends + pops {cost[kind[bottom & (kind > 0)]].sum() / total * 100:.1f} %")
+    # what a unit-step DDA inside a 4^3 mask would pay for the same stretch: one step per advance trip there (25 VALU), nothing for the
+    # descends and pops inside, one entry per descend INTO level depth-1
+    enters = ((level == depth - 2) & (kind == 1)).sum()
+    dda = ((kind == 0) & bottom).sum() * 25.0 + enters * 60.0
+    print(f"a 4^3-mask DDA for that stretch: {dda / total * 100:.1f} % of today's cost  ->  walk cost x {(total - cost[kind[bottom]].sum() + dda) / total:.3f}")
