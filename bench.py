@@ -526,7 +526,9 @@ def pick_deal(world, steps, inflight=0, batch=0):
     short = steps < 2 * 16 * (inflight if inflight > 0 else (2 if world == 1 else 3))
     if short and world >= 8 and inflight <= 0 and batch <= 0:
         return 4, 1
-    return BAND_ROWS, 0
+    # the steady state from 8 ranks on keeps head + tail and takes the finer interleave too: slowest rank 0.0148 against 0.0151 ms per
+    # frame (emulated, profiles/r05/rank_emulation.txt; 2 and 4 ranks: no difference)
+    return (4 if world >= 8 else BAND_ROWS), 0
 
 
 def free_port():

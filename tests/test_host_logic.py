@@ -158,7 +158,7 @@ def test_bench_schedule_choice():
     assert bench.pick_schedule(8, 1000, inflight=2, batch=4) == (2, 4)   # explicit values are kept
     # a short block from 8 ranks on: 4-row bands and the all-in-one kernel (round 5); everything else the default deal
     assert bench.pick_deal(8, 20) == (4, 1) and bench.pick_deal(4, 20) == (8, 0) and bench.pick_deal(1, 20) == (8, 0)
-    assert bench.pick_deal(8, 1000) == (8, 0) and bench.pick_deal(8, 20, inflight=2, batch=10) == (8, 0)
+    assert bench.pick_deal(8, 1000) == (4, 0) and bench.pick_deal(8, 20, inflight=2, batch=10) == (4, 0) and bench.pick_deal(4, 1000) == (8, 0)
     assert bench.algorithmic_bytes(1920 * 1080, 4, 359016 + 640000) == 48 * 1920 * 1080 + 999016 + 32 * 65536
 
 
