@@ -64,4 +64,14 @@ LazyPool* lazy_pool(uint32_t level, uint32_t clip, const uint8_t mrgb[4], uint32
 LazyTree* lazy_acquire(LazyPool* pool);      // a tree for the calling thread's exclusive use ...
 void lazy_release(LazyPool* pool, LazyTree* tree);   // ... handed back with what it has materialised
 Scene lazy_scene(LazyTree* tree);
+
+// Two of the driver-defined choices as functions, shared by oshaders.cpp and the SPIR-V interpreter (ospirv.cpp):
+// U5: affine inverse of [R U F O; 0 0 0 1] — rows of A^-1 and t = -A^-1 O, as 12 floats (temporal.comp:75-82)
+void affine_inverse(const float* R, const float* U, const float* F, const float* O, float inv[12]);
+// U4: an rgba32f image behind the Linear / ClampToEdge sampler of src/context.rs:980-989
+struct Tex {
+    const float* data; int w, h;
+    void fetch(int x, int y, float* o) const;
+    void sample(float u, float v, float* o) const;
+};
 }  // namespace orc

@@ -407,3 +407,64 @@ def detmath(fn, x, y=None):
     out = np.zeros_like(x)
     lib().orc_detmath(C.c_int(names[fn]), _p(x), _p(y), _p(out), C.c_size_t(x.size))
     return out
+
+
+# ---- the SPIR-V interpreter (ospirv.cpp): the reference's COMPILED shaders, executed instruction by instruction -------------------
+class SpvBinding(C.Structure):
+    _fields_ = [("set", C.c_uint32), ("binding", C.c_uint32), ("kind", C.c_uint32), ("pad", C.c_uint32), ("data", C.c_void_p),
+                ("bytes", C.c_uint64), ("width", C.c_uint32), ("height", C.c_uint32), ("ox", C.c_uint32), ("oy", C.c_uint32),
+                ("cw", C.c_uint32), ("ch", C.c_uint32)]
+
+
+SPV_POISON = 1     # fill every Function variable with a NaN pattern at each function entry (does an output depend on an undefined read?)
+
+
+class SpirvError(RuntimeError):
+    pass
+
+
+def spirv_buffer(binding, array):
+    """A uniform / storage buffer binding over `array` (kept alive by the caller)."""
+    a = np.ascontiguousarray(array)
+    return (binding, 0, a, None)
+
+
+def spirv_image(binding, array, size=None, origin=(0, 0), sampled=False):
+    """A storage (or sampled) rgba32f image: `array` float32[h, w, 4] holds the window at `origin` of an image of `size` = (width, height)
+    (default: the array is the whole image)."""
+    a = np.ascontiguousarray(array, np.float32)
+    assert a.ndim == 3 and a.shape[2] == 4
+    return (binding, 2 if sampled else 1, a, (size or (a.shape[1], a.shape[0]), origin))
+
+
+def spirv_sampler(binding):
+    return (binding, 3, None, None)
+
+
+def spirv_dispatch(module_bytes, bindings, x0, y0, x1, y1, flags=0, nthreads=None):
+    """Runs the GLCompute entry point of a SPIR-V module for the invocation ids [x0, x1) x [y0, y1).  `bindings`: what spirv_buffer /
+    spirv_image / spirv_sampler return (descriptor set 0); images are written in place.  Returns the instructions interpreted."""
+    if len(module_bytes) % 4 or len(module_bytes) < 20:
+        raise SpirvError("not a SPIR-V module (not a whole number of words)")
+    words = np.frombuffer(module_bytes, dtype="<u4")
+    arr = (SpvBinding * len(bindings))()
+    keep = []
+    for k, (binding, kind, a, img) in enumerate(bindings):
+        b = arr[k]
+        b.set, b.binding, b.kind = 0, binding, kind
+        if a is not None:
+            if not a.flags.writeable and kind == 1:
+                raise ValueError("a storage image must be writeable")
+            keep.append(a)
+            b.data, b.bytes = a.ctypes.data, a.nbytes
+        if img is not None:
+            (b.width, b.height), (b.ox, b.oy) = img
+            b.ch, b.cw = a.shape[0], a.shape[1]
+    L = lib()
+    L.orc_spirv_error.restype = C.c_char_p
+    n = C.c_uint64(0)
+    rc = L.orc_spirv_dispatch(_p(words), C.c_size_t(len(words)), arr, C.c_int(len(bindings)), C.c_uint32(x0), C.c_uint32(y0), C.c_uint32(x1),
+                              C.c_uint32(y1), C.c_uint32(flags), C.c_int(nthreads or os.cpu_count() or 1), C.byref(n))
+    if rc != 0:
+        raise SpirvError(L.orc_spirv_error().decode())
+    return n.value

@@ -343,7 +343,7 @@ static void parallel_rows(int y0, int y1, int nthreads, F f) {
 }
 
 // affine inverse of [R U F O; 0 0 0 1] (U5): rows of A^-1 and t = -A^-1 O, as 12 floats.
-static void affine_inverse(const float* R, const float* U, const float* F, const float* O, float inv[12]) {
+void affine_inverse(const float* R, const float* U, const float* F, const float* O, float inv[12]) {
 #if ORC_ALT_BUILTINS
     if (g_alt_mask & 8) {   // U5 the other way: the same adjugate / determinant, every operation in binary32
         float a = R[0], b = U[0], c = F[0], d = R[1], e = U[1], f = F[1], g = R[2], h = U[2], i = F[2];
@@ -369,14 +369,14 @@ static void affine_inverse(const float* R, const float* U, const float* F, const
     }
 }
 
-struct Tex {  // rgba32f image + the Linear/ClampToEdge sampler of src/context.rs:980-989 (U4)
-    const float* data; int w, h;
-    void fetch(int x, int y, float* o) const {
-        x = x < 0 ? 0 : (x >= w ? w - 1 : x);
-        y = y < 0 ? 0 : (y >= h ? h - 1 : y);
-        memcpy(o, data + 4 * ((size_t)y * w + x), 16);
-    }
-    void sample(float u, float v, float* o) const {
+// struct Tex (oracle.h): rgba32f image + the Linear/ClampToEdge sampler of src/context.rs:980-989 (U4)
+void Tex::fetch(int x, int y, float* o) const {
+    x = x < 0 ? 0 : (x >= w ? w - 1 : x);
+    y = y < 0 ? 0 : (y >= h ? h - 1 : y);
+    memcpy(o, data + 4 * ((size_t)y * w + x), 16);
+}
+void Tex::sample(float u, float v, float* o) const {
+    {
         float fx = u * (float)w - 0.5f, fy = v * (float)h - 0.5f;
         float x0 = vx_floor(fx), y0 = vx_floor(fy);
         float ax = vx_floor((fx - x0) * 256.0f + 0.5f) / 256.0f, ay = vx_floor((fy - y0) * 256.0f + 0.5f) / 256.0f;
@@ -396,7 +396,7 @@ struct Tex {  // rgba32f image + the Linear/ClampToEdge sampler of src/context.r
             o[k] = ay == 0.0f ? top : (ay == 1.0f ? bot : (top * (1.0f - ay) + bot * ay));
         }
     }
-};
+}
 
 }  // namespace orc
 

@@ -1,0 +1,157 @@
+"""Test infrastructure: the reference's frame loop (Context::render, src/context.rs:2014-2043) over its COMPILED shaders — the three
+SPIR-V modules it hands to the GPU (shaders/{voxels,temporal,denoise}.comp.spv), executed by oracle/ospirv.cpp — and the cases that
+tests/golden/spirv_exec/ holds their outputs for.  Used by tests/golden/make_spirv_exec_fixture.py (writes the fixtures; needs
+/root/reference), tests/test_oracle_spirv_exec.py (oracle against fixtures; compiled shaders against oracle where the reference is
+mounted) and tests/test_gpu_spirv_goldens.py (the HIP path against the fixtures).  Nothing here is imported by the product."""
+import os
+
+import numpy as np
+
+SHADERS = "/root/reference/shaders"
+MAX_BOUNCES = 3      # `#define MAX_BOUNCES 3` (voxels.comp:4) is compiled into the module
+
+
+def have_shaders():
+    return all(os.path.isfile(os.path.join(SHADERS, f"{n}.comp.spv")) for n in ("voxels", "temporal", "denoise"))
+
+
+def module(name):
+    with open(os.path.join(SHADERS, f"{name}.comp.spv"), "rb") as f:
+        return f.read()
+
+
+def _block(struct, size):
+    """A uniform block's bytes, padded to the size the module's layout may read (std140 rounds a block up to 16)."""
+    raw = np.frombuffer(bytes(struct), np.uint8)
+    return np.concatenate([raw, np.zeros(size - len(raw), np.uint8)])
+
+
+def spirv_trace(O, octree, noise, u, w, h, crop=None, flags=0, nthreads=None):
+    """voxels.comp.spv over crop = (x0, y0, x1, y1) of a w x h frame -> colour, normal/depth, albedo (float32[ch, cw, 4]), instructions."""
+    x0, y0, x1, y1 = crop or (0, 0, w, h)
+    out = [np.zeros((y1 - y0, x1 - x0, 4), np.float32) for _ in range(3)]
+    b = [O.spirv_image(k, out[k], (w, h), (x0, y0)) for k in range(3)]                     # bindings 0-2: voxels.comp:17-25
+    b += [O.spirv_buffer(3, _block(u, 160)), O.spirv_buffer(4, np.zeros(64, np.uint8)),      # uniforms, old_uniforms (unused by main)
+          O.spirv_buffer(5, octree), O.spirv_buffer(6, noise)]                              # octree_data, randomness
+    n = O.spirv_dispatch(module("voxels"), b, x0, y0, x1, y1, flags=flags, nthreads=nthreads)
+    return out[0], out[1], out[2], n
+
+
+def spirv_temporal(O, color, nd, old_color, old_nd, cam16, old_cam16, tu, flags=0):
+    """temporal.comp.spv over a whole frame -> the accumulated colour (rgb + blending)."""
+    h, w = color.shape[:2]
+    out = np.zeros((h, w, 4), np.float32)
+    b = [O.spirv_sampler(0), O.spirv_image(1, old_color, sampled=True), O.spirv_image(2, np.array(color)), O.spirv_image(3, out),
+         O.spirv_image(4, old_nd, sampled=True), O.spirv_image(5, np.array(nd)), O.spirv_buffer(6, _block(tu, 16)),
+         O.spirv_buffer(7, np.array(cam16, np.float32)), O.spirv_buffer(8, np.array(old_cam16, np.float32))]
+    O.spirv_dispatch(module("temporal"), b, 0, 0, w, h, flags=flags)
+    return out
+
+
+def spirv_denoise(O, colors, nd, albedo, cam16, du, flags=0):
+    """denoise.comp.spv over a whole frame."""
+    h, w = colors.shape[:2]
+    out = np.zeros((h, w, 4), np.float32)
+    b = [O.spirv_image(0, out), O.spirv_image(1, np.array(colors)), O.spirv_image(2, np.array(nd)), O.spirv_image(3, np.array(albedo)),
+         O.spirv_buffer(4, np.array(cam16, np.float32)), O.spirv_buffer(5, _block(du, 16))]
+    O.spirv_dispatch(module("denoise"), b, 0, 0, w, h, flags=flags)
+    return out
+
+
+class Pipeline:
+    """Frame sequencing of Context::render / update_bindings (frame_number first; the old camera and the history are the previous frame's)
+    over either set of kernels: `compiled=True` the reference's SPIR-V modules, False the oracle's restatement."""
+
+    def __init__(self, O, octree, noise, w, h, radius, compiled, specularity=0.0, sun_strength=None, emit_strength=None):
+        self.O, self.w, self.h, self.compiled = O, w, h, compiled
+        self.octree, self.noise = octree, noise
+        self.u = O.Uniforms.default()
+        self.u.specularity = specularity
+        if sun_strength is not None:
+            self.u.sun_strength = sun_strength
+        if emit_strength is not None:
+            self.u.emit_strength = emit_strength
+        self.du = O.Denoise.default()
+        self.du.radius = radius
+        self.tu = O.Temporal.default()
+        self.old_c = np.zeros((h, w, 4), np.float32)
+        self.old_nd = np.zeros((h, w, 4), np.float32)
+        self.old_cam16 = np.zeros(16, np.float32)
+        self.frame = 0
+
+    def render(self, cam):
+        O, w, h = self.O, self.w, self.h
+        self.frame += 1
+        self.u.frame_number = self.frame
+        self.u.set_camera(cam[0], O.camera_axis_scaled(cam[0], cam[1], cam[2], w, h))
+        cam16 = self.u.camera16()
+        if self.compiled:
+            color, nd, alb, _ = spirv_trace(O, self.octree, self.noise, self.u, w, h)
+            accum = spirv_temporal(O, color, nd, self.old_c, self.old_nd, cam16, self.old_cam16, self.tu)   # frame 1: all-zero history and old camera (U3)
+            den = spirv_denoise(O, accum, nd, alb, cam16, self.du)
+        else:
+            color, nd, alb, _ = O.trace(self.octree, self.noise, self.u, w, h, MAX_BOUNCES, crop=(0, 0, w, h))
+            accum = O.temporal(color, nd, self.old_c, self.old_nd, cam16, self.old_cam16, self.tu, self.frame > 1)
+            den = O.denoise(accum, nd, alb, cam16, self.du)
+        self.old_c, self.old_nd, self.old_cam16 = accum, nd, cam16
+        return color, nd, alb, accum, den
+
+
+def cap_scene():
+    """A row of 4 096 voxels along x: rays beside it reach the 2 048-trip cap (tests/test_gpu_trace.py: cap_scene)."""
+    n = 4096
+    pos = np.zeros((n, 3), np.int16)
+    pos[:, 0] = np.arange(n)
+    return pos, np.tile(np.array([[0, 200, 100, 50]], np.uint8), (n, 1))
+
+
+def _f32(*v):
+    return np.array(v, np.float32)
+
+
+def cases(scenes):
+    """name -> dict(scene, w, h, radius, frames: [(position, direction, fov)], uniforms overrides): the sequences the fixtures hold."""
+    out = {}
+
+    def close(name):
+        _, _, size = scenes.load_scene(name)
+        return scenes.close_camera(size)
+
+    p, d, fov = close("castle")
+    out["castle_moving_r2"] = dict(scene="castle", w=96, h=64, radius=2, frames=[
+        (p + np.float32(0.05 * f) * _f32(1, 0.2, 0.1), d + np.float32(0.015 * f) * _f32(0, 1, 0), fov) for f in range(3)])
+    p, d, fov = close("menger")
+    out["menger_static_r8"] = dict(scene="menger", w=80, h=48, radius=8, frames=[(p, d, fov)] * 2)
+    p, d, fov = close("monu10")
+    out["monu10_specular_r1"] = dict(scene="monu10", w=80, h=48, radius=1, frames=[(p, d, fov)] * 2, specularity=0.4)
+    p, d, fov = close("room")
+    out["room_sun_off_r0"] = dict(scene="room", w=80, h=48, radius=0, frames=[(p, d, fov)] * 2, sun_strength=0.0, emit_strength=3.0)
+    # an axis-aligned camera on integer coordinates sends its centre rays exactly along +z through node mid-planes: (center - origin) *
+    # (1 / 0) = 0 * inf = NaN (voxels.comp:140,191) goes through the compiled code as it does through the oracle, NaN outputs included
+    out["zero_times_inf_r0"] = dict(scene="8x8x8", w=64, h=64, radius=0, frames=[(_f32(1, 1, -5), _f32(0, 0, 1), 1.0)])
+    # the 2 048-trip cap (voxels.comp:166-169) returns true with `normal` unwritten (U1): the module then reads memory this interpreter
+    # zeroed at the invocation's start, which is the oracle's definition (normal = 0)
+    out["cap_row_r0"] = dict(scene="cap", w=96, h=64, radius=0, frames=[(_f32(-1, 0.6, 0.25), _f32(1, 0, 0), 0.01)])
+    return out
+
+
+def build_case(O, scenes, noise, spec, compiled):
+    if spec["scene"] == "cap":
+        pos, mrgb = cap_scene()
+    else:
+        pos, mrgb, _ = scenes.load_scene(spec["scene"])
+    pipe = Pipeline(O, O.create_octree(pos, mrgb), noise, spec["w"], spec["h"], spec["radius"], compiled,
+                    specularity=spec.get("specularity", 0.0), sun_strength=spec.get("sun_strength"), emit_strength=spec.get("emit_strength"))
+    return pipe, (pos, mrgb)
+
+
+def run_case(O, scenes, noise, spec, compiled):
+    """{key: image}: frame 1's three trace outputs, every frame's accumulated and denoised colour."""
+    pipe, _ = build_case(O, scenes, noise, spec, compiled)
+    out = {}
+    for f, cam in enumerate(spec["frames"], 1):
+        color, nd, alb, accum, den = pipe.render(cam)
+        if f == 1:
+            out["f1_color"], out["f1_nd"], out["f1_albedo"] = color, nd, alb
+        out[f"f{f}_accum"], out[f"f{f}_denoised"] = accum, den
+    return out

@@ -1,0 +1,47 @@
+"""GPU parity against OUTPUTS OF THE REFERENCE'S COMPILED SHADERS: tests/golden/spirv_exec/*.npz hold what
+shaders/{voxels,temporal,denoise}.comp.spv — the modules the reference hands to its GPU — produce for six short frame sequences
+when executed instruction by instruction (oracle/ospirv.cpp; made by tests/golden/make_spirv_exec_fixture.py where the reference is
+mounted; driver-defined operations bound to the documented choices U1-U8).  The HIP path, through the C ABI, must give the same
+images: moving camera with a denoise window, the 17 x 17 window, specular and sun-off shading, 0 * inf rays, the 2 048-trip cap."""
+import os
+
+import numpy as np
+import pytest
+
+import spirv_pipeline as SP
+from conftest import GOLDEN, assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+FIXTURES = os.path.join(GOLDEN, "spirv_exec")
+CASES = sorted(f[:-4] for f in os.listdir(FIXTURES) if f.endswith(".npz"))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_hip_frames_equal_the_compiled_shaders_frames(H, scenes, noise, name):
+    from gpu_voxel_raytracer_amd import ALL, Camera, Context
+    z = np.load(os.path.join(FIXTURES, name + ".npz"))
+    w, h = int(z["w"]), int(z["h"])
+    pos, mrgb = SP.cap_scene() if str(z["scene"]) == "cap" else scenes.load_scene(str(z["scene"]))[:2]
+    with Context(w, h, max_bounces=int(z["max_bounces"]), noise=noise) as ctx:
+        ctx.recreate_octree(pos, mrgb)
+        ctx.uniforms.specularity = float(z["specularity"])
+        ctx.uniforms.sun_strength = float(z["sun_strength"])
+        ctx.uniforms.emit_strength = float(z["emit_strength"])
+        ctx.denoise_uniforms.radius = int(z["radius"])
+        for f in range(1, len(z["fov"]) + 1):
+            ctx.camera = Camera(z["cam_pos"][f - 1], z["cam_dir"][f - 1], float(z["fov"][f - 1]))
+            ctx.render(ALL)
+            if f == 1:
+                for img, key in ((0, "f1_color"), (1, "f1_nd"), (2, "f1_albedo")):
+                    assert_bits_equal(ctx.read(img), z[key], f"{name} {key}")
+            assert_bits_equal(ctx.read(3), z[f"f{f}_accum"], f"{name} accumulated colour of frame {f}")
+            assert_bits_equal(ctx.read(4), z[f"f{f}_denoised"], f"{name} denoised colour of frame {f}")
+        assert ctx.stats().frames == len(z["fov"])
+
+
+def test_the_product_needs_no_interpreter(H):
+    """The fixtures are data: nothing of oracle/ospirv.cpp is linked into or loaded by the product library."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", H._build.LIB], capture_output=True, text=True).stdout
+    assert "orc_spirv" not in out and "orc_" not in out
