@@ -1,9 +1,12 @@
 // ORACLE — test infrastructure only.  Nothing in the product path may include, link or call this.
 //
 // CPU restatement of the hot path of nolanderc/gpu-voxel-raytracer (scene prep + the three compute
-// shaders + the dead src/cpu.rs ray caster).  Parity status: UNPINNED — the reference ships no
-// tests, golden vectors or runnable build for this path; the restatement is pinned
-// by review, by the Appendix-C node-count table and by an independent dense-grid DDA (odda.cpp).
+// shaders + the dead src/cpu.rs ray caster).  Parity status: the three SHADERS are pinned by the
+// reference's own compiled modules, executed by ospirv.cpp (tests/test_oracle_spirv_exec.py), up to the
+// operations SPIR-V leaves to a driver (oshaders.cpp: U1-U8); the HOST-SIDE restatements (parser, octree
+// builder, camera, src/cpu.rs) stay UNPINNED by any reference output — it ships no tests or golden vectors
+// and cannot be built here — and are held by review, the Appendix-C node-count table,
+// sha256 known answers and an independent dense-grid DDA (odda.cpp).
 #pragma once
 #include <cstddef>
 #include <cstdint>

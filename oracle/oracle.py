@@ -2,7 +2,9 @@
 
 ctypes front end of oracle/_build/liboracle.so, the CPU restatement of the reference's hot path
 (see oracle.h).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
-this module; the product package never does.  Parity status: UNPINNED by the reference.
+this module; the product package never does.  Parity status: the shaders' restatement is pinned by the reference's
+compiled modules executed by ospirv.cpp (spirv_dispatch below; tests/test_oracle_spirv_exec.py), up to driver-defined operations;
+the host-side functions are unpinned by any reference output.
 """
 import ctypes as C
 import os

@@ -6,8 +6,13 @@
 //   * shaders/temporal.comp — reprojection + exponential blending           (orc_temporal)
 //   * shaders/denoise.comp  — (2r+1)^2 cross-bilateral filter               (orc_denoise)
 // Statement by statement, in the shaders' operation order, on the numeric contract of
-// include/vxrt_detmath.h.  Parity status: UNPINNED by the reference (no tests, cannot be executed
-// here: no Rust, no Vulkan, no glslang — SURVEY.md §8c).
+// include/vxrt_detmath.h.  Parity status: PINNED BY THE REFERENCE'S COMPILED SHADERS, up to the driver-defined operations
+// listed below.  The reference ships no tests or golden images and its host cannot be built here (no Rust, no Vulkan — SURVEY.md
+// §8c), but it does ship the three shaders compiled (shaders/*.comp.spv, what it hands to the GPU): ospirv.cpp executes those
+// modules instruction by instruction with U2-U8 bound to the functions below, and this restatement gives the same bits on every
+// scene file, a moving camera, every denoise radius, NaN / inf G-buffers, 0 * inf rays and the trip cap
+// (tests/test_oracle_spirv_exec.py; outputs of the modules as fixtures: tests/golden/spirv_exec/).  What stays open is what
+// SPIR-V itself leaves to a driver — U1-U8 — whose width tests/test_oracle_builtin_sensitivity.py measures.
 //
 // Places where GLSL leaves behaviour undefined and this restatement picks one:
 //   U1  cast_bounded_ray's iteration cap returns true without writing `normal`

@@ -14,9 +14,9 @@ What it writes and where each comes from:
                        reproduce SURVEY.md Appendix C (computed there by an unrelated throw-away parser).
   config1_3x3x3_256.npz  the restated src/cpu.rs image (u8) + primary-hit colours for BASELINE config 1.
   frames_<scene>.npz   small full-pipeline frames rendered BY THE ORACLE (trace -> temporal -> denoise
-                       for frames 1..N): self-goldens that pin the oracle against silent change.  The
-                       reference ships no golden images and cannot be executed here (no Rust / Vulkan /
-                       glslang), so nothing stronger exists: parity is UNPINNED by the reference.
+                       for frames 1..N): self-goldens that pin the oracle against silent change.  (The
+                       fixtures that come from the reference itself — its compiled shaders, executed —
+                       are tests/golden/spirv_exec/, written by make_spirv_exec_fixture.py.)
 """
 import hashlib
 import json

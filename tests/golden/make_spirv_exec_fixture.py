@@ -29,7 +29,7 @@ OUT = os.path.join(HERE, "spirv_exec")
 
 def make(name, spec, noise):
     images = SP.run_case(O, scenes, noise, spec, compiled=True)
-    meta = {"scene": spec["scene"], "w": spec["w"], "h": spec["h"], "radius": spec["radius"], "max_bounces": SP.MAX_BOUNCES,
+    meta = {"scene": spec["scene"], "w": spec["w"], "h": spec["h"], "radius": spec["radius"], "max_bounces": spec.get("bounces", SP.MAX_BOUNCES),
             "specularity": np.float32(spec.get("specularity", 0.0)),
             "sun_strength": np.float32(spec.get("sun_strength", O.Uniforms.default().sun_strength)),
             "emit_strength": np.float32(spec.get("emit_strength", O.Uniforms.default().emit_strength)),
@@ -47,6 +47,26 @@ def main():
         data = make(name, spec, noise)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **data)
         print(name, {k: v.shape for k, v in data.items() if isinstance(v, np.ndarray) and v.ndim == 3}, os.path.getsize(os.path.join(OUT, name + ".npz")) // 1024, "KB")
+    if "--no-full-size" not in sys.argv:
+        full_size(noise)
+
+
+def full_size(noise):
+    """full_size.json: sha256 per slab of rows of what the compiled voxels.comp gives for BASELINE's whole frames (minutes of CPU)."""
+    import json
+    import time
+    cases = []
+    for case in SP.FULL_SIZE:
+        t = time.time()
+        n = (case["h"] + SP.SLAB_ROWS - 1) // SP.SLAB_ROWS
+        hashes = SP.full_size_slab_hashes(O, scenes, noise, case, range(n), compiled=True)
+        cases.append({**case, "frame_number": 1, "slab_rows": SP.SLAB_ROWS,
+                      "sha256": {k: [hashes[s][k] for s in range(n)] for k in ("color", "nd", "albedo")}})
+        print(case["name"], n, "slabs", f"{time.time() - t:.0f} s", flush=True)
+    with open(os.path.join(OUT, "full_size.json"), "w") as f:
+        json.dump({"what": "sha256 (NaN and -0 canonical; the albedo image's leaf word as it is) of each slab of rows of the three images "
+                           "shaders/voxels.comp.spv produces, executed by oracle/ospirv.cpp with its loop bound set to the config's bounce count",
+                   "cases": cases}, f, indent=1)
 
 
 if __name__ == "__main__":

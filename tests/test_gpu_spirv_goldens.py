@@ -40,6 +40,30 @@ def test_hip_frames_equal_the_compiled_shaders_frames(H, scenes, noise, name):
         assert ctx.stats().frames == len(z["fov"])
 
 
+def test_hip_full_size_frames_hash_to_the_compiled_shaders_known_answers(H, scenes, noise):
+    """BASELINE's frames at their full sizes — configs[1] (menger 1920 x 1080, 4 bounces: the frame bench.py times) and the frames of
+    configs 3 and 4 (monu10 / castle, 3840 x 2160, 8 bounces): the HIP trace stage's three images, hashed slab by slab, equal what the
+    reference's compiled voxels.comp gave (tests/golden/spirv_exec/full_size.json)."""
+    import json
+    from gpu_voxel_raytracer_amd import TRACE, Camera, Context
+    with open(os.path.join(FIXTURES, "full_size.json")) as f:
+        cases = json.load(f)["cases"]
+    assert len(cases) == 3
+    for c in cases:
+        pos, mrgb, size = scenes.load_scene(c["scene"])
+        cam = scenes.bench_camera(size) if c["view"] == "bench" else scenes.close_camera(size)
+        with Context(c["w"], c["h"], max_bounces=c["bounces"], noise=noise) as ctx:
+            ctx.recreate_octree(pos, mrgb)
+            ctx.camera = Camera(*cam)
+            ctx.render(TRACE)
+            images = {"color": ctx.read(0), "nd": ctx.read(1), "albedo": ctx.read(2)}
+        rows = c["slab_rows"]
+        for k, img in images.items():
+            for s, want in enumerate(c["sha256"][k]):
+                got = SP.canonical_sha256(img[s * rows:(s + 1) * rows], node_channel=(k == "albedo"))
+                assert got == want, f"{c['name']}: rows {s * rows}-{(s + 1) * rows} of the {k} image"
+
+
 def test_the_product_needs_no_interpreter(H):
     """The fixtures are data: nothing of oracle/ospirv.cpp is linked into or loaded by the product library."""
     import subprocess

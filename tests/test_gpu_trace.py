@@ -320,7 +320,8 @@ CAP_RAYS_D = np.array([[1, 0, 0], [1, 1e-5, 1e-5], [1, 1e-4, -2e-5], [1, 0, 1e-6
                                  {"VXRT_TRACE_VARIANT": "5"}, {"VXRT_WIDE": "1"}])
 def test_iteration_cap(O, H, noise, monkeypatch, env):
     """voxels.comp:163-169: the 2 048th trip of the loop returns TRUE with out_node = LEAF_BIT, the time the walk is at, and
-    the normal unwritten (defined as 0 here and in the oracle, U1 — the shader leaves it undefined: parity unpinned).
+    the normal unwritten (defined as 0 here and in the oracle, U1 — the shader leaves it undefined; the compiled module executed over
+    zeroed memory gives the same 0: tests/test_oracle_spirv_exec.py::test_undefined_reads_matter_only_at_the_trip_cap).
     Probe rays (both walks: regular rays -> walkf_step, a zero direction component -> walk_step) and a rendered frame in
     which hundreds of primary rays are capped and their paths go on from the capped "hit" — for every tracer variant."""
     from gpu_voxel_raytracer_amd import Camera, Context

@@ -27,7 +27,8 @@ The finding (thresholds below are set from what was measured, with head room):
    met between ANY two implementations that differ in one rounding, the reference's own GPU driver and its own CPU included.  Bit-exact
    against one fully specified restatement is the only checkable contract, which is what tests/ hold the kernels to; what it cannot
    say — which of the conforming images the reference's driver would have produced — is bounded by these numbers.
-Parity status: unpinned by the reference (no output of it exists); this test measures the width of that gap, it does not close it."""
+What this measures is the part of the contract that NO output of the reference could pin: tests/test_oracle_spirv_exec.py holds the oracle to
+the reference's compiled shaders for everything SPIR-V defines; the built-ins varied here are what SPIR-V leaves to a driver."""
 import json
 import os
 import sys

@@ -1,8 +1,8 @@
 """CPU: the oracle reproduces its committed frames (tests/golden/frames_*.npz) bit for bit.
 
 These are SELF-goldens (made by tests/golden/make_fixtures.py with the oracle): they pin the oracle
-against silent change, they do not pin it to the reference, which ships no images and cannot be run
-here — parity with the reference itself stays UNPINNED."""
+against silent change, they do not pin it to the reference, which ships no images.  What does pin it to the reference:
+tests/test_oracle_spirv_exec.py — the reference's compiled shaders, executed — and tests/golden/spirv_exec/."""
 import os
 
 import numpy as np

@@ -9,8 +9,8 @@ one operation, type conversions, pow(x, 2) -> x * x which is choice U2 of DESIGN
 
 What this pins: constants, operation order, select order, which built-in sits where.  What it cannot pin: the value any built-in
 returns (exp, log, pow, sin, cos, normalize, inverse(): driver-defined — U5/U6), the sampler (U4), undefined behaviour (U1, U3, U7).
-No reference OUTPUT exists, so parity stays "unpinned" in the sense of DESIGN.md section 2; this replaces "a human read the .comp text"
-by a checked statement about the compiled code."""
+This is the static half; tests/test_oracle_spirv_exec.py is the dynamic one — it EXECUTES the same modules (oracle/ospirv.cpp) and holds
+the oracle to their outputs bit for bit."""
 import ast
 import json
 import os
