@@ -63,10 +63,17 @@ def full_size(noise):
         cases.append({**case, "frame_number": 1, "slab_rows": SP.SLAB_ROWS,
                       "sha256": {k: [hashes[s][k] for s in range(n)] for k in ("color", "nd", "albedo")}})
         print(case["name"], n, "slabs", f"{time.time() - t:.0f} s", flush=True)
+    t = time.time()
+    loop = SP.pipeline_hashes(O, scenes, noise, compiled=True, log=lambda m: print(SP.PIPELINE_CASE["name"], m, f"{time.time() - t:.0f} s", flush=True))
+    print(SP.PIPELINE_CASE["name"], f"{time.time() - t:.0f} s", flush=True)
     with open(os.path.join(OUT, "full_size.json"), "w") as f:
         json.dump({"what": "sha256 (NaN and -0 canonical; the albedo image's leaf word as it is) of each slab of rows of the three images "
                            "shaders/voxels.comp.spv produces, executed by oracle/ospirv.cpp with its loop bound set to the config's bounce count",
-                   "cases": cases}, f, indent=1)
+                   "cases": cases,
+                   "frame_loop": {**SP.PIPELINE_CASE, "slab_rows": SP.SLAB_ROWS, "r8_rows": list(SP.R8_ROWS), "frames": 2, "radius": 2,
+                                  "what": "two frames of a camera at rest through voxels / temporal / denoise .comp.spv: accumulated colour of both frames, "
+                                          "frame 2 denoised with radius 2 (whole frame) and with radius 8 (rows r8_rows)",
+                                  "sha256": loop}}, f, indent=1)
 
 
 if __name__ == "__main__":

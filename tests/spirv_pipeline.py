@@ -244,3 +244,47 @@ def full_size_slab_hashes(O, scenes, noise, case, slabs, compiled):
             color, nd, alb, _ = O.trace(octree, noise, u, case["w"], case["h"], case["bounces"], crop=crop)
         out[s] = {"color": canonical_sha256(color), "nd": canonical_sha256(nd), "albedo": canonical_sha256(alb, node_channel=True)}
     return out
+
+
+# Config 3's frame loop at its full size (monu10, 3840 x 2160, 8 bounces; camera at rest, one sample per frame): two frames through all
+# three compiled modules — frame 2's temporal stage blends frame 1's history — hashed like the trace images above: the accumulated
+# colour of both frames, frame 2 denoised with the 5 x 5 window (whole frame) and with the 17 x 17 window (rows R8_ROWS only: the
+# interpreter needs ~45 000 instructions per pixel there).
+PIPELINE_CASE = dict(name="config3_monu10_4k_8_bounces_frame_loop", scene="monu10", view="close", w=3840, h=2160, bounces=8)
+R8_ROWS = (1040, 1080)
+
+
+def slab_hashes(img, rows=SLAB_ROWS):
+    return [canonical_sha256(img[s:s + rows]) for s in range(0, img.shape[0], rows)]
+
+
+def spirv_denoise_rows(O, colors, nd, albedo, cam16, du, y0, y1):
+    """denoise.comp.spv for the rows [y0, y1) of a frame whose inputs are bound whole."""
+    h, w = colors.shape[:2]
+    out = np.zeros((y1 - y0, w, 4), np.float32)
+    b = [O.spirv_image(0, out, (w, h), (0, y0)), O.spirv_image(1, np.array(colors)), O.spirv_image(2, np.array(nd)), O.spirv_image(3, np.array(albedo)),
+         O.spirv_buffer(4, np.array(cam16, np.float32)), O.spirv_buffer(5, _block(du, 16))]
+    O.spirv_dispatch(module("denoise"), b, 0, y0, w, y1)
+    return out
+
+
+def pipeline_hashes(O, scenes, noise, compiled, case=PIPELINE_CASE, log=None):
+    """{"f1_accum", "f2_accum", "f2_denoised_r2": [sha256 per slab], "f2_denoised_r8_rows": sha256 of rows R8_ROWS}"""
+    pos, mrgb, cam, u = full_size_uniforms(O, scenes, case)
+    pipe = Pipeline(O, O.create_octree(pos, mrgb), noise, case["w"], case["h"], 2, compiled, bounces=case["bounces"])
+    out = {}
+    for f in (1, 2):
+        color, nd, alb, accum, den = pipe.render(cam)
+        out[f"f{f}_accum"] = slab_hashes(accum)
+        if log:
+            log(f"frame {f} done")
+    out["f2_denoised_r2"] = slab_hashes(den)
+    du = O.Denoise.default()
+    du.radius = 8
+    cam16 = pipe.u.camera16()
+    if compiled:
+        rows = spirv_denoise_rows(O, accum, nd, alb, cam16, du, *R8_ROWS)
+    else:
+        rows = O.denoise(accum, nd, alb, cam16, du)[R8_ROWS[0]:R8_ROWS[1]]
+    out["f2_denoised_r8_rows"] = canonical_sha256(rows)
+    return out

@@ -64,6 +64,31 @@ def test_hip_full_size_frames_hash_to_the_compiled_shaders_known_answers(H, scen
                 assert got == want, f"{c['name']}: rows {s * rows}-{(s + 1) * rows} of the {k} image"
 
 
+def test_hip_frame_loop_at_config3_size_hashes_to_the_compiled_shaders_known_answers(H, scenes, noise):
+    """Config 3's frame loop at its size (monu10, 3840 x 2160, 8 bounces, camera at rest): two frames through all three stages — the
+    accumulated colour of both frames and frame 2 denoised with the 5 x 5 window hash, slab by slab, to what the reference's three compiled
+    modules gave; so does the strip of frame 2 denoised again with the 17 x 17 window."""
+    import json
+    from gpu_voxel_raytracer_amd import ALL, DENOISE, Camera, Context
+    with open(os.path.join(FIXTURES, "full_size.json")) as f:
+        z = json.load(f)["frame_loop"]
+    pos, mrgb, size = scenes.load_scene(z["scene"])
+    cam = scenes.close_camera(size)
+    with Context(z["w"], z["h"], max_bounces=z["bounces"], noise=noise) as ctx:
+        ctx.recreate_octree(pos, mrgb)
+        ctx.camera = Camera(*cam)
+        ctx.denoise_uniforms.radius = z["radius"]
+        for f in (1, 2):
+            ctx.render(ALL)
+            assert SP.slab_hashes(ctx.read(3), z["slab_rows"]) == z["sha256"][f"f{f}_accum"], f"accumulated colour of frame {f}"
+        assert SP.slab_hashes(ctx.read(4), z["slab_rows"]) == z["sha256"]["f2_denoised_r2"]
+        ctx.denoise_uniforms.radius = 8
+        ctx.update_bindings()
+        ctx.render_stage(DENOISE)
+        y0, y1 = z["r8_rows"]
+        assert SP.canonical_sha256(ctx.read(4)[y0:y1]) == z["sha256"]["f2_denoised_r8_rows"]
+
+
 def test_the_product_needs_no_interpreter(H):
     """The fixtures are data: nothing of oracle/ospirv.cpp is linked into or loaded by the product library."""
     import subprocess

@@ -5,7 +5,7 @@ oracle/ospirv.cpp interprets them instruction by instruction (control flow, memo
 module's order); what SPIR-V leaves to the driver — exp / log / pow / sin / cos / sqrt / normalize, the sampler, inverse(mat4), float ->
 int conversion out of range, the association of dot products — is bound to the documented choices U2-U8 (that file's header).
 
-  * tests/golden/spirv_exec/*.npz hold what the compiled shaders produce for six short frame sequences (made by
+  * tests/golden/spirv_exec/ holds what the compiled shaders produce — eight short frame sequences as images, BASELINE's whole frames as hashes (made by
     tests/golden/make_spirv_exec_fixture.py in the container where /root/reference is mounted): the ORACLE must reproduce every image
     bit for bit — here and on the GPU box, where tests/test_gpu_spirv_goldens.py holds the HIP path to the same files;
   * where the reference is mounted, the fixtures are regenerated from its modules and must equal the committed files, and the oracle
@@ -345,3 +345,45 @@ def test_full_size_known_answers_are_what_the_module_gives(O, scenes, noise):
         for s in slabs:
             for k in ("color", "nd", "albedo"):
                 assert fresh[s][k] == c["sha256"][k][s], (c["name"], s, k)
+
+
+def _frame_loop():
+    import json
+    with open(os.path.join(FIXTURES, "full_size.json")) as f:
+        return json.load(f)["frame_loop"]
+
+
+def test_oracle_reproduces_the_full_size_frame_loop(O, scenes, noise):
+    """Config 3's frame loop at its size (monu10, 3840 x 2160, 8 bounces): two frames through trace, temporal and denoise — frame 2 blends
+    frame 1's history — hash to what the reference's three compiled modules gave: accumulated colour of both frames, frame 2 denoised with
+    the 5 x 5 window (whole frame) and the 17 x 17 window (a strip of rows)."""
+    z = _frame_loop()
+    assert z["name"] == SP.PIPELINE_CASE["name"] and tuple(z["r8_rows"]) == SP.R8_ROWS and z["slab_rows"] == SP.SLAB_ROWS
+    got = SP.pipeline_hashes(O, scenes, noise, compiled=False)
+    assert sorted(got) == sorted(z["sha256"])
+    for k, want in z["sha256"].items():
+        assert got[k] == want, k
+
+
+@needs_reference
+def test_full_size_frame_loop_hashes_are_what_the_modules_give(O, scenes, noise):
+    """Provenance of the frame-loop hashes.  The trace stage's whole frames are covered by the per-slab hashes above; here the temporal
+    and denoise MODULES run on frame 2's inputs (the oracle's images, which those hashes say are the modules' own): temporal over the
+    whole frame, denoise with radius 2 on two slabs and with radius 8 on its strip."""
+    z = _frame_loop()
+    pos, mrgb, cam, _ = SP.full_size_uniforms(O, scenes, SP.PIPELINE_CASE)
+    pipe = SP.Pipeline(O, O.create_octree(pos, mrgb), noise, z["w"], z["h"], 2, compiled=False, bounces=z["bounces"])
+    _, nd1, _, acc1, _ = pipe.render(cam)
+    old_cam16 = pipe.old_cam16.copy()
+    color, nd, alb, acc2, _ = pipe.render(cam)
+    cam16 = pipe.u.camera16()
+    assert SP.slab_hashes(acc2) == z["sha256"]["f2_accum"]
+    fresh = SP.spirv_temporal(O, color, nd, acc1, nd1, cam16, old_cam16, pipe.tu)
+    assert SP.slab_hashes(fresh) == z["sha256"]["f2_accum"]
+    du = O.Denoise.default()
+    du.radius = 2
+    for s in (8, 15):
+        rows = SP.spirv_denoise_rows(O, acc2, nd, alb, cam16, du, s * SP.SLAB_ROWS, (s + 1) * SP.SLAB_ROWS)
+        assert SP.canonical_sha256(rows) == z["sha256"]["f2_denoised_r2"][s], s
+    du.radius = 8
+    assert SP.canonical_sha256(SP.spirv_denoise_rows(O, acc2, nd, alb, cam16, du, *SP.R8_ROWS)) == z["sha256"]["f2_denoised_r8_rows"]
