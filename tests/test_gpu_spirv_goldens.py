@@ -89,6 +89,53 @@ def test_hip_frame_loop_at_config3_size_hashes_to_the_compiled_shaders_known_ans
         assert SP.canonical_sha256(ctx.read(4)[y0:y1]) == z["sha256"]["f2_denoised_r8_rows"]
 
 
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_banded_contexts_with_a_halo_equal_the_compiled_shaders_frames(H, scenes, noise, nranks):
+    """Row (e) against the same reference-made frames: the moving-camera sequence rendered by `nranks` contexts in interleaved 16-row bands —
+    history and denoise window across band edges through the halo export / import path (what RCCL carries between GPUs, handed over
+    directly) — stitched, equals the accumulated and denoised frames of the reference's compiled shaders."""
+    import ctypes as C
+    from gpu_voxel_raytracer_amd import DENOISE, TEMPORAL, TRACE, Camera, Context
+    from gpu_voxel_raytracer_amd.host import OPT_HALO_ROWS
+    z = np.load(os.path.join(FIXTURES, "castle_moving_r2.npz"))
+    w, h = int(z["w"]), int(z["h"])
+    pos, mrgb = scenes.load_scene("castle")[:2]
+    rt = C.CDLL("libamdhip64.so")
+    rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    rt.hipFree.argtypes = [C.c_void_p]
+    ctxs = [Context(w, h, max_bounces=int(z["max_bounces"]), noise=noise, rank=r, nranks=nranks, band_rows=16) for r in range(nranks)]
+    try:
+        for c in ctxs:
+            c.recreate_octree(pos, mrgb)
+            c.denoise_uniforms.radius = int(z["radius"])
+            c.set_option(OPT_HALO_ROWS, 16)
+        rows = [c.local_rows() for c in ctxs]
+        for f in range(1, len(z["fov"]) + 1):
+            bufs = {}
+            for r, c in enumerate(ctxs):
+                c.camera = Camera(z["cam_pos"][f - 1], z["cam_dir"][f - 1], float(z["fov"][f - 1]))
+                c.render(TRACE | TEMPORAL)
+                p, n = C.c_void_p(), C.c_void_p()
+                assert rt.hipMalloc(C.byref(p), c.halo_bytes()) == 0 and rt.hipMalloc(C.byref(n), c.halo_bytes()) == 0
+                c.halo_export(p.value, n.value)
+                bufs[r] = (p, n)
+            for r, c in enumerate(ctxs):
+                c.halo_import(bufs[(r - 1) % nranks][1].value, bufs[(r + 1) % nranks][0].value)
+                c.render_stage(DENOISE)
+            for c in ctxs:
+                c.sync()
+            for p, n in bufs.values():
+                rt.hipFree(p); rt.hipFree(n)
+            for img, key in ((3, f"f{f}_accum"), (4, f"f{f}_denoised")):
+                got = np.zeros((h, w, 4), np.float32)
+                for c, rr in zip(ctxs, rows):
+                    got[rr] = c.read(img)
+                assert_bits_equal(got, z[key], f"{key} from {nranks} banded contexts")
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def test_the_product_needs_no_interpreter(H):
     """The fixtures are data: nothing of oracle/ospirv.cpp is linked into or loaded by the product library."""
     import subprocess
