@@ -387,3 +387,42 @@ def test_full_size_frame_loop_hashes_are_what_the_modules_give(O, scenes, noise)
         assert SP.canonical_sha256(rows) == z["sha256"]["f2_denoised_r2"][s], s
     du.radius = 8
     assert SP.canonical_sha256(SP.spirv_denoise_rows(O, acc2, nd, alb, cam16, du, *SP.R8_ROWS)) == z["sha256"]["f2_denoised_r8_rows"]
+
+
+@needs_reference
+def test_compiled_voxels_shader_equals_the_oracle_from_random_cameras(O, scenes, noise):
+    """Cameras drawn at random — outside the model, INSIDE its box (rays that start inside the tree, some inside voxels), axis-aligned
+    views whose rays have zero direction components — with random shading parameters and bounce counts, on five scenes: the compiled
+    module and the oracle agree on every bit."""
+    import zlib
+    w, h = 96, 60
+    for name in ("menger", "room", "castle", "nature", "3x3x3"):
+        pos, mrgb, size = scenes.load_scene(name)
+        octree = O.create_octree(pos, mrgb)
+        ext = scenes.world_extent(size)
+        centre = ext * np.float32(0.5)
+        rng = np.random.default_rng(zlib.crc32(name.encode()))
+        inside = 0
+        for i in range(10):
+            p = (centre + ext.max() * rng.uniform(-1.1, 1.1, 3)).astype(np.float32)
+            if i % 3 == 1:
+                p = (centre + ext * rng.uniform(-0.45, 0.45, 3)).astype(np.float32)
+                inside += 1
+            d = (centre + ext * rng.uniform(-0.3, 0.3, 3) - p).astype(np.float32)
+            if i % 5 == 2:
+                d = np.array([[1, 0, 0], [0, 0, 1], [0, -1, 0]][(i // 5) % 3], np.float32)
+                p = np.round(p)                                   # integer coordinates: rays along node mid-planes
+            u = O.Uniforms.default()
+            u.specularity = float(rng.choice([0.0, 0.0, 0.3, 1.0]))
+            u.sun_strength = float(rng.choice([4.0, 4.0, 0.0]))
+            u.sun_size = float(rng.choice([0.05, 0.3]))
+            u.sun_yaw, u.sun_pitch = float(rng.uniform(0, 6.28)), float(rng.uniform(0.1, 1.5))
+            u.emit_strength = float(rng.choice([4.0, 0.0, 20.0]))
+            u.frame_number = int(rng.integers(1, 5000))
+            bounces = int(rng.choice([1, 3, 3, 5]))
+            u.set_camera(p, O.camera_axis_scaled(p, d, scenes.FOV_70, w, h))
+            ref = O.trace(octree, noise, u, w, h, bounces, crop=(0, 0, w, h))
+            got = SP.spirv_trace(O, octree, noise, u, w, h, bounces=bounces)
+            for a, b, label in zip(got[:3], ref[:3], IMAGES):
+                raw_equal(a, b, f"{name} camera {i} at {p.tolist()} looking {d.tolist()}, {bounces} bounces: {label}")
+        assert inside >= 3
