@@ -131,6 +131,29 @@ class alt_builtins:
         _lib = self._saved
 
 
+_FMA_PATH = os.path.join(_HERE, "_build", "liboracle_fma.so")
+_fma = None
+
+
+class contracted:
+    """with oracle.contracted(): every call goes to liboracle_fma.so (`make -C oracle fma`): the same restatement compiled with
+    -ffp-contract=fast, i.e. a * b + c fused wherever the compiler can — the freedom a Vulkan driver has with the reference's modules,
+    which carry no NoContraction decoration (U9).  Only tests/test_oracle_builtin_sensitivity.py uses it."""
+
+    def __enter__(self):
+        global _lib, _fma
+        if _fma is None:
+            subprocess.check_call(["make", "-s", "-C", _HERE, "fma"])
+            _fma = _declare(C.CDLL(_FMA_PATH))
+        self._saved = lib()
+        _lib = _fma
+        return self
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._saved
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 

@@ -25,6 +25,9 @@
 //       ran on), clamp-to-edge; a texel whose quantised weight is 0 is not read.
 //   U5  inverse(mat4) (temporal.comp:82): affine inverse by adjugate/determinant in binary64,
 //       rounded once to binary32, hoisted out of the pixel loop (the matrix is per-frame).
+//   U6  sin cos tan exp log pow sqrt normalize: include/vxrt_detmath.h.   U7  float -> int out of range: saturating.
+//   U8  dot and matrix x vector: summed left to right.   U9  no contraction of a * b + c (a driver may fuse: the compiled
+//       modules carry no NoContraction decoration).
 #include <atomic>
 #include <cmath>
 #include <cstring>

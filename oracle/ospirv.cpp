@@ -20,7 +20,9 @@
 //   U6  Sin Cos Pow Exp Log Sqrt -> include/vxrt_detmath.h; Normalize = v / sqrt(dot); Length, Distance, Cross, Reflect, FMix, FClamp,
 //       FMin, FMax, FSign, FAbs as in oracle/ovec.h;
 //   U7  OpConvertFToS / OpConvertFToU -> saturating (vx_f2i);
-//   U8  the association of OpDot and OpMatrixTimesVector (SPIR-V fixes no order): left to right, ((x + y) + z) + w, as ovec.h's dot.
+//   U8  the association of OpDot and OpMatrixTimesVector (SPIR-V fixes no order): left to right, ((x + y) + z) + w, as ovec.h's dot;
+//   U9  contraction: the modules carry no NoContraction decoration, so a driver may fuse a * b + c; here, as in the oracle and the
+//       kernels, never (tests/test_oracle_builtin_sensitivity.py measures what fusing moves).
 // Undefined reads (U1: a Function variable read before it is written): memory is zeroed when an invocation starts and persists across
 // calls; with flag ORC_SPV_POISON every Function variable is filled with a NaN pattern at each function entry instead — outputs that do
 // not change between the two modes do not depend on an undefined read.

@@ -139,6 +139,8 @@ def measure(O, scenes, noise, names=None):
         for m in MASKS:
             with O.alt_builtins(getattr(O, m)):
                 out[name][m] = compare(base, run(O, scenes, noise))
+        with O.contracted():      # U9: a * b + c fused wherever the compiler can (the modules carry no NoContraction decoration)
+            out[name]["CONTRACTED"] = compare(base, run(O, scenes, noise))
     if not names:
         base = moving_camera_pipeline(O, scenes, noise)
         out["moving camera: castle 480x270, 4 frames, trace + temporal + denoise r = 2"] = pipe = {}
@@ -168,6 +170,20 @@ def test_image_moves_by_path_flips_not_by_rounding(O, scenes, noise, name):
     if "config 5" in name:
         assert worst > 1e-2 and r["ALT_NORMALIZE"]["fraction_changed"] > 0.01    # the 1e-5 offset is below half an ulp at |x| ~ 1000
     assert r["ALT_LIBM"]["rmse"] <= r["ALT_NORMALIZE"]["rmse"] + 1e-9 or r["ALT_LIBM"]["pixels_whose_path_changed"] > 0
+
+
+@pytest.mark.parametrize("name", [n for n in CASES if "config 5" not in n])
+def test_contraction_is_one_more_freedom_of_the_same_kind(O, scenes, noise, name):
+    """U9.  The reference's SPIR-V carries no NoContraction decoration, so its driver may fuse a * b + c; the oracle and the kernels never do
+    (-ffp-contract=off, include/vxrt_detmath.h).  The oracle compiled with -ffp-contract=fast moves the image exactly as a differently
+    rounded built-in does: ~1e-7 where no decision changes, a handful of pixels whose path changes, no primary ray."""
+    run, rmse_cap, flip_cap = CASES[name]
+    base = run(O, scenes, noise)
+    with O.contracted():
+        c = compare(base, run(O, scenes, noise))
+    assert c["primary_hit_flips"] == 0 and c["first_voxel_differs"] == 0
+    assert c["rmse_over_unchanged_pixels"] < 2e-6 and c["fraction_changed"] <= flip_cap and c["rmse"] <= rmse_cap, c
+    assert c["rmse_over_unchanged_pixels"] > 0.0                                   # the fused build really computes differently
 
 
 def test_sampler_and_inverse_choices_under_a_moving_camera(O, scenes, noise):
