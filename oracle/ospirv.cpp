@@ -853,33 +853,12 @@ thread_local std::string g_spv_error;
 }  // namespace
 
 extern "C" {
-
 // One binding of a dispatch.  kind 0: uniform / storage buffer (data, bytes); 1: storage image rgba32f; 2: sampled image rgba32f;
 // 3: sampler (no data).  Images: width x height is the image the shader sees (imageSize / textureSize); data holds the window
 // [ox, ox + cw) x [oy, oy + ch) of it, row-major, 4 floats per texel — an access outside the window is an error, not a guess.
 struct OrcSpvBinding { uint32_t set, binding, kind, pad; void* data; uint64_t bytes; uint32_t width, height, ox, oy, cw, ch; };
 
 enum { ORC_SPV_POISON = 1 };   // flags; bits 8 and up: the instruction budget of one invocation in millions (0: 200)
-}
-namespace {
-int dispatch(const uint32_t* words, size_t nwords, const OrcSpvBinding* bind, int nbind, uint32_t x0, uint32_t y0, uint32_t x1,
-             uint32_t y1, uint32_t flags, int nthreads, uint64_t* executed);
-}
-extern "C" {
-
-// Runs the module's GLCompute entry point once per invocation id (x, y, 0), x0 <= x < x1, y0 <= y < y1 (the workgroup shape does not
-// matter to shaders without shared memory or barriers: these three have neither).  0, or -1 with orc_spirv_error() set.
-// executed (optional): instructions interpreted, summed over the invocations.
-int orc_spirv_dispatch(const uint32_t* words, size_t nwords, const OrcSpvBinding* bind, int nbind, uint32_t x0, uint32_t y0, uint32_t x1,
-                       uint32_t y1, uint32_t flags, int nthreads, uint64_t* executed) {
-    g_spv_error.clear();
-    try {
-        return dispatch(words, nwords, bind, nbind, x0, y0, x1, y1, flags, nthreads, executed);
-    } catch (const std::exception& e) {     // out of memory on a hostile module: an error, not an abort through the C boundary
-        g_spv_error = std::string("exception: ") + e.what();
-        return -1;
-    }
-}
 }  // extern "C"
 
 namespace {
@@ -937,4 +916,22 @@ int dispatch(const uint32_t* words, size_t nwords, const OrcSpvBinding* bind, in
 }
 }  // namespace
 
-extern "C" const char* orc_spirv_error(void) { return g_spv_error.c_str(); }
+extern "C" {
+
+// Runs the module's GLCompute entry point once per invocation id (x, y, 0), x0 <= x < x1, y0 <= y < y1 (the workgroup shape does not
+// matter to shaders without shared memory or barriers: these three have neither).  0, or -1 with orc_spirv_error() set.
+// executed (optional): instructions interpreted, summed over the invocations.
+int orc_spirv_dispatch(const uint32_t* words, size_t nwords, const OrcSpvBinding* bind, int nbind, uint32_t x0, uint32_t y0, uint32_t x1,
+                       uint32_t y1, uint32_t flags, int nthreads, uint64_t* executed) {
+    g_spv_error.clear();
+    try {
+        return dispatch(words, nwords, bind, nbind, x0, y0, x1, y1, flags, nthreads, executed);
+    } catch (const std::exception& e) {     // out of memory on a hostile module: an error, not an abort through the C boundary
+        g_spv_error = std::string("exception: ") + e.what();
+        return -1;
+    }
+}
+
+const char* orc_spirv_error(void) { return g_spv_error.c_str(); }
+
+}  // extern "C"
