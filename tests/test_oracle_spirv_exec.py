@@ -337,10 +337,11 @@ def test_oracle_reproduces_the_full_size_known_answers(O, scenes, noise):
 
 @needs_reference
 def test_full_size_known_answers_are_what_the_module_gives(O, scenes, noise):
-    """Provenance of full_size.json: the whole configs[1] frame and two slabs of each 4K frame, regenerated from the reference's module."""
+    """Provenance of full_size.json: slabs of every frame regenerated from the reference's module (the three middle slabs of configs[1]'s
+    frame — the model — and one of each 4K frame; tests/diag_spirv_full_frames.py and the fixture script run the whole frames)."""
     for c in _full_size():
         n = (c["h"] + c["slab_rows"] - 1) // c["slab_rows"]
-        slabs = range(n) if c["h"] == 1080 else (n // 2 - 1, n - 3)
+        slabs = (3, 4, 5) if c["h"] == 1080 else (n // 2 - 1,)
         fresh = SP.full_size_slab_hashes(O, scenes, noise, c, slabs, compiled=True)
         for s in slabs:
             for k in ("color", "nd", "albedo"):
@@ -369,7 +370,7 @@ def test_oracle_reproduces_the_full_size_frame_loop(O, scenes, noise):
 def test_full_size_frame_loop_hashes_are_what_the_modules_give(O, scenes, noise):
     """Provenance of the frame-loop hashes.  The trace stage's whole frames are covered by the per-slab hashes above; here the temporal
     and denoise MODULES run on frame 2's inputs (the oracle's images, which those hashes say are the modules' own): temporal over the
-    whole frame, denoise with radius 2 on two slabs and with radius 8 on its strip."""
+    whole frame, denoise with radius 2 on one slab and with radius 8 on its strip."""
     z = _frame_loop()
     pos, mrgb, cam, _ = SP.full_size_uniforms(O, scenes, SP.PIPELINE_CASE)
     pipe = SP.Pipeline(O, O.create_octree(pos, mrgb), noise, z["w"], z["h"], 2, compiled=False, bounces=z["bounces"])
@@ -382,7 +383,7 @@ def test_full_size_frame_loop_hashes_are_what_the_modules_give(O, scenes, noise)
     assert SP.slab_hashes(fresh) == z["sha256"]["f2_accum"]
     du = O.Denoise.default()
     du.radius = 2
-    for s in (8, 15):
+    for s in (8,):
         rows = SP.spirv_denoise_rows(O, acc2, nd, alb, cam16, du, s * SP.SLAB_ROWS, (s + 1) * SP.SLAB_ROWS)
         assert SP.canonical_sha256(rows) == z["sha256"]["f2_denoised_r2"][s], s
     du.radius = 8
