@@ -89,6 +89,33 @@ def test_hip_frame_loop_at_config3_size_hashes_to_the_compiled_shaders_known_ans
         assert SP.canonical_sha256(ctx.read(4)[y0:y1]) == z["sha256"]["f2_denoised_r8_rows"]
 
 
+@pytest.mark.parametrize("env", [{"VXRT_TRACE_VARIANT": "0"}, {"VXRT_TRACE_VARIANT": "2", "VXRT_TRACE_SPLIT": "0x3"}, {"VXRT_TRACE_VARIANT": "3"},
+                                 {"VXRT_TRACE_VARIANT": "4", "VXRT_TAIL_FROM": "0"}, {"VXRT_TRACE_VARIANT": "5"}, {"VXRT_WIDE": "1"},
+                                 {"VXRT_FUSED_TAIL": "1"}])
+@pytest.mark.parametrize("name", ["castle_moving_r2", "cap_row_r0", "monu10_8_bounces_r2"])
+def test_every_schedule_and_scene_format_gives_the_compiled_shaders_frames(H, scenes, noise, monkeypatch, env, name):
+    """The all-in-one kernel, the wavefront, ray-queue and path-refill tracers, the hand-over at the first hit, the fused head + tail and the
+    two-level scene records (the variants library, loaded beside the product): the same frames as the reference's compiled shaders."""
+    from conftest import require_variants
+    from gpu_voxel_raytracer_amd import ALL, Camera, Context
+    require_variants(H, env)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    z = np.load(os.path.join(FIXTURES, name + ".npz"))
+    pos, mrgb = SP.cap_scene() if str(z["scene"]) == "cap" else scenes.load_scene(str(z["scene"]))[:2]
+    with Context(int(z["w"]), int(z["h"]), max_bounces=int(z["max_bounces"]), noise=noise) as ctx:
+        ctx.recreate_octree(pos, mrgb)
+        ctx.uniforms.specularity = float(z["specularity"])
+        ctx.denoise_uniforms.radius = int(z["radius"])
+        for f in range(1, len(z["fov"]) + 1):
+            ctx.camera = Camera(z["cam_pos"][f - 1], z["cam_dir"][f - 1], float(z["fov"][f - 1]))
+            ctx.render(ALL)
+            if f == 1:
+                for img, key in ((0, "f1_color"), (1, "f1_nd"), (2, "f1_albedo")):
+                    assert_bits_equal(ctx.read(img), z[key], f"{name} {key} {env}")
+            assert_bits_equal(ctx.read(4), z[f"f{f}_denoised"], f"{name} denoised colour of frame {f} {env}")
+
+
 @pytest.mark.parametrize("nranks", [2, 4])
 def test_banded_contexts_with_a_halo_equal_the_compiled_shaders_frames(H, scenes, noise, nranks):
     """Row (e) against the same reference-made frames: the moving-camera sequence rendered by `nranks` contexts in interleaved 16-row bands —
