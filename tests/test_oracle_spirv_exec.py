@@ -427,3 +427,44 @@ def test_compiled_voxels_shader_equals_the_oracle_from_random_cameras(O, scenes,
             for a, b, label in zip(got[:3], ref[:3], IMAGES):
                 raw_equal(a, b, f"{name} camera {i} at {p.tolist()} looking {d.tolist()}, {bounces} bounces: {label}")
         assert inside >= 3
+
+
+@needs_reference
+@pytest.mark.parametrize("name", ["castle", "menger", "nature"])
+def test_compiled_traversal_over_the_built_octree_finds_the_voxel_lists_first_hits(O, scenes, noise, name):
+    """The octree BUILDER (src/context.rs:710-834, restated; Rust: no compiled form to run) is held by known answers only — but its output
+    is what the reference's compiled traversal reads.  Primary rays of a frame through the compiled voxels.comp over the built buffer
+    against an independent binary64 DDA over the plain voxel list (oracle/odda.cpp): the same hit or miss, the same voxel, the same
+    entry face, and the leaf word the shader returns is that voxel's material and colour — the layout `nodes[8 * node + octant]`, the
+    leaf and emittance bits and the header are the ones the compiled shader expects."""
+    from test_oracle_traversal import dense_grid
+    w, h = 240, 135
+    pos, mrgb, size = scenes.load_scene(name)
+    octree = O.create_octree(pos, mrgb)
+    cam = scenes.close_camera(size)
+    u = O.Uniforms.default()
+    basis = O.camera_axis_scaled(cam[0], cam[1], cam[2], w, h)
+    u.set_camera(cam[0], basis)
+    u.frame_number = 1
+    _, nd, alb, _ = SP.spirv_trace(O, octree, noise, u, w, h)
+    xs, ys = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
+    d = xs[..., None] * basis[0:3] - ys[..., None] * basis[3:6] + basis[6:9]
+    d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32).reshape(-1, 3)
+    o = np.tile(np.asarray(cam[0], np.float32), (w * h, 1))
+    grid, base = dense_grid(pos)
+    dhit, dt, daxis, dcell = O.dda_cast(grid, base, o, d)
+    hit = (nd[..., 3] >= 0).ravel()
+    assert hit.sum() > 5000 and (hit == dhit).mean() > 0.9995
+    both = hit & dhit
+    t = nd[..., 3].ravel()
+    assert np.quantile(np.abs(t[both] - dt[both]) / np.maximum(dt[both], 1e-3), 0.999) < 1e-4
+    normal = nd[..., :3].reshape(-1, 3)
+    assert (np.argmax(np.abs(normal[both]), 1) == daxis[both]).mean() > 0.9995
+    # the voxel the DDA found, looked up in the voxel list, against the leaf word the shader wrote (intBitsToFloat, voxels.comp:396)
+    lut = {tuple(p): k for k, p in enumerate(pos.astype(np.int32).tolist())}
+    word = alb[..., 3].ravel().view(np.uint32)
+    idx = np.nonzero(both)[0][::7]
+    want = np.array([lut[tuple(dcell[i])] for i in idx])
+    m, r, g, b = (mrgb[want, k].astype(np.uint32) for k in range(4))
+    expect = 0x80000000 | ((m & 0x7f) << 24) | (r << 16) | (g << 8) | b
+    assert (word[idx] == expect).mean() > 0.9995
