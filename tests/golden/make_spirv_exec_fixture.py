@@ -47,6 +47,13 @@ def main():
         data = make(name, spec, noise)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **data)
         print(name, {k: v.shape for k, v in data.items() if isinstance(v, np.ndarray) and v.ndim == 3}, os.path.getsize(os.path.join(OUT, name + ".npz")) // 1024, "KB")
+    sweep = {}
+    for name in SP.sweep_scenes():
+        for key, img in zip(("color", "nd", "albedo"), SP.sweep_frame(O, scenes, noise, name, compiled=True)):
+            sweep[f"{name}_{key}"] = img
+    np.savez_compressed(os.path.join(OUT, "scene_sweep.npz"), w=SP.SWEEP["w"], h=SP.SWEEP["h"], frame_number=SP.SWEEP["frame_number"],
+                        max_bounces=SP.MAX_BOUNCES, **sweep)
+    print("scene_sweep", len(sweep) // 3, "scenes", os.path.getsize(os.path.join(OUT, "scene_sweep.npz")) // 1024, "KB")
     if "--no-full-size" not in sys.argv:
         full_size(noise)
 

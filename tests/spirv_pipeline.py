@@ -288,3 +288,25 @@ def pipeline_hashes(O, scenes, noise, compiled, case=PIPELINE_CASE, log=None):
         rows = O.denoise(accum, nd, alb, cam16, du)[R8_ROWS[0]:R8_ROWS[1]]
     out["f2_denoised_r8_rows"] = canonical_sha256(rows)
     return out
+
+
+# ---- every scene file once: the trace stage's three images of a small frame (tests/golden/spirv_exec/scene_sweep.npz) --------------
+SWEEP = dict(w=64, h=40, frame_number=1)
+
+
+def sweep_scenes():
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenes")
+    return sorted(f[:-4] for f in os.listdir(golden) if f.endswith(".npz"))
+
+
+def sweep_frame(O, scenes, noise, name, compiled):
+    """(colour, normal/depth, albedo) of the scene's close view at SWEEP's size, 3 bounces, through the compiled module or the oracle."""
+    pos, mrgb, size = scenes.load_scene(name)
+    cam = scenes.close_camera(size)
+    u = O.Uniforms.default()
+    u.set_camera(cam[0], O.camera_axis_scaled(cam[0], cam[1], cam[2], SWEEP["w"], SWEEP["h"]))
+    u.frame_number = SWEEP["frame_number"]
+    octree = O.create_octree(pos, mrgb)
+    if compiled:
+        return spirv_trace(O, octree, noise, u, SWEEP["w"], SWEEP["h"])[:3]
+    return O.trace(octree, noise, u, SWEEP["w"], SWEEP["h"], MAX_BOUNCES, crop=(0, 0, SWEEP["w"], SWEEP["h"]))[:3]

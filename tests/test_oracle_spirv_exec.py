@@ -23,7 +23,7 @@ import spirv_pipeline as SP
 from conftest import GOLDEN, assert_bits_equal, needs_reference
 
 FIXTURES = os.path.join(GOLDEN, "spirv_exec")
-CASES = sorted(f[:-4] for f in os.listdir(FIXTURES) if f.endswith(".npz"))
+CASES = sorted(f[:-4] for f in os.listdir(FIXTURES) if f.endswith(".npz") and f != "scene_sweep.npz")
 IMAGES = ("f1_color", "f1_nd", "f1_albedo")
 
 
@@ -468,3 +468,24 @@ def test_compiled_traversal_over_the_built_octree_finds_the_voxel_lists_first_hi
     m, r, g, b = (mrgb[want, k].astype(np.uint32) for k in range(4))
     expect = 0x80000000 | ((m & 0x7f) << 24) | (r << 16) | (g << 8) | b
     assert (word[idx] == expect).mean() > 0.9995
+
+
+def test_oracle_reproduces_the_scene_sweep(O, scenes, noise):
+    """Every scene file of the reference (15), its close view at 64 x 40: the three trace images of the compiled shader, from the oracle."""
+    z = np.load(os.path.join(FIXTURES, "scene_sweep.npz"))
+    names = SP.sweep_scenes()
+    assert len(names) == 15 and (int(z["w"]), int(z["h"]), int(z["max_bounces"])) == (SP.SWEEP["w"], SP.SWEEP["h"], SP.MAX_BOUNCES)
+    hits = 0
+    for name in names:
+        for key, img in zip(("color", "nd", "albedo"), SP.sweep_frame(O, scenes, noise, name, compiled=False)):
+            raw_equal(img, z[f"{name}_{key}"], f"{name} {key}")
+        hits += int((z[f"{name}_nd"][..., 3] >= 0).sum())
+    assert hits > 15 * 200
+
+
+@needs_reference
+def test_scene_sweep_is_what_the_module_gives(O, scenes, noise):
+    z = np.load(os.path.join(FIXTURES, "scene_sweep.npz"))
+    for name in SP.sweep_scenes():
+        for key, img in zip(("color", "nd", "albedo"), SP.sweep_frame(O, scenes, noise, name, compiled=True)):
+            raw_equal(img, z[f"{name}_{key}"], f"{name} {key}")
