@@ -953,6 +953,11 @@ def trace_bench(args):
                     extra["config4_one_rank_of_8"] = measure_config4_rank(Context, Camera, (TRACE, TEMPORAL, TIMED, DENOISE_INTERIOR, DENOISE_EDGE), scenes, device)
                 except Exception as e:  # noqa: BLE001
                     extra["config4_one_rank_of_8"] = {"error": repr(e)}
+            if default_cfg:
+                try:
+                    extra["parity_check"] = parity_check(Context, Camera, TRACE, scenes, pos, mrgb, cam, device)
+                except Exception as e:  # noqa: BLE001
+                    extra["parity_check"] = {"error": repr(e)}
             out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pos, mrgb, cam)
@@ -963,6 +968,40 @@ def trace_bench(args):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def parity_check(Context, Camera, TRACE, scenes, pos, mrgb, cam, device):
+    """The frame this benchmark times (menger 1920x1080, 4 bounces, frame 1) rendered once more and hashed slab by slab against what the
+    REFERENCE'S COMPILED voxels.comp gives for it (tests/golden/spirv_exec/full_size.json: the module executed instruction by instruction
+    where the reference is mounted; data here).  Says in the line itself that the timed kernels compute the reference's frame."""
+    import hashlib
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "spirv_exec", "full_size.json")
+    with open(path) as f:
+        case = next(c for c in json.load(f)["cases"] if c["scene"] == SCENE and (c["w"], c["h"]) == (1920, 1080))
+
+    def digest(img, node_channel):
+        a = np.ascontiguousarray(img, np.float32)
+        v = a.view(np.uint32).copy()
+        keep = v[..., 3].copy()
+        v[np.isnan(a)] = 0x7fc00000          # what IEEE leaves open, made canonical (tests/spirv_pipeline.py: canonical_sha256)
+        v[v == 0x80000000] = 0
+        if node_channel:
+            v[..., 3] = keep                 # the albedo image's .w is the leaf word, an integer
+        return hashlib.sha256(v.tobytes()).hexdigest()
+    with Context(1920, 1080, device=device, max_bounces=case["bounces"]) as ctx:
+        ctx.recreate_octree(pos, mrgb)
+        ctx.camera = Camera(*cam)
+        ctx.render(TRACE)
+        rows, slabs, bad = case["slab_rows"], 0, []
+        for key, img in (("color", 0), ("nd", 1), ("albedo", 2)):
+            a = ctx.read(img)
+            for s, want in enumerate(case["sha256"][key]):
+                slabs += 1
+                if digest(a[s * rows:(s + 1) * rows], key == "albedo") != want:
+                    bad.append(f"{key} rows {s * rows}-{(s + 1) * rows}")
+    return {"against": "the reference's compiled shaders/voxels.comp.spv executed by oracle/ospirv.cpp (fixture tests/golden/spirv_exec/full_size.json)",
+            "frame": f"vox/{SCENE}.vox 1920x1080, {case['bounces']} bounces, frame 1: colour, normal/depth, albedo/node images", "slabs_hashed": slabs,
+            "bit_exact": not bad, "differing": bad}
 
 
 def pipeline_bench(args):

@@ -321,6 +321,8 @@ def test_bench_contract_line():
     assert c5["bound"] == "hbm" and c5["frac_raw"] < c5["frac_read_doubled"] < 1.0 and "MEASURED" in c5["source"]
     assert 0.2 < c5["l2_hit_rate"] < 0.8 and 0.1 < c5["lane_utilisation"] < 0.6 and 0.3 < c5["valu_issue_slot_frac"] < 1.0
     assert "RECORDED" not in lines[0]             # every counter figure of the line is measured by the run itself
+    pc = d["extra"]["parity_check"]               # the timed frame, hashed against the reference's compiled shader's output, in the line itself
+    assert pc["bit_exact"] is True and pc["slabs_hashed"] == 27 and pc["differing"] == []
     assert d["data"].startswith("vox/menger.vox")
     r = d["roofline"]
     assert r["bound"] == "hbm" and "valu" in r["limited_by"] and r["unit"] == "GB/s" and r["peak"] == 8000.0
