@@ -555,23 +555,39 @@ def spawn_ranks(n, argv):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
     deadline = time.time() + float(os.environ.get("VXRT_BENCH_SPAWN_TIMEOUT", "1500"))
-    line, status, pending = None, 0, set(range(n))
+    line, status = None, 0
     import threading
     out_lines = []
     reader = threading.Thread(target=lambda: out_lines.extend(procs[0].stdout), daemon=True)
     reader.start()
-    while pending:
-        for r in sorted(pending):
-            rc = procs[r].poll()
-            if rc is not None:
-                pending.discard(r)
-                if rc != 0 and status == 0:
-                    status = rc if rc > 0 else 128 - rc
-                    print(f"bench.py: rank {r} exited with status {rc}; stopping the other ranks", file=sys.stderr)
-        if status != 0 or time.time() > deadline:
-            if status == 0:
-                status = 124
-                print("bench.py: ranks did not finish in time; stopping them", file=sys.stderr)
+    # one waiter per rank notes WHEN its rank ended: a rank that fails takes its peers down with it within milliseconds (their collective
+    # breaks), and the job's status is that of the rank that went first, not of whichever a polling loop happens to look at first
+    exits, lock = [], threading.Lock()
+
+    def wait_for(r):
+        rc = procs[r].wait()
+        with lock:
+            exits.append((time.monotonic(), r, rc))
+    waiters = [threading.Thread(target=wait_for, args=(r,), daemon=True) for r in range(n)]
+    for t in waiters:
+        t.start()
+    while True:
+        with lock:
+            done = list(exits)
+        failed = [e for e in done if e[2] != 0]
+        if failed:
+            time.sleep(0.2)                      # exits that came in the same breath are all in by now
+            with lock:
+                _, r, rc = min(e for e in exits if e[2] != 0)
+            status = rc if rc > 0 else 128 - rc
+            print(f"bench.py: rank {r} exited with status {rc}; stopping the other ranks", file=sys.stderr)
+        elif len(done) == n:
+            break
+        elif time.time() > deadline:
+            status = 124
+            print("bench.py: ranks did not finish in time; stopping them", file=sys.stderr)
+        if status != 0:
+            pending = [r for r in range(n) if procs[r].poll() is None]
             for r in pending:                    # exactly the processes started above, by PID
                 procs[r].send_signal(signal.SIGTERM)
             for r in pending:
