@@ -489,3 +489,38 @@ def test_scene_sweep_is_what_the_module_gives(O, scenes, noise):
     for name in SP.sweep_scenes():
         for key, img in zip(("color", "nd", "albedo"), SP.sweep_frame(O, scenes, noise, name, compiled=True)):
             raw_equal(img, z[f"{name}_{key}"], f"{name} {key}")
+
+
+@needs_reference
+def test_compiled_voxels_shader_equals_the_oracle_on_edge_scenes(O, noise):
+    """The scene format's corners through the compiled module: no voxels at all (a root of eight empty slots), one voxel, one voxel in the
+    negative octant, 6 000 random voxels on both sides of the origin, a depth-10 slab far from it, and the deepest tree int16 coordinates
+    allow (depth 15 = MAX_DEPTH - 1 frames of the shader's stack, voxels.comp:3,127-130) at both extremes."""
+    f32 = np.float32
+    rng = np.random.default_rng(42)
+    xs, ys = np.meshgrid(np.arange(900, 960), np.arange(900, 960))
+    far = np.stack([xs.ravel(), ys.ravel(), 900 + (xs.ravel() * 7 + ys.ravel() * 3) % 5], 1).astype(np.int16)
+    cases = [
+        (np.zeros((0, 3), np.int16), np.zeros((0, 4), np.uint8), (np.array([3, 2, -4], f32), np.array([-3, -2, 4], f32), 1.0), 96, 64),
+        (np.array([[0, 0, 0]], np.int16), np.array([[0x40, 200, 100, 50]], np.uint8), (np.array([3, 2, -4], f32), np.array([-3, -2, 4], f32), 1.0), 96, 64),
+        (np.array([[-1, -1, -1]], np.int16), np.array([[0, 1, 2, 3]], np.uint8), (np.array([3, 2, -4], f32), np.array([-3, -2, 4], f32), 1.0), 96, 64),
+        (rng.integers(-40, 40, (6000, 3)).astype(np.int16), rng.integers(0, 256, (6000, 4)).astype(np.uint8),
+         (np.array([45, 30, -50], f32), np.array([-45, -30, 50], f32), 1.1), 160, 96),
+        (far, np.tile(np.array([[0, 255, 128, 0]], np.uint8), (len(far), 1)), (np.array([462, 470, 438], f32), np.array([0.1, -0.25, 1.0], f32), 1.2), 128, 96),
+    ]
+    for extreme in (32767, -32768):
+        cases.append((np.array([[extreme, 3, -2], [0, 0, 0]], np.int16), np.array([[0, 10, 200, 30], [0x40, 255, 255, 255]], np.uint8),
+                      (np.array([extreme / 2 + (3 if extreme > 0 else -3), 4, -6], f32), np.array([-0.5 if extreme > 0 else 0.5, -0.4, 1.0], f32), 0.9), 64, 48))
+    depths = []
+    for pos, mrgb, cam, w, h in cases:
+        octree = O.create_octree(pos, mrgb)
+        depths.append(O.voxel_depth(pos) if len(pos) else 0)
+        u = O.Uniforms.default()
+        u.set_camera(cam[0], O.camera_axis_scaled(cam[0], cam[1], cam[2], w, h))
+        for frame in (1, 7):
+            u.frame_number = frame
+            ref = O.trace(octree, noise, u, w, h, SP.MAX_BOUNCES, crop=(0, 0, w, h))
+            got = SP.spirv_trace(O, octree, noise, u, w, h)
+            for a, b, label in zip(got[:3], ref[:3], IMAGES):
+                raw_equal(a, b, f"{len(pos)} voxels, depth {depths[-1]}, frame {frame}: {label}")
+    assert 10 in depths and depths.count(15) == 2
