@@ -162,25 +162,30 @@ def live_probes():
     config 5's scene from outside -> FETCH_SIZE per frame of trace_kernel; config 3's frame loop at r = 8 -> SQ_INSTS_VALU per launch of
     denoise_pair_kernel.  -> dict (possibly partial); a probe that fails is simply absent and the line falls back to profiles/."""
     out = {}
+    # run_probe("config5"): per view 4 warm-up + 8 timed launches of trace_kernel, outside view first, then the tunnel
+    views = {"": slice(4, 12), "_tunnel": slice(16, 24)}
     try:
-        got, line = pmc_pass(["FETCH_SIZE"], ["--probe", "config5"], r"trace_kernel")
+        got, line = pmc_pass(["FETCH_SIZE"], ["--probe", "config5"], r"trace_kernel", timeout=240)
         f = got["trace_kernel"]["FETCH_SIZE"]
-        out["config5_fetch_bytes_per_frame"] = sum(f[-8:]) / len(f[-8:]) * 1024.0
+        for tag, sl in views.items():
+            out["config5_fetch_bytes_per_frame" + tag] = sum(f[sl]) / len(f[sl]) * 1024.0
         out["config5_probe_ms_per_frame"] = line.get("ms_per_frame")
     except Exception as e:  # noqa: BLE001
         out["config5_error"] = repr(e)[:200]
     try:    # the L2's hit rate of the same frames (a pass of its own: the TCC block has four counters, FETCH_SIZE takes three)
-        got, _ = pmc_pass(["TCC_HIT_sum", "TCC_MISS_sum"], ["--probe", "config5"], r"trace_kernel")
-        h, m = got["trace_kernel"]["TCC_HIT_sum"][-8:], got["trace_kernel"]["TCC_MISS_sum"][-8:]
-        out["config5_l2_hit_rate"] = sum(h) / (sum(h) + sum(m))
+        got, _ = pmc_pass(["TCC_HIT_sum", "TCC_MISS_sum"], ["--probe", "config5"], r"trace_kernel", timeout=240)
+        for tag, sl in views.items():
+            h, m = got["trace_kernel"]["TCC_HIT_sum"][sl], got["trace_kernel"]["TCC_MISS_sum"][sl]
+            out["config5_l2_hit_rate" + tag] = sum(h) / (sum(h) + sum(m))
     except Exception as e:  # noqa: BLE001
         out["config5_l2_error"] = repr(e)[:200]
     try:    # ... and their lane utilisation and VALU issue
-        got, line = pmc_pass(["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVES"], ["--probe", "config5"], r"trace_kernel")
+        got, line = pmc_pass(["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVES"], ["--probe", "config5"], r"trace_kernel", timeout=240)
         c = got["trace_kernel"]
-        act, thr = sum(c["SQ_ACTIVE_INST_VALU"][-8:]), sum(c["SQ_THREAD_CYCLES_VALU"][-8:])
-        out["config5_lane_utilisation"] = thr / (act * 64)
-        out["config5_valu_wave_instr_per_frame"] = sum(c["SQ_INSTS_VALU"][-8:]) / len(c["SQ_INSTS_VALU"][-8:])
+        for tag, sl in views.items():
+            act, thr = sum(c["SQ_ACTIVE_INST_VALU"][sl]), sum(c["SQ_THREAD_CYCLES_VALU"][sl])
+            out["config5_lane_utilisation" + tag] = thr / (act * 64)
+            out["config5_valu_wave_instr_per_frame" + tag] = sum(c["SQ_INSTS_VALU"][sl]) / len(c["SQ_INSTS_VALU"][sl])
     except Exception as e:  # noqa: BLE001
         out["config5_sq_error"] = repr(e)[:200]
     try:
@@ -198,13 +203,16 @@ def run_probe(which):
     if which == "config5":
         with Context(3840, 2160, max_bounces=8, frames_in_flight=1, frames_per_launch=1) as ctx:
             ctx.set_menger(*scenes.CONFIG5)
-            ctx.camera = Camera(*scenes.config5_cameras()["outside"])
-            ctx.render_frames(TRACE, 4)
-            ctx.sync()
-            t0 = time.perf_counter()
-            ctx.render_frames(TRACE, 8)
-            ctx.sync()
-            print(json.dumps({"probe": which, "ms_per_frame": round((time.perf_counter() - t0) / 8 * 1e3, 4)}), flush=True)
+            ms = {}
+            for view in ("outside", "tunnel"):      # live_probes: per view 4 warm-up + 8 timed launches, in this order
+                ctx.camera = Camera(*scenes.config5_cameras()[view])
+                ctx.render_frames(TRACE, 4)
+                ctx.sync()
+                t0 = time.perf_counter()
+                ctx.render_frames(TRACE, 8)
+                ctx.sync()
+                ms[view] = round((time.perf_counter() - t0) / 8 * 1e3, 4)
+            print(json.dumps({"probe": which, "ms_per_frame": ms["outside"], "ms_per_frame_tunnel": ms["tunnel"]}), flush=True)
     else:
         pos, mrgb, size = scenes.load_scene("monu10")
         with Context(3840, 2160, max_bounces=8, frames_in_flight=2, frames_per_launch=4) as ctx:
@@ -227,6 +235,189 @@ def recorded_json(name):
         except (OSError, ValueError):
             continue
     return None, None
+
+
+def measure_reference_loop(Context, Camera, flags, scenes, device, frames=120):
+    """The loop the reference itself runs (src/main.rs:34-38 -> Context::update / render, src/context.rs:1959-2075, 2136-2162), timed as a
+    drop-in host would call it: per frame `vxrt_set_camera` (a moving camera: frame_loop.orbit_camera, a quarter revolution over 960
+    frames = 0.09 degrees per frame), `vxrt_render(ALL)` — the three dispatches — and `vxrt_sync`, with the reference's MAX_BOUNCES 3
+    (shaders/voxels.comp:4), at 1920x1080 and at 1600x1600 (the reference's 800x800 logical window, src/context.rs:597, at scale factor 2),
+    denoise radius 0 (the reference's default) and 2.  Four more rows per case: the same loop when the host pulls EVERY denoised frame
+    with `vxrt_read` (synchronous, pageable: what round 5 had), with `vxrt_read_async` into two pinned buffers (frame n travels while
+    frame n + 1 renders), the transfer alone, and the same frames through `vxrt_render_path` (the whole camera path handed over: 16
+    frames per trace launch, two launches in flight) — the gap between "drop-in" and "pipelined" in one place."""
+    from gpu_voxel_raytracer_amd import DENOISED
+    from gpu_voxel_raytracer_amd.frame_loop import orbit_camera
+    ALL, TIMED = flags
+    pos, mrgb, size = scenes.load_scene(SCENE)
+    path = [orbit_camera(size, 0.62 + 0.25 * f / 960.0) for f in range(frames + 8)]
+    rows = {}
+    for w, h in ((1920, 1080), (1600, 1600)):
+        for radius in (0, 2):
+            row = {}
+            with Context(w, h, device=device, max_bounces=3) as ctx:          # one frame at a time on one stream: the reference's single queue
+                ctx.recreate_octree(pos, mrgb)
+                ctx.denoise_uniforms.radius = radius
+
+                def loop(first, count, pull=None, timed=False):
+                    for f in range(first, first + count):
+                        ctx.camera = Camera(*path[f])
+                        ctx.render(ALL | (TIMED if timed else 0))
+                        if pull is None:
+                            ctx.sync()
+                        else:
+                            pull(f)
+                loop(0, 8)
+                ctx.reset_stats()
+                t0 = time.perf_counter()
+                loop(8, frames, timed=True)
+                dt = time.perf_counter() - t0
+                st = ctx.stats()
+                row["ms_per_frame"] = round(dt / frames * 1e3, 4)
+                row["mrays_per_s"] = round(st.rays / dt / 1e6, 1)
+                row["rays_per_pixel"] = round(st.rays / frames / (w * h), 4)
+                row["stage_ms"] = {"trace": round(st.trace_ms / frames, 4), "temporal": round(st.temporal_ms / frames, 4), "denoise": round(st.denoise_ms / frames, 4)}
+                # ... the host takes every denoised frame: synchronously into pageable memory (vxrt_read)
+                img = np.zeros((h, w, 4), np.float32)
+                nbytes = img.nbytes
+
+                def pull_sync(f):
+                    ctx.read_into(DENOISED, img)
+                loop(0, 4, pull_sync)
+                t0 = time.perf_counter()
+                loop(8, frames // 2, pull_sync)
+                row["with_vxrt_read_ms_per_frame"] = round((time.perf_counter() - t0) / (frames // 2) * 1e3, 4)
+                # ... without blocking: two pinned buffers, frame f's transfer is waited for after frame f + 1 has been submitted
+                pinned = [ctx.pinned_image(), ctx.pinned_image()]
+
+                def pull_async(f):
+                    ctx.read_async(DENOISED, pinned[f & 1], f & 1)
+                    ctx.read_wait((f + 1) & 1)             # the previous frame has arrived: the host may show it
+                loop(0, 4, pull_async)
+                ctx.read_wait(0); ctx.read_wait(1)
+                t0 = time.perf_counter()
+                loop(8, frames, pull_async)
+                ctx.read_wait(0); ctx.read_wait(1)
+                row["with_vxrt_read_async_ms_per_frame"] = round((time.perf_counter() - t0) / frames * 1e3, 4)
+                ctx.sync()
+                t0 = time.perf_counter()
+                for k in range(16):
+                    ctx.read_async(DENOISED, pinned[k & 1], k & 1)
+                    ctx.read_wait(k & 1)
+                row["transfer_alone_ms"] = round((time.perf_counter() - t0) / 16 * 1e3, 4)
+                row["transfer_gb_per_s"] = round(nbytes / (row["transfer_alone_ms"] * 1e-3) / 1e9, 1)
+                row["read_async_over_max_of_render_and_transfer"] = round(row["with_vxrt_read_async_ms_per_frame"] / max(row["ms_per_frame"], row["transfer_alone_ms"]), 3)
+                for pb in pinned:
+                    pb.close()
+            with Context(w, h, device=device, max_bounces=3, frames_in_flight=2, frames_per_launch=16) as ctx:   # the same frames, the path handed over
+                ctx.recreate_octree(pos, mrgb)
+                ctx.denoise_uniforms.radius = radius
+                ctx.render_path(ALL, [p[0] for p in path[:8]], [p[1] for p in path[:8]], path[0][2])
+                ctx.sync()
+                n = frames // 16 * 16
+                t0 = time.perf_counter()
+                ctx.render_path(ALL, [p[0] for p in path[8:8 + n]], [p[1] for p in path[8:8 + n]], path[0][2])
+                ctx.sync()
+                row["vxrt_render_path_ms_per_frame"] = round((time.perf_counter() - t0) / n * 1e3, 4)
+            rows[f"{w}x{h}_r{radius}"] = row
+    return {"workload": f"vox/{SCENE}.vox, MAX_BOUNCES 3, orbiting camera (0.09 degrees per frame), trace + temporal + denoise; {frames} frames per figure",
+            "loop": "per frame: vxrt_set_camera -> vxrt_render(VXRT_ALL) -> vxrt_sync, frames_in_flight 1, frames_per_launch 1 (src/context.rs:2004-2075)",
+            "rows": rows}
+
+
+def measure_config5_touch(device, views=("outside", "tunnel"), frames=2):
+    """SURVEY 8d's "bricks actually touched" for BASELINE configs[4]'s scene: the UNIQUE 64-byte lines of node records and leaf words
+    that one 3840x2160, 8-bounce frame reads, per view — the compulsory scene traffic of a frame, each byte once.  Measured with the
+    touch map of the -DVXRT_VARIANTS=1 library (csrc/trace_common.h: VX_TOUCH; the product's kernels hold no such code), loaded
+    beside the product for this probe only; the frames are the frames the timed view renders (same scene, camera, frame numbers from 3
+    on — the noise differs per frame, so `frames` consecutive frames are measured apart).  -> {view: {...}}"""
+    from gpu_voxel_raytracer_amd import TRACE, Camera, Context, host, scenes
+    out = {}
+    host.use_library(host.variants_library())
+    try:
+        with Context(3840, 2160, device=device, max_bounces=8, frames_in_flight=1, frames_per_launch=1) as ctx:
+            ctx.set_menger(*scenes.CONFIG5)
+            for view in views:
+                ctx.camera = Camera(*scenes.config5_cameras()[view])
+                ctx.render_frames(TRACE, 2)
+                ctx.touch_map(True)
+                per_frame = []
+                for _ in range(frames):
+                    ctx.render_frames(TRACE, 1)
+                    per_frame.append(ctx.touch_count(reset=True))
+                ctx.render_frames(TRACE, 8)                       # ... and what eight consecutive frames touch together
+                eight = ctx.touch_count(reset=True)
+                ctx.touch_map(False)
+                t = per_frame[0]
+                out[view] = {"unique_scene_bytes_per_frame": t["unique_bytes_64"], "at_128_byte_lines": t["unique_bytes_128"],
+                             "node_record_bytes": 64 * t["node_lines_64"], "leaf_word_bytes": 64 * t["leaf_lines_64"],
+                             "other_frames": [f["unique_bytes_64"] for f in per_frame[1:]], "eight_frames_together": eight["unique_bytes_64"],
+                             "scene_bytes": t["scene_bytes"], "share_of_the_scene": round(t["unique_bytes_64"] / t["scene_bytes"], 5)}
+    finally:
+        host.use_library(None)
+    return out
+
+
+def measure_config5(Context, Camera, TRACE, scenes, device, probes):
+    """BASELINE configs[4]'s scene (procedural Menger level 7 clipped to 2048^3: 5.6 GB, HBM-resident — north_star's "HBM-bound stress", the one
+    config where achieved GB/s against 8 TB/s is the right axis) on this GPU: one 3840x2160, 8-bounce frame per launch (one GPU's share of
+    the 7680x4320 frame is a band set of it), from outside and from inside a tunnel.  Per view: ms per frame (this run), and a roofline in
+    SURVEY 8d's sense — ALGORITHMIC bytes = 48 B/px written + the UNIQUE scene bytes the frame touches (measure_config5_touch: every
+    64-byte line of node records and leaf words it reads, counted once) + the noise layers, over the frame time — beside what the
+    counters say the frame really moved (FETCH_SIZE, L2 hit rate, lanes: the run's own rocprofv3 child passes), and their ratio:
+    refetch = bytes fetched / unique bytes = how often the same line comes from beyond the L2 again."""
+    out = {}
+    try:
+        touch = measure_config5_touch(device)
+    except Exception as e:  # noqa: BLE001 — an extra must never cost the headline line
+        touch = {"error": repr(e)[:300]}
+    for view, key, tag, frames, blocks in (("outside", "config5_outside_view", "", 24, 5), ("tunnel", "config5_tunnel_view", "_tunnel", 8, 3)):
+        try:
+            c5 = dict(
+                measure_view(Context, Camera, TRACE, None, None, scenes.config5_cameras()[view], device, 8, 1, 1, width=3840, height=2160, frames=frames, blocks=blocks,
+                             setup=lambda ctx: ctx.set_menger(*scenes.CONFIG5)),
+                workload="BASELINE configs[4]'s scene (procedural Menger level 7 clipped to 2048^3, 5.6 GB: HBM-resident) at 3840x2160, "
+                         f"8 bounces, one frame per launch, view '{view}'; one GPU's share is a band set of the 7680x4320 frame")
+            sec = c5["ms_per_frame"] * 1e-3
+            written = 48.0 * 3840 * 2160
+            noise = min(8 * 8, 512) * 128 * 128 * 4
+            roof = {"bound": "hbm", "kernel": "trace_kernel (all-in-one, 6 waves per SIMD)", "peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_written_per_frame": int(written)}
+            t = touch.get(view)
+            if t:
+                alg = written + t["unique_scene_bytes_per_frame"] + noise
+                roof.update({"algorithmic_bytes_per_frame": int(alg), "unique_scene_bytes_per_frame": t["unique_scene_bytes_per_frame"],
+                             "unique_scene_bytes": t, "noise_layer_bytes": noise,
+                             "achieved": round(alg / sec / 1e9, 1), "frac": round(alg / sec / 1e9 / HBM_PEAK_GBS, 4),
+                             "algorithmic_source": "48 B/px + the unique 64-byte lines of node records and leaf words one frame reads (touch map of the -DVXRT_VARIANTS=1 "
+                                                   "library, MEASURED in this invocation on the same scene, view and frame size) + 64 noise layers"})
+            elif "error" in touch:
+                roof["unique_scene_bytes_error"] = touch["error"]
+            fetch = probes.get("config5_fetch_bytes_per_frame" + tag)
+            if fetch:
+                roof.update({"bytes_fetched_per_frame": int(fetch), "traffic": int(written + 2 * fetch), "traffic_raw": int(written + fetch),
+                             "achieved_traffic_raw": round((written + fetch) / sec / 1e9, 1), "frac_traffic_raw": round((written + fetch) / sec / 1e9 / HBM_PEAK_GBS, 4),
+                             "achieved_traffic_read_doubled": round((written + 2 * fetch) / sec / 1e9, 1),
+                             "frac_traffic_read_doubled": round((written + 2 * fetch) / sec / 1e9 / HBM_PEAK_GBS, 4)})
+                if t:
+                    roof["refetch"] = round(fetch / t["unique_scene_bytes_per_frame"], 2)                    # as counted
+                    roof["refetch_read_doubled"] = round(2 * fetch / t["unique_scene_bytes_per_frame"], 2)   # the guide's gfx950 correction of the read side
+                    roof["traffic_over_algorithmic"] = round((written + 2 * fetch) / alg, 2)
+            if probes.get("config5_l2_hit_rate" + tag) is not None:
+                roof["l2_hit_rate"] = round(probes["config5_l2_hit_rate" + tag], 4)
+            if probes.get("config5_lane_utilisation" + tag) is not None:
+                roof["lane_utilisation"] = round(probes["config5_lane_utilisation" + tag], 4)
+                vi = probes["config5_valu_wave_instr_per_frame" + tag]
+                roof["valu_wave_instr_per_frame"] = int(vi)
+                roof["valu_issue_slot_frac"] = round(vi * 2 / (1024 * 2.4e9 * sec), 3)
+            errs = [v for k, v in probes.items() if k.startswith("config5") and k.endswith("error")]
+            roof["counters_source"] = ("FETCH_SIZE, TCC_HIT_sum / TCC_MISS_sum and the SQ counters MEASURED in this invocation: three rocprofv3 --pmc child passes over "
+                                       "`bench.py --probe config5` (the same scene, views and frame size); traffic = written + 2 x fetched (the guide's gfx950 read-side "
+                                       "correction), traffic_raw as counted" if not errs else f"a probe failed: {errs}")
+            c5["roofline"] = roof
+            out[key] = c5
+        except Exception as e:  # noqa: BLE001
+            out[key] = {"error": repr(e)[:300]}
+    return out
 
 
 def measure_config3(Context, Camera, ALL, TIMED, scenes, device, shown=12, live_valu=None):
@@ -910,53 +1101,7 @@ def trace_bench(args):
                 m4["workload"] = f"vox/{SCENE}.vox 3840x2160, 1 spp, {args.bounces} bounces, trace stage, camera 'bench'; {view_batch} frames per launch x {view_inflight} launches in flight"
                 extra["menger_4k"] = m4
             if default_cfg and not args.no_config5:
-                try:
-                    c5cam = scenes.config5_cameras()["outside"]
-                    c5 = dict(
-                        measure_view(Context, Camera, TRACE, None, None, c5cam, device, 8, 1, 1, width=3840, height=2160, frames=24, blocks=5,
-                                     setup=lambda ctx: ctx.set_menger(*scenes.CONFIG5)),
-                        workload="BASELINE configs[4]'s scene (procedural Menger level 7 clipped to 2048^3, 5.6 GB: HBM-resident) at 3840x2160, "
-                                 "8 bounces, one frame per launch, view from outside; one GPU's share is a band set of the 7680x4320 frame")
-                    # the one HBM-relevant config: what it writes (48 B/px) + what its scene gathers fetched from HBM (RECORDED counters)
-                    rec, rec_path = recorded_json("config5_formats_summary.json")
-                    try:
-                        o = rec["formats"]["8-byte records"]["outside"]
-                        fetch = float(o["fetch_size_kb"]) * 1024.0
-                        live_fetch = getattr(args, "live_probes", {}).get("config5_fetch_bytes_per_frame")
-                        if live_fetch:
-                            fetch = float(live_fetch)
-                        written = 48.0 * 3840 * 2160
-                        sec = c5["ms_per_frame"] * 1e-3
-                        c5["roofline"] = {"bound": "hbm", "kernel": "trace_kernel (all-in-one, 6 waves per SIMD)", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                          "bytes_written_per_frame": int(written), "bytes_fetched_per_frame": int(fetch),
-                                          "achieved_raw": round((written + fetch) / sec / 1e9, 1), "frac_raw": round((written + fetch) / sec / 1e9 / HBM_PEAK_GBS, 4),
-                                          "achieved_read_doubled": round((written + 2 * fetch) / sec / 1e9, 1),
-                                          "frac_read_doubled": round((written + 2 * fetch) / sec / 1e9 / HBM_PEAK_GBS, 4),
-                                          "fetch_over_written": round(fetch / written, 2)}
-                        probes = getattr(args, "live_probes", {})
-                        if probes.get("config5_l2_hit_rate") is not None:
-                            c5["roofline"]["l2_hit_rate"] = round(probes["config5_l2_hit_rate"], 4)
-                        else:
-                            c5["roofline"]["l2_hit_rate_recorded"] = o.get("l2_hit_rate")
-                        if probes.get("config5_lane_utilisation") is not None:
-                            c5["roofline"]["lane_utilisation"] = round(probes["config5_lane_utilisation"], 4)
-                            vi = probes["config5_valu_wave_instr_per_frame"]
-                            c5["roofline"]["valu_wave_instr_per_frame"] = int(vi)
-                            c5["roofline"]["valu_issue_slot_frac"] = round(vi * 2 / (1024 * 2.4e9 * sec), 3)
-                        else:
-                            c5["roofline"]["lane_utilisation_recorded"] = o.get("lane_utilisation")
-                        measured = [k for k in ("config5_fetch_bytes_per_frame", "config5_l2_hit_rate", "config5_lane_utilisation") if probes.get(k) is not None]
-                        c5["roofline"]["source"] = (
-                            ("FETCH_SIZE, the L2 hit rate (TCC_HIT_sum / TCC_MISS_sum) and the lane utilisation (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU) MEASURED in this "
-                             "invocation: three rocprofv3 --pmc child passes over `bench.py --probe config5` (the same scene, view and frame size)" if len(measured) == 3 else
-                             f"measured in this invocation: {measured}; the rest quoted from {rec_path} (rocprofv3 --pmc passes of scripts/profile_config5.sh, same scene, "
-                             f"view and frame size, {o.get('avg_ms')} ms per frame there) because a probe failed: {[v for k, v in probes.items() if k.endswith('error')]}") +
-                            "; bytes over this run's frame time; read-doubled = the guide's gfx950 correction of the read side")
-                    except (KeyError, TypeError, ValueError, ZeroDivisionError):
-                        pass
-                    extra["config5_outside_view"] = c5
-                except Exception as e:  # noqa: BLE001 — an extra must never cost the headline line
-                    extra["config5_outside_view"] = {"error": repr(e)}
+                extra.update(measure_config5(Context, Camera, TRACE, scenes, device, getattr(args, "live_probes", {})))
             if default_cfg and not args.no_config3:
                 try:
                     from gpu_voxel_raytracer_amd import ALL
@@ -970,6 +1115,11 @@ def trace_bench(args):
                 except Exception as e:  # noqa: BLE001
                     extra["config4_one_rank_of_8"] = {"error": repr(e)}
             if default_cfg:
+                try:
+                    from gpu_voxel_raytracer_amd import ALL as _ALL
+                    extra["reference_loop"] = measure_reference_loop(Context, Camera, (_ALL, TIMED), scenes, device)
+                except Exception as e:  # noqa: BLE001
+                    extra["reference_loop"] = {"error": repr(e)[:300]}
                 try:
                     extra["parity_check"] = parity_check(Context, Camera, TRACE, scenes, pos, mrgb, cam, device)
                 except Exception as e:  # noqa: BLE001

@@ -14,6 +14,7 @@ SOURCES = ["api_context.hip", "api_scene.hip", "api_trace.hip", "api_frame.hip",
 # tracers 2 (wavefront), 3 (ray queues), 5 (per-lane path refill) and the wide records (two tree levels per 16-byte record)
 VARIANT_SOURCES = ["trace_wavefront.hip", "trace_paths.hip", "trace_pool.hip", "trace_dda.hip"]
 HEADERS = ["ctx.h", "halo_view.h", "kernels.h", "trace_common.h", "trace_tail_body.h", "ray_queue.h", "walk_wide.h", "scene_host.h", "vx_vec.h", os.path.join("..", "..", "include", "vxrt.h"),
+           os.path.join("..", "..", "include", "vxrt_host.h"), os.path.join("..", "..", "include", "vxrt_debug.h"),
            os.path.join("..", "..", "include", "vxrt_detmath.h"),
            os.path.join("..", "..", "include", "vxrt_bluenoise.h")]
 

@@ -38,7 +38,12 @@ void free_images(vxrt_ctx* c) {
         *p = nullptr;
     }
     for (vxrt_ctx::TileSchedule& t : c->schedules)
+    {
         for (uint32_t** p : {&t.cost, &t.order, &t.last_cost, &t.scratch}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        if (t.host_heavy) (void)hipHostFree(t.host_heavy);
+        if (t.heavy_ready) (void)hipEventDestroy(t.heavy_ready);
+        t.host_heavy = nullptr; t.heavy_ready = nullptr;
+    }
     c->schedules.clear();
     for (vxrt_ctx::StreamQueues& sq : c->queues) {
         for (float4** p : {&sq.hitq[0], &sq.hitq[1]}) { if (*p) (void)hipFree(*p); *p = nullptr; }
@@ -142,6 +147,12 @@ int alloc_images(vxrt_ctx* c) {
         }
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t.scratch), 256 * 128 * sizeof(uint32_t)));
         t.valid = false;
+        t.heavy = 0; t.heavy_pending = false;
+        if (c->trace_priority) {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&t.host_heavy), 64, hipHostMallocDefault));
+            t.host_heavy[0] = 0u;
+            HIP_TRY(hipEventCreateWithFlags(&t.heavy_ready, hipEventDisableTiming));
+        }
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->slot = 0;
@@ -275,7 +286,7 @@ int apply_option(vxrt_ctx* c, uint32_t option, uint32_t value, bool at_create) {
         set_error(what); return false;
 #endif
     };
-    switch (option) {
+    switch (int(option)) {
         case VXRT_OPT_DENOISE_MODE:
             if (value > 3) { set_error("denoise mode must be 0 (exact) or 1 (tolerant), + 2 for the generic kernel"); return VXRT_E_INVALID; }
             c->denoise_mode = int(value);
@@ -367,6 +378,11 @@ int apply_option(vxrt_ctx* c, uint32_t option, uint32_t value, bool at_create) {
             if (value != 0 && !needs_variants("the split launch of the longest tiles is not in this build of libvxrt (compile with -DVXRT_VARIANTS=1: it measured slower)")) return VXRT_E_INVALID;
             c->long_tiles_permille = value;
             return VXRT_OK;
+        case VXRT_OPT_TRACE_PRIORITY:   // the streams are made at creation
+            if (!create_only()) return VXRT_E_INVALID;
+            if (value > 1) { set_error("trace priority must be 0 or 1"); return VXRT_E_INVALID; }
+            c->trace_priority = int(value);
+            return VXRT_OK;
         case VXRT_OPT_HEAD_STAGGER:
             if (value > 1) { set_error("head stagger must be 0 or 1"); return VXRT_E_INVALID; }
             if (value != 0 && !needs_variants("the head stagger is not in this build of libvxrt (compile with -DVXRT_VARIANTS=1: it measured slower)")) return VXRT_E_INVALID;
@@ -381,7 +397,7 @@ int apply_option(vxrt_ctx* c, uint32_t option, uint32_t value, bool at_create) {
 
 extern "C" {
 
-uint32_t vxrt_abi_version(void) { return 5; }
+uint32_t vxrt_abi_version(void) { return 6; }   // 6: vxrt_read_async / vxrt_read_wait / vxrt_host_alloc / vxrt_host_free, vxrt_stats.split_launches; the header in three
 uint32_t vxrt_build_features(void) { return VXRT_VARIANTS ? uint32_t(VXRT_FEATURE_VARIANTS) : 0u; }
 
 const char* vxrt_last_error(void) { return vxrt::last_error().c_str(); }
@@ -434,7 +450,7 @@ int vxrt_create_tuned(const vxrt_config* cfg, const vxrt_tuning* tuning, size_t 
     // 16 for a denoise window (its 16 x 16 tiles must not straddle bands: check_render); 8 = the tracer's tile height, what a launch of
     // single frames wants (a wave is an 8 x 8 pixel tile); 2 or 4 rows are for launches of frame groups, whose waves hold 2 rows x 4
     // frames or 1 row x 8 frames (VXRT_OPT_FRAME_LANES): the finer the interleave, the more alike the ranks' shares
-    if (band_rows % 2 != 0 || (band_rows % 8 != 0 && band_rows > 8)) { set_error("band_rows must be 2, 4 or a multiple of 8 (of 16 for a denoise radius > 0)"); return VXRT_E_INVALID; }
+    if (!(band_rows == 2 || band_rows == 4 || band_rows % 8 == 0)) { set_error("band_rows must be 2, 4 or a multiple of 8 (of 16 for a denoise radius > 0)"); return VXRT_E_INVALID; }
 
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -454,7 +470,6 @@ int vxrt_create_tuned(const vxrt_config* cfg, const vxrt_tuning* tuning, size_t 
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) c->wave_slots = unsigned(cus) * 4u * 5u;
     }
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipStreamCreate"));
     if (hipEventCreateWithFlags(&c->halo_event, hipEventDisableTiming) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipEventCreate"));
     c->inflight = cfg->frames_in_flight == 0 ? 1 : int(cfg->frames_in_flight);
     // vxrt_config.tracer: 0 auto, 1 monolithic, 2 wavefront, 3 ray queues, 4 monolithic head + compacted tail (internally
@@ -485,12 +500,30 @@ int vxrt_create_tuned(const vxrt_config* cfg, const vxrt_tuning* tuning, size_t 
     if (c->inflight < 1 || c->inflight > 16) { set_error("frames_in_flight must be 1..16"); return fail(VXRT_E_INVALID); }
     c->batch = cfg->frames_per_launch == 0 ? 1 : int(cfg->frames_per_launch);
     if (c->batch < 1 || c->batch > kMaxBatch) { set_error("frames_per_launch must be 1..32"); return fail(VXRT_E_INVALID); }
+    // VXRT_OPT_TRACE_PRIORITY: the streams that carry trace launches at the device's highest priority (numerically lowest), one
+    // low-priority stream per trace stream for the grid of tiles that only store sky (trace_frames)
+    int prio_least = 0, prio_greatest = 0;
+    if (c->trace_priority) (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    auto make_stream = [&](hipStream_t* st, bool trace) {
+        return (c->trace_priority && trace) ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_greatest) : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    };
+    if (make_stream(&c->stream, c->inflight == 1) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipStreamCreate"));
     c->trace_streams.assign(size_t(c->inflight), nullptr);
     if (c->inflight == 1) {
         c->trace_streams[0] = c->stream;
     } else {
         for (hipStream_t& t : c->trace_streams)
-            if (hipStreamCreateWithFlags(&t, hipStreamNonBlocking) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipStreamCreate"));
+            if (make_stream(&t, true) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipStreamCreate"));
+    }
+    if (c->trace_priority) {
+        c->low_streams.assign(size_t(c->inflight), nullptr);
+        c->low_fork.assign(size_t(c->inflight), nullptr);
+        c->low_join.assign(size_t(c->inflight), nullptr);
+        for (size_t i = 0; i < size_t(c->inflight); i++) {
+            if (hipStreamCreateWithPriority(&c->low_streams[i], hipStreamNonBlocking, prio_least) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipStreamCreateWithPriority"));
+            if (hipEventCreateWithFlags(&c->low_fork[i], hipEventDisableTiming) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipEventCreate"));
+            if (hipEventCreateWithFlags(&c->low_join[i], hipEventDisableTiming) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipEventCreate"));
+        }
     }
     c->launch_events.assign(size_t(c->inflight) * 2, nullptr);
     c->launch_event_turn.assign(size_t(c->inflight), 0u);
@@ -534,6 +567,16 @@ int vxrt_destroy(vxrt_ctx* c) try {
     for (hipEvent_t e : c->aux_fork) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->aux_join) if (e) (void)hipEventDestroy(e);
     for (hipStream_t t : c->aux_streams) if (t) (void)hipStreamDestroy(t);
+    for (hipStream_t t : c->low_streams) if (t) { (void)hipStreamSynchronize(t); (void)hipStreamDestroy(t); }
+    for (hipEvent_t e : c->low_fork) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->low_join) if (e) (void)hipEventDestroy(e);
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    for (vxrt_ctx::ReadSlot& rs : c->read_slots) {
+        if (rs.stage) (void)hipFree(rs.stage);
+        if (rs.snap) (void)hipEventDestroy(rs.snap);
+        if (rs.arrived) (void)hipEventDestroy(rs.arrived);
+    }
+    drop_touch_maps(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return VXRT_OK;
@@ -617,6 +660,76 @@ int vxrt_read(vxrt_ctx* c, vxrt_image which, float* dst, size_t bytes) try {
     return VXRT_OK;
 } VXRT_CATCH
 
+// The non-blocking read-back (vxrt.h).  Order of events for slot k:
+//   context stream:  [wait arrived_k of the slot's previous use] [wait the trace launch, for a trace image] D2D image -> stage_k, record snap_k
+//   copy stream:     wait snap_k, D2H stage_k -> dst, record arrived_k
+// The image itself is free for the next frame as soon as the context stream has passed the D2D copy (33 MB at 1080p: ~0.03 ms of HBM
+// time), the stage is not reused before its transfer has arrived, and the host only ever waits in vxrt_read_wait.
+int vxrt_read_async(vxrt_ctx* c, vxrt_image which, float* dst, size_t bytes, uint32_t slot) try {
+    if (!valid_ctx(c)) return VXRT_E_INVALID;
+    float4* src = image_ptr(c, which);
+    if (!src || !dst) { set_error("bad image or null destination"); return VXRT_E_INVALID; }
+    if (slot > 1) { set_error("vxrt_read_async: slot must be 0 or 1"); return VXRT_E_INVALID; }
+    if (bytes != image_bytes(c)) { set_error("vxrt_read_async: bytes must equal local_rows*width*16"); return VXRT_E_INVALID; }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    vxrt_ctx::ReadSlot& rs = c->read_slots[slot];
+    if (c->copy_stream == nullptr) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (rs.snap == nullptr) {
+        HIP_TRY(hipEventCreateWithFlags(&rs.snap, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&rs.arrived, hipEventDisableTiming));
+    }
+    if (rs.stage_bytes < bytes) {    // first use, or after vxrt_resize: a new stage (the old one's transfer must have arrived)
+        if (rs.in_flight) HIP_TRY(hipEventSynchronize(rs.arrived));
+        rs.in_flight = false;
+        if (rs.stage) (void)hipFree(rs.stage);
+        rs.stage = nullptr; rs.stage_bytes = 0;
+        if (bytes) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&rs.stage), bytes));
+        rs.stage_bytes = bytes;
+    }
+    if (bytes == 0) { rs.in_flight = false; return VXRT_OK; }
+    if (rs.in_flight) HIP_TRY(hipStreamWaitEvent(c->stream, rs.arrived, 0));
+    // a trace output lives in a ring slot written by a trace stream: the context stream waits for that launch (the post stages do the same)
+    const bool trace_image = which == VXRT_SAMPLED_COLOR || which == VXRT_NORMAL_DEPTH || which == VXRT_ALBEDO_NODE || (which == VXRT_ACCUM_COLOR && c->accum_is_sampled);
+    vxrt_ctx::Slot& cur = c->ring[size_t(c->slot)];
+    if (trace_image && cur.trace_done != nullptr) HIP_TRY(hipStreamWaitEvent(c->stream, cur.trace_done, 0));
+    HIP_TRY(hipMemcpyAsync(rs.stage, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipEventRecord(rs.snap, c->stream));
+    if (trace_image) {   // the ring slot may be traced into again only after the snapshot has read it
+        HIP_TRY(hipEventRecord(cur.own, c->stream));
+        cur.last_use = cur.own;
+        cur.last_use_recorded = true;
+    }
+    HIP_TRY(hipStreamWaitEvent(c->copy_stream, rs.snap, 0));
+    HIP_TRY(hipMemcpyAsync(dst, rs.stage, bytes, hipMemcpyDeviceToHost, c->copy_stream));
+    HIP_TRY(hipEventRecord(rs.arrived, c->copy_stream));
+    rs.in_flight = true;
+    return VXRT_OK;
+} VXRT_CATCH
+
+int vxrt_read_wait(vxrt_ctx* c, uint32_t slot) try {
+    if (!valid_ctx(c)) return VXRT_E_INVALID;
+    if (slot > 1) { set_error("vxrt_read_wait: slot must be 0 or 1"); return VXRT_E_INVALID; }
+    vxrt_ctx::ReadSlot& rs = c->read_slots[slot];
+    if (!rs.in_flight) return VXRT_OK;          // nothing was asked for (or it has been waited for already)
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipEventSynchronize(rs.arrived));
+    rs.in_flight = false;
+    return VXRT_OK;
+} VXRT_CATCH
+
+int vxrt_host_alloc(size_t bytes, void** out) try {
+    if (!out) { set_error("null argument"); return VXRT_E_INVALID; }
+    *out = nullptr;
+    if (bytes == 0) return VXRT_OK;
+    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return VXRT_OK;
+} VXRT_CATCH
+
+int vxrt_host_free(void* p) try {
+    if (p) HIP_TRY(hipHostFree(p));
+    return VXRT_OK;
+} VXRT_CATCH
+
 int vxrt_device_image(vxrt_ctx* c, vxrt_image which, void** device_ptr, size_t* bytes) try {
     if (!valid_ctx(c) || !device_ptr) { set_error("null argument"); return VXRT_E_INVALID; }
     float4* src = image_ptr(c, which);
@@ -658,6 +771,7 @@ int vxrt_get_stats(vxrt_ctx* c, vxrt_stats* out) try {
     out->halo_exchanges = c->halo_exchanges;
     out->cull_box_valid = c->box_valid ? 1u : 0u;
     out->frame_lane_launches = c->frame_lane_launches;
+    out->split_launches = uint32_t(c->split_launches);
     memcpy(out->cull_box_min, c->box_min, sizeof c->box_min);
     memcpy(out->cull_box_max, c->box_max, sizeof c->box_max);
     out->timed_frames = c->timed_frames;
@@ -689,6 +803,7 @@ int vxrt_reset_stats(vxrt_ctx* c) try {
     c->ms[0] = c->ms[1] = c->ms[2] = c->ms[3] = c->ms[4] = 0.0;
     c->halo_exchanges = 0;
     c->frame_lane_launches = 0;
+    c->split_launches = 0;
     return VXRT_OK;
 } VXRT_CATCH
 

@@ -183,30 +183,27 @@ int vxrt_debug_culled_pixels(vxrt_ctx* c, uint64_t* count) try {
 } VXRT_CATCH
 
 #if VXRT_VARIANTS
-// PROTOTYPE (round 5, csrc/trace_dda.hip): the same rays through the exact walk (cast_probe_kernel) and through the two-level DDA over a
-// caller-built dense bit grid, both timed with HIP events (second of two launches each).  bricks: 8 words per 8^3 brick; brick_bits:
-// one bit per brick; leaf: one word per cell; levels: log2 of the cells (leaf octants) per axis = the tree's depth + 1.  out_*: 8 floats per ray =
-// hit, time, bits(leaf word), normal xyz, flagged, steps.  ms[0] = walk, ms[1] = DDA.
-int vxrt_debug_dda_rays(vxrt_ctx* c, const uint64_t* bricks, const uint32_t* brick_bits, const int32_t* leaf, int32_t levels, const float* origins,
-                        const float* dirs, size_t n, int32_t certify, float margin_scale, float* out_walk, float* out_dda, double ms[2]) try {
-    if (!valid_ctx(c) || !bricks || !brick_bits || !leaf || !origins || !dirs || !out_walk || !out_dda || !ms) { set_error("null argument"); return VXRT_E_INVALID; }
+// PROTOTYPE (csrc/trace_dda.hip; -DVXRT_VARIANTS=1 builds only): the same rays through the exact walk (cast_probe_kernel over the
+// context's scene format) and through the three-level DDA over a bit grid that is built on the device from the scene in place (first
+// call; kept until the scene changes), both timed with HIP events (the second of two launches each).  flags: bit 0 = the certificate,
+// bit 1 = the super-brick bits staged in LDS, bit 2 = skip the walk (out_walk untouched, ms[0] = 0), bit 3 = skip the DDA (no grid is built: for timing the walk of a
+// wide-record context on the same rays).  max_steps: the DDA gives a ray
+// up (flags it) beyond that many steps.  out_*: 8 floats per ray = hit, time, bits(leaf word), normal xyz, flagged, steps.
+// ms[0] = walk, ms[1] = DDA, ms[2] = the grid's build (0 when it was there), ms[3] = its bytes.  origins / dirs / out_*: HOST arrays.
+int vxrt_debug_dda_rays(vxrt_ctx* c, const float* origins, const float* dirs, size_t n, uint32_t flags, float margin_scale, uint32_t max_steps,
+                        float* out_walk, float* out_dda, double ms[4]) try {
+    if (!valid_ctx(c) || !origins || !dirs || !out_dda || !ms || (!out_walk && !(flags & 4u))) { set_error("null argument"); return VXRT_E_INVALID; }
     if (!c->has_scene) { set_error("no scene set"); return VXRT_E_NOSCENE; }
-    if (levels < 3 || levels > 9 || uint32_t(levels) != c->depth + 1u) { set_error("levels must be the tree's depth + 1 (3..9): the leaf octants per axis are 2 << depth"); return VXRT_E_INVALID; }
+    const int levels = int(c->depth) + 1;
+    if (levels < 3 || levels > 12) { set_error("the DDA grid wants a tree of depth 2..11 (4 .. 4096 cells per axis)"); return VXRT_E_INVALID; }
     if (n == 0) return VXRT_OK;
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = vxrt_sync(c)) return rc;
-    const size_t cells = size_t(1) << (3 * levels), nbricks = cells >> 9;
-    ScratchBuffer b_o, b_d, b_w, b_x, b_br, b_bb, b_lf;
-    HIP_TRY(b_o.alloc(n * 12)); HIP_TRY(b_d.alloc(n * 12)); HIP_TRY(b_w.alloc(n * 32)); HIP_TRY(b_x.alloc(n * 32));
-    HIP_TRY(b_br.alloc(nbricks * 64)); HIP_TRY(b_bb.alloc((nbricks + 31) / 32 * 4)); HIP_TRY(b_lf.alloc(cells * 4));
-    HIP_TRY(hipMemcpy(b_o.as<float>(), origins, n * 12, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(b_d.as<float>(), dirs, n * 12, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(b_br.as<char>(), bricks, nbricks * 64, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(b_bb.as<char>(), brick_bits, (nbricks + 31) / 32 * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(b_lf.as<char>(), leaf, cells * 4, hipMemcpyHostToDevice));
     TraceArgs a{};
     a.svo = c->d_svo; a.leaves = c->d_leaves;
     a.root_rec = c->root_rec;
+    a.wide = c->d_wide;
+    a.wide_root = c->wide_root;
     a.node_levels = int(c->depth) + 1;
     memcpy(a.root_center, c->root_center, sizeof a.root_center);
     a.root_size = c->root_size;
@@ -214,27 +211,121 @@ int vxrt_debug_dda_rays(vxrt_ctx* c, const uint64_t* bricks, const uint32_t* bri
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     float t = 0.0f;
-    for (int rep = 0; rep < 2; rep++) {
+    ms[0] = ms[1] = ms[2] = ms[3] = 0.0;
+    size_t sz[4] = {0, 0, 0, 0};
+    dda_grid_sizes(levels, &sz[0], &sz[1], &sz[2], &sz[3]);
+    const bool dda = !(flags & 8u);
+    if (dda && (c->dda_grid[0] == nullptr || c->dda_levels != levels)) {
+        drop_touch_maps(c);
+        for (int k = 0; k < 4; k++) {
+            if (sz[k] == 0) continue;
+            HIP_TRY(hipMalloc(&c->dda_grid[k], sz[k]));
+            HIP_TRY(hipMemsetAsync(c->dda_grid[k], 0, sz[k], c->stream));
+        }
         HIP_TRY(hipEventRecord(e0, c->stream));
-        HIP_TRY(launch_cast_probe(a, false, b_o.as<float>(), b_d.as<float>(), b_w.as<float>(), unsigned(n), c->stream));
+        HIP_TRY(launch_dda_build(a, levels, c->dda_grid[0], c->dda_grid[1], c->dda_grid[2], c->dda_grid[3], c->stream));
         HIP_TRY(hipEventRecord(e1, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipEventElapsedTime(&t, e0, e1));
-        ms[0] = double(t);
+        ms[2] = double(t);
+        c->dda_levels = levels;
+    }
+    ms[3] = double(sz[0] + sz[1] + sz[2] + sz[3]);
+    ScratchBuffer b_o, b_d, b_w, b_x;
+    HIP_TRY(b_o.alloc(n * 12)); HIP_TRY(b_d.alloc(n * 12)); HIP_TRY(b_w.alloc(n * 32)); HIP_TRY(b_x.alloc(n * 32));
+    HIP_TRY(hipMemcpy(b_o.as<float>(), origins, n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b_d.as<float>(), dirs, n * 12, hipMemcpyHostToDevice));
+    for (int rep = 0; rep < 2; rep++) {
+        if (!(flags & 4u)) {
+            HIP_TRY(hipEventRecord(e0, c->stream));
+            HIP_TRY(launch_cast_probe(a, use_wide(c), b_o.as<float>(), b_d.as<float>(), b_w.as<float>(), unsigned(n), c->stream));
+            HIP_TRY(hipEventRecord(e1, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+            ms[0] = double(t);
+        }
+        if (!dda) continue;
         HIP_TRY(hipEventRecord(e0, c->stream));
-        HIP_TRY(launch_dda_probe(a, b_br.as<char>(), b_bb.as<char>(), b_lf.as<char>(), levels, b_o.as<float>(), b_d.as<float>(), b_x.as<float>(), unsigned(n), certify,
-                                 margin_scale, c->stream));
+        HIP_TRY(launch_dda_probe(a, c->dda_grid[0], c->dda_grid[1], c->dda_grid[2], c->dda_grid[3], levels, b_o.as<float>(), b_d.as<float>(), b_x.as<float>(),
+                                 unsigned(n), int(flags & 1u), margin_scale, max_steps, int((flags >> 1) & 1u), c->stream));
         HIP_TRY(hipEventRecord(e1, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipEventElapsedTime(&t, e0, e1));
         ms[1] = double(t);
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    HIP_TRY(hipMemcpy(out_walk, b_w.as<float>(), n * 32, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(out_dda, b_x.as<float>(), n * 32, hipMemcpyDeviceToHost));
+    if (!(flags & 4u)) HIP_TRY(hipMemcpy(out_walk, b_w.as<float>(), n * 32, hipMemcpyDeviceToHost));
+    if (dda) HIP_TRY(hipMemcpy(out_dda, b_x.as<float>(), n * 32, hipMemcpyDeviceToHost));
     return VXRT_OK;
 } VXRT_CATCH
 #endif
+
+}  // extern "C"
+// ---- touch map (vxrt_debug.h): which 64-byte lines of the scene does a frame read? ---------------------------------------------
+namespace {
+// set bits of a bitmap, at one bit per line (out[0]) and with neighbouring pairs of lines folded (128-byte lines, out[1])
+__global__ __launch_bounds__(256) void touch_count_kernel(const uint32_t* map, size_t words, unsigned long long* out) {
+    unsigned long long n64 = 0, n128 = 0;
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < words; i += size_t(gridDim.x) * 256) {
+        const uint32_t w = map[i];
+        n64 += unsigned(__popc(w));
+        n128 += unsigned(__popc((w | (w >> 1)) & 0x55555555u));
+    }
+    for (int off = 32; off > 0; off >>= 1) { n64 += __shfl_down(n64, off, 64); n128 += __shfl_down(n128, off, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(out, n64); atomicAdd(out + 1, n128); }
+}
+}  // namespace
+extern "C" {
+
+int vxrt_debug_touch_map(vxrt_ctx* c, uint32_t enable) try {
+    if (!valid_ctx(c)) return VXRT_E_INVALID;
+#if !VXRT_VARIANTS
+    (void)enable;
+    set_error("the touch map is not in this build of libvxrt (compile with -DVXRT_VARIANTS=1)");
+    return VXRT_E_INVALID;
+#else
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = vxrt_sync(c)) return rc;
+    for (uint32_t** p : {&c->d_touch_nodes, &c->d_touch_leaves}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    c->touch_node_lines = c->touch_leaf_lines = 0;
+    if (!enable) return VXRT_OK;
+    if (!c->has_scene) { set_error("no scene set"); return VXRT_E_NOSCENE; }
+    const size_t node_bytes = use_wide(c) ? c->wide_count * sizeof(WideRec) : c->svo_count * sizeof(SvoRecord);
+    c->touch_node_lines = (node_bytes + 63) / 64;
+    c->touch_leaf_lines = (c->leaf_count * sizeof(int32_t) + 63) / 64;
+    const size_t wn = (c->touch_node_lines + 31) / 32 + 1, wl = (c->touch_leaf_lines + 31) / 32 + 1;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_touch_nodes), wn * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_touch_leaves), wl * 4));
+    HIP_TRY(hipMemsetAsync(c->d_touch_nodes, 0, wn * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_touch_leaves, 0, wl * 4, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VXRT_OK;
+#endif
+} VXRT_CATCH
+
+int vxrt_debug_touch_count(vxrt_ctx* c, uint64_t out[6], uint32_t reset) try {
+    if (!valid_ctx(c) || !out) { set_error("null argument"); return VXRT_E_INVALID; }
+    if (c->d_touch_nodes == nullptr) { set_error("no touch map (vxrt_debug_touch_map(ctx, 1) first; -DVXRT_VARIANTS=1 builds only)"); return VXRT_E_INVALID; }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = vxrt_sync(c)) return rc;
+    ScratchBuffer b;
+    HIP_TRY(b.alloc(4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(b.p, 0, 4 * sizeof(unsigned long long), c->stream));
+    const size_t wn = (c->touch_node_lines + 31) / 32 + 1, wl = (c->touch_leaf_lines + 31) / 32 + 1;
+    hipLaunchKernelGGL(touch_count_kernel, dim3(1024), dim3(256), 0, c->stream, c->d_touch_nodes, wn, b.as<unsigned long long>());
+    hipLaunchKernelGGL(touch_count_kernel, dim3(1024), dim3(256), 0, c->stream, c->d_touch_leaves, wl, b.as<unsigned long long>() + 2);
+    HIP_TRY(hipGetLastError());
+    if (reset) {
+        HIP_TRY(hipMemsetAsync(c->d_touch_nodes, 0, wn * 4, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_touch_leaves, 0, wl * 4, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(h, b.p, sizeof h, hipMemcpyDeviceToHost));
+    out[0] = h[0]; out[1] = h[2]; out[2] = h[1]; out[3] = h[3];
+    out[4] = c->touch_node_lines; out[5] = c->touch_leaf_lines;
+    return VXRT_OK;
+} VXRT_CATCH
 
 // Diagnostics of the last fused launch of trace stream 0 (VXRT_OPT_FUSED_TAIL; trace.hip: FusedCtl::prof; every 64th wave reports):
 // out[0] ticks of the 100 MHz clock from the first wave's start to the moment every head block was finished, out[1] ... to the last wave's end, out[2] / out[3] chunks taken

@@ -160,6 +160,7 @@ int upload_svo(vxrt_ctx* c, std::vector<SvoRecord>& recs, std::vector<int32_t>& 
     if (c->d_svo) (void)hipFree(c->d_svo);
     if (c->d_leaves) (void)hipFree(c->d_leaves);
     if (c->d_wide) (void)hipFree(c->d_wide);
+    drop_touch_maps(c);
     c->d_svo = nullptr;
     c->d_leaves = nullptr;
     c->d_wide = nullptr;
@@ -252,6 +253,7 @@ int vxrt_set_menger(vxrt_ctx* c, uint32_t level, uint32_t clip, const uint8_t mr
         if (c->d_svo) (void)hipFree(c->d_svo);
         if (c->d_leaves) (void)hipFree(c->d_leaves);
         if (c->d_wide) (void)hipFree(c->d_wide);
+        drop_touch_maps(c);
         c->d_svo = svo; c->d_leaves = lw; c->d_wide = nullptr;
         c->svo_count = nsvo; c->leaf_count = nlw; c->wide_count = 0;
         c->root_rec = root;

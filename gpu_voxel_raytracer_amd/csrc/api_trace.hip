@@ -96,6 +96,10 @@ void frame_constants(const vxrt_ctx* c, TraceArgs& a) {
     a.block_first = 0;
     a.cull = 0;
     a.stack_levels = c->depth < 1 ? 1 : int(c->depth);
+#if VXRT_VARIANTS
+    a.touch_nodes = c->d_touch_nodes;
+    a.touch_leaves = c->d_touch_leaves;
+#endif
     // voxels.comp:296 and the other per-frame constants, evaluated once with the same operations
     f3 sun_dir = mk3(vx_cos(u.sun_yaw) * vx_cos(u.sun_pitch), -vx_sin(u.sun_pitch), vx_sin(u.sun_yaw) * vx_cos(u.sun_pitch));
     f3 sun_n = norm3(sun_dir), neg_sun_n = norm3(-sun_dir);
@@ -133,6 +137,31 @@ void set_cull(const vxrt_ctx* c, TraceArgs& a, const Cam* cams, uint32_t g) {
             a.cull = 1;
         }
     }
+}
+
+// One launch of trace_kernel over all tiles — or, with VXRT_OPT_TRACE_PRIORITY and a tile order whose walking tiles are known, as TWO
+// grids: the tiles that walk (the first `heavy` of the plain longest-first order) on the high-priority trace stream, the tiles that
+// only store sky on the lane's low-priority stream, forked and joined by events, so that the dispatcher takes blocks of the long
+// chains first whenever both grids have blocks waiting.  Same blocks, same arithmetic.
+static int launch_trace_split(vxrt_ctx* c, const TraceArgs& a, bool wide, bool hbm, hipStream_t ts, size_t lane, unsigned g, unsigned first = 0) {
+    vxrt_ctx::TileSchedule& sched = c->schedules[lane];
+    if (c->trace_priority && sched.heavy_pending && hipEventQuery(sched.heavy_ready) == hipSuccess) {
+        sched.heavy = sched.host_heavy[0];
+        sched.heavy_pending = false;
+    }
+    const unsigned tiles = trace_tile_count(c->band.width, c->band.local_rows);
+    const unsigned heavy = (c->trace_priority && a.tile_order != nullptr && !sched.heavy_pending && first == 0) ? sched.heavy : 0u;
+    if (heavy == 0u || heavy >= tiles) {
+        HIP_TRY(launch_trace(a, wide, hbm, ts, first, 0u));
+        return VXRT_OK;
+    }
+    HIP_TRY(hipEventRecord(c->low_fork[lane], ts));                         // after everything this launch waits for
+    HIP_TRY(hipStreamWaitEvent(c->low_streams[lane], c->low_fork[lane], 0));
+    HIP_TRY(launch_trace(a, wide, hbm, ts, 0u, heavy * g));                  // high priority: the chains
+    HIP_TRY(launch_trace(a, wide, hbm, c->low_streams[lane], heavy * g, 0u));   // low priority: the stores
+    HIP_TRY(hipEventRecord(c->low_join[lane], c->low_streams[lane]));
+    c->split_launches++;
+    return VXRT_OK;
 }
 
 // The trace stage of the next g frames (parameters at rest) as ONE launch of the tracer: g ring slots, frame numbers
@@ -306,7 +335,7 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
                     HIP_TRY(hipEventRecord(c->aux_join[lane], c->aux_streams[lane]));
                 }
 #endif
-                HIP_TRY(launch_trace(a, use_wide(c) && c->trace_variant == 4, scene_bytes > (size_t(256) << 20), ts, long_blocks, 0u));
+                if (int rc = launch_trace_split(c, a, use_wide(c) && c->trace_variant == 4, scene_bytes > (size_t(256) << 20), ts, lane, g, long_blocks)) return rc;
 #if VXRT_VARIANTS
                 if (c->head_stagger) {
                     HIP_TRY(hipEventRecord(c->head_events[lane], ts));
@@ -346,15 +375,24 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
                 if (long_blocks != 0u) HIP_TRY(hipStreamWaitEvent(ts, c->aux_join[lane], 0));   // the launch is over when both grids are
                 }   // !fused_done
             } else {
-                HIP_TRY(launch_trace(a, use_wide(c), scene_bytes > (size_t(256) << 20), ts));
+                if (int rc = launch_trace_split(c, a, use_wide(c), scene_bytes > (size_t(256) << 20), ts, lane, g)) return rc;
                 if (a.frame_lanes && !use_wide(c) && scene_bytes <= (size_t(256) << 20)) c->frame_lane_launches++;
             }
+            if (c->trace_priority) HIP_TRY(hipStreamWaitEvent(ts, c->low_join[lane], 0));   // the launch is over when both grids are (a no-op before the first split)
             if (timed) HIP_TRY(hipEventRecord(p.b, ts));
             // Re-sort the tiles for this stream's coming frames from the costs just measured: after its first
             // frame, then every 8th (costs keep accumulating as a running maximum in between; ~7 us per sort).
             if (c->use_tile_order && (!sched.valid || sched.age >= 8)) {
                 const unsigned tiles = trace_tile_count(c->band.width, c->band.local_rows);
-                HIP_TRY(launch_tile_order(sched.cost, sched.order, sched.last_cost, sched.scratch, tiles, g * unsigned(c->inflight), c->wave_slots, c->spread_override, ts));
+                // (the priority split needs the walking tiles FIRST in the order: no spreading; and their number on the host)
+                HIP_TRY(launch_tile_order(sched.cost, sched.order, sched.last_cost, sched.scratch, tiles, g * unsigned(c->inflight), c->wave_slots,
+                                          c->trace_priority ? 0 : c->spread_override, ts));
+                if (c->trace_priority) {
+                    if (sched.heavy_pending) HIP_TRY(hipEventSynchronize(sched.heavy_ready));
+                    HIP_TRY(hipMemcpyAsync(sched.host_heavy, sched.scratch + 128 * 64, sizeof(unsigned), hipMemcpyDeviceToHost, ts));
+                    HIP_TRY(hipEventRecord(sched.heavy_ready, ts));
+                    sched.heavy_pending = true;
+                }
                 sched.valid = true;
                 sched.age = 0;
             }

@@ -19,6 +19,8 @@
 #include <vector>
 
 #include "../../include/vxrt.h"
+#include "../../include/vxrt_debug.h"
+#include "../../include/vxrt_host.h"
 #include "kernels.h"
 #include "scene_host.h"
 
@@ -190,6 +192,12 @@ struct vxrt_ctx {
         uint32_t* scratch = nullptr;    // per-block histograms of the sort (256 x 128)
         bool valid = false;
         int age = 0;  // frames traced since the last sort
+        // VXRT_OPT_TRACE_PRIORITY: how many tiles of `order` walk (they come first: the order is plain longest-first then), read back
+        // after every sort; 0 = not known (yet): the launch goes out as one grid
+        unsigned* host_heavy = nullptr;     // pinned
+        hipEvent_t heavy_ready = nullptr;
+        bool heavy_pending = false;
+        unsigned heavy = 0;
     };
     std::vector<TileSchedule> schedules;
     int last_schedule = 0;
@@ -210,9 +218,42 @@ struct vxrt_ctx {
     double ms[5] = {0, 0, 0, 0, 0};   // trace, temporal, denoise, halo pack, halo unpack
     uint64_t halo_exchanges = 0;
     std::vector<EventPair> pending, free_pairs;
+
+    // vxrt_read_async (api_context.hip): a copy stream of the context's own, two slots; a slot = a device-side snapshot of the image
+    // (so that later frames may overwrite the image while the snapshot travels) + "snapshot taken" / "transfer arrived" events
+    struct ReadSlot {
+        float4* stage = nullptr;
+        size_t stage_bytes = 0;
+        hipEvent_t snap = nullptr, arrived = nullptr;
+        bool in_flight = false;
+    };
+    hipStream_t copy_stream = nullptr;
+    ReadSlot read_slots[2];
+
+    // VXRT_OPT_TRACE_PRIORITY (round 6's experiment): the trace streams at the device's highest priority, the tiles that only store
+    // sky as a grid of their own on a low-priority stream per trace stream
+    int trace_priority = 0;
+    uint64_t split_launches = 0;        // trace launches that went out as two grids
+    std::vector<hipStream_t> low_streams;
+    std::vector<hipEvent_t> low_fork, low_join;
+
+    // touch map (vxrt_debug_touch_map; -DVXRT_VARIANTS=1 builds): one bit per 64-byte line of the node records / the leaf words
+    uint32_t* d_touch_nodes = nullptr;
+    uint32_t* d_touch_leaves = nullptr;
+    size_t touch_node_lines = 0, touch_leaf_lines = 0;
+    // the DDA prototype's grid of the scene in place (vxrt_debug_dda_rays; -DVXRT_VARIANTS=1 builds): bricks, brick bits, super-brick bits, first leaf per brick
+    void* dda_grid[4] = {nullptr, nullptr, nullptr, nullptr};
+    int dda_levels = 0;
 };
 
 namespace vxrt {
+// a new scene: the touch maps were sized for the old one (vxrt_debug_touch_map)
+inline void drop_touch_maps(vxrt_ctx* c) {
+    for (uint32_t** p : {&c->d_touch_nodes, &c->d_touch_leaves}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    c->touch_node_lines = c->touch_leaf_lines = 0;
+    for (void*& g : c->dda_grid) { if (g) (void)hipFree(g); g = nullptr; }   // ... and so was the DDA prototype's grid
+    c->dda_levels = 0;
+}
 // ---- api_context.hip
 size_t image_bytes(const vxrt_ctx* c);
 int count_local_rows(const BandMap& b);

@@ -147,6 +147,13 @@ struct TraceArgs {
     int frame_lanes;       // trace_kernel: 0, or the frames a wave holds: 8 (of a row of 8 pixels) or 4 (of two rows) — one camera for the launch, whole groups
     int cull;
     float cull_min[3], cull_max[3];
+#if VXRT_VARIANTS
+    // Touch map (vxrt_debug_touch_map; -DVXRT_VARIANTS=1 only): when set, every scene load of the walk marks the 64-byte line it reads —
+    // bit (index * record bytes) >> 6 of touch_nodes for a node record (8-byte or wide), of touch_leaves for a leaf word — so that the
+    // unique bytes a frame touches ("bricks actually touched") can be counted.  null: off (every timed run).
+    uint32_t* touch_nodes;
+    uint32_t* touch_leaves;
+#endif
 };
 
 // The rows of the neighbouring ranks that this rank can see (multi-rank: api_halo.hip, halo.hip).  Two messages are kept, side 0 =
@@ -216,8 +223,12 @@ struct RayQueue {
 // hbm_scene: the kernel compiled for one more wave per SIMD (a scene beyond the Infinity Cache)
 // head and compacted tail of a launch as one grid of `waves` persistent waves (trace.hip: fused_kernel); ctl: fused_ctl_bytes() of zeros
 size_t fused_ctl_bytes();
-hipError_t launch_dda_probe(const TraceArgs& a, const void* bricks, const void* brick_bits, const void* leaf, int levels, const float* origins,
-                            const float* dirs, float* out, unsigned n, int certify, float margin_scale, hipStream_t s);   // trace_dda.hip (variants build)
+// trace_dda.hip (variants build): the DDA prototype's grid, built on the device from the 8-byte records, and its probe kernel
+void dda_grid_sizes(int levels, size_t* brick_bytes, size_t* brick_bit_bytes, size_t* super_bit_bytes, size_t* first_leaf_bytes);
+hipError_t launch_dda_build(const TraceArgs& a, int levels, void* bricks, void* brick_bits, void* super_bits, void* first_leaf, hipStream_t s);
+hipError_t launch_dda_probe(const TraceArgs& a, const void* bricks, const void* brick_bits, const void* super_bits, const void* first_leaf, int levels,
+                            const float* origins, const float* dirs, float* out, unsigned n, int certify, float margin_scale, unsigned max_steps, int lds_top,
+                            hipStream_t s);
 size_t fused_ctl_error_offset();
 size_t fused_ctl_profile_offset();
 hipError_t launch_fused(const TraceArgs& a, void* ctl, unsigned waves, const uint32_t* sort_scratch, uint32_t stamp, hipStream_t s);

@@ -8,6 +8,8 @@
 #include <vector>
 
 #include "../../include/vxrt.h"
+#include "../../include/vxrt_debug.h"
+#include "../../include/vxrt_host.h"
 
 namespace vxrt {
 

@@ -50,7 +50,24 @@ struct SceneView {
     float root_size;
     float cell, inv_cell;  // edge of the finest cell a node's octant can be (root_size * 2^-levels), and its reciprocal
     int levels;            // node levels 0 .. levels-1
+#if VXRT_VARIANTS
+    uint32_t* touch_nodes;   // TraceArgs::touch_nodes / touch_leaves (null: off)
+    uint32_t* touch_leaves;
+#endif
 };
+
+// Touch map (variants build only; TraceArgs::touch_nodes): mark the 64-byte line `line` of a scene array as read.  The test before the
+// atomic keeps the map's own traffic down (a stale read only costs a redundant atomic).  Compiles to nothing in the product.
+#if VXRT_VARIANTS
+__device__ __forceinline__ void touch_line(uint32_t* map, uint32_t line) {
+    if (map == nullptr) return;
+    const uint32_t bit = 1u << (line & 31u);
+    if ((__builtin_nontemporal_load(map + (line >> 5)) & bit) == 0u) atomicOr(map + (line >> 5), bit);
+}
+#define VX_TOUCH(map, line) touch_line(map, line)
+#else
+#define VX_TOUCH(map, line) ((void)0)
+#endif
 
 // cast_bounded_ray, voxels.comp:134-247.  `stack` points at this thread's column of the LDS stack
 // (entry l at stack[l * kStackStride]).  On the iteration cap the shader returns true without writing the
@@ -125,6 +142,7 @@ __device__ __forceinline__ int walk_step(Walk& w, const SceneView& sc, float max
                 w.has_next_mask |= 1u << w.lvl;
             }
             raw = *reinterpret_cast<const uint2*>(sc.svo + (w.rec.base + __popc(w.rec.masks & (bit - 1u))));
+            VX_TOUCH(sc.touch_nodes, (w.rec.base + __popc(w.rec.masks & (bit - 1u))) >> 3);
             w.ix = (w.ix << 1) | ((w.octant >> 2) & 1u);
             w.iy = (w.iy << 1) | ((w.octant >> 1) & 1u);
             w.iz = (w.iz << 1) | (w.octant & 1u);
@@ -275,6 +293,7 @@ __device__ __forceinline__ void walkf_locate(WalkF& w, const SceneView& sc, uint
         stack[l * kStackStride] = make_uint2(rec.masks | (oct ^ transition) << 16, rec.base);   // read back only if has_next
         mask |= (has_next ? 1u : 0u) << l;
         const uint2 raw = *reinterpret_cast<const uint2*>(sc.svo + (rec.base + __popc(rec.masks & (bit - 1u))));
+        VX_TOUCH(sc.touch_nodes, (rec.base + __popc(rec.masks & (bit - 1u))) >> 3);
         ex = mk3(far_x ? ex.x : tm.x, far_y ? ex.y : tm.y, far_z ? ex.z : tm.z);
         exit = vx_min3(ex.x, ex.y, ex.z);
         center = center + mk3(bx ? quarter : -quarter, by ? quarter : -quarter, bz ? quarter : -quarter);   // exact
@@ -315,6 +334,7 @@ __device__ __forceinline__ int walkf_step(WalkF& w, const SceneView& sc, uint2* 
     uint2 early = make_uint2(0u, 0u);
     if ((w.rec.masks & bit) != 0u) {
         early = *reinterpret_cast<const uint2*>(sc.svo + (w.rec.base + __popc(w.rec.masks & (bit - 1u))));
+        VX_TOUCH(sc.touch_nodes, (w.rec.base + __popc(w.rec.masks & (bit - 1u))) >> 3);
         asm volatile("" ::: "memory");   // the load is issued here (nothing that touches memory moves across), waited for where it is used
     }
 #endif
@@ -343,6 +363,7 @@ __device__ __forceinline__ int walkf_step(WalkF& w, const SceneView& sc, uint2* 
             raw = early;
 #else
             raw = *reinterpret_cast<const uint2*>(sc.svo + (w.rec.base + __popc(w.rec.masks & (bit - 1u))));
+            VX_TOUCH(sc.touch_nodes, (w.rec.base + __popc(w.rec.masks & (bit - 1u))) >> 3);
 #endif
             w.ix = (w.ix << 1) | ((w.octant >> 2) & 1u);
             w.iy = (w.iy << 1) | ((w.octant >> 1) & 1u);
@@ -406,6 +427,7 @@ __device__ __forceinline__ bool finish_ray(const SceneView& sc, int status, f3 o
         return true;
     }
     hit.node = sc.leaves[leaf_index];
+    VX_TOUCH(sc.touch_leaves, leaf_index >> 4);
     const float size = __builtin_ldexpf(sc.root_size, -int(lvl));
     f3 delta = mk3(float((octant >> 2) & 1u), float((octant >> 1) & 1u), float(octant & 1u));
     f3 oc = center + (0.5f * size) * (delta - splat3(0.5f));
@@ -687,6 +709,10 @@ __device__ __forceinline__ SceneView make_scene(const TraceArgs& a) {
     sc.levels = a.stack_levels;
     sc.cell = __builtin_ldexpf(a.root_size, -a.stack_levels);
     sc.inv_cell = 1.0f / sc.cell;
+#if VXRT_VARIANTS
+    sc.touch_nodes = a.touch_nodes;
+    sc.touch_leaves = a.touch_leaves;
+#endif
     return sc;
 }
 

@@ -23,12 +23,65 @@
 namespace vxrt {
 namespace {
 
+// Round 6: the grid is built ON THE DEVICE from the scene in place (dda_build_kernel below: one thread per brick descends the 8-byte
+// records along the brick's coordinates), so that the prototype also runs on BASELINE config 5's 2048^3 scene (512^3 bricks, 8.6 GB of
+// address space of which the sponge's octant, 1 GiB, is populated).  Three levels now: one bit per 64^3-cell SUPER-BRICK (32 KB for
+// config 5: optionally staged in LDS, north_star's "LDS-staged"), one bit per 8^3 brick, 64 bytes per brick.  No dense leaf array any
+// more: the leaves of a brick's subtree are one run of the tree's breadth-first leaf array, in exactly the order of the brick's 512
+// mask bits, so a hit's leaf word is leaves[first_leaf[brick] + popcount(mask bits below the cell's)].
 struct DdaGrid {
     const unsigned long long* bricks;   // per 8^3 brick 8 words: word = the brick's 4^3 octant (x>>2, y>>2, z>>2), byte = the 2^3 node inside it, bit = the cell
     const uint32_t* brick_bits;         // one bit per brick: holds a voxel
-    const int32_t* leaf;                // leaf word per cell (dense)
+    const uint32_t* super_bits;         // one bit per super-brick of 8^3 bricks (64^3 cells); null: levels < 6
+    const uint32_t* first_leaf;         // per brick: index of its first leaf word in `leaves`
+    const int32_t* leaves;              // the scene's leaf words (breadth-first order)
     int levels;                         // cells (leaf octants) per axis = 1 << levels = 2 << depth
 };
+
+// One thread per brick: descend the SVO from the root along the brick's coordinates (levels - 3 records), then gather the leaf masks
+// of the up to 64 leaf parents below the brick's node into its 8 words.  slot = 4 x + 2 y + z (src/context.rs:726-729) at every level,
+// which is also the bit order of cell_bit_index.
+__global__ __launch_bounds__(256) void dda_build_kernel(const SvoRecord* svo, SvoRecord root, int levels, unsigned long long* bricks, uint32_t* brick_bits,
+                                                         uint32_t* super_bits, uint32_t* first_leaf) {
+    const unsigned nb = 1u << (levels - 3);
+    const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= size_t(nb) * nb * nb) return;
+    const unsigned bz = unsigned(i % nb), by = unsigned((i / nb) % nb), bx = unsigned(i / (size_t(nb) * nb));
+    SvoRecord rec = root;
+    for (int l = 0; l < levels - 3; l++) {            // node level l: its slot from bit (levels - 4 - l) of the brick coordinates
+        const int sh = levels - 4 - l;
+        const unsigned slot = ((bx >> sh) & 1u) << 2 | ((by >> sh) & 1u) << 1 | ((bz >> sh) & 1u);
+        const unsigned bit = 1u << slot;
+        if ((rec.masks & bit) == 0u) return;          // empty (the arrays were cleared)
+        rec = svo[rec.base + __popc(rec.masks & (bit - 1u))];
+    }
+    // rec: the node of 8^3 cells; its children: 4^3 cells; theirs: the leaf parents (2^3 cells, masks >> 8 = leaf mask, base = first leaf)
+    uint32_t first = 0xffffffffu;
+    bool any = false;
+    for (unsigned n4 = 0; n4 < 8; n4++) {
+        unsigned long long word = 0ull;
+        if (rec.masks & (1u << n4)) {
+            const SvoRecord r4 = svo[rec.base + __popc(rec.masks & ((1u << n4) - 1u))];
+            for (unsigned n2 = 0; n2 < 8; n2++)
+                if (r4.masks & (1u << n2)) {
+                    const SvoRecord r2 = svo[r4.base + __popc(r4.masks & ((1u << n2) - 1u))];
+                    word |= (unsigned long long)((r2.masks >> 8) & 0xffu) << (8u * n2);
+                    if (first == 0xffffffffu) first = r2.base;
+                }
+        }
+        bricks[i * 8u + n4] = word;
+        any |= word != 0ull;
+    }
+    if (any) {
+        first_leaf[i] = first;
+        atomicOr(brick_bits + (i >> 5), 1u << (i & 31u));
+        if (super_bits) {
+            const unsigned ns = nb >> 3;
+            const size_t si = (size_t(bx >> 3) * ns + (by >> 3)) * ns + (bz >> 3);
+            atomicOr(super_bits + (si >> 5), 1u << (si & 31u));
+        }
+    }
+}
 
 __device__ __forceinline__ unsigned cell_bit_index(int x, int y, int z) {   // within a brick: 0..511
     const unsigned n4 = unsigned((x >> 2) & 1) << 2 | unsigned((y >> 2) & 1) << 1 | unsigned((z >> 2) & 1);
@@ -59,10 +112,19 @@ __device__ __forceinline__ bool near_plane(float p, float dt, float rmin, float 
 }
 
 // out: hit flag, time, bits(leaf word), normal xyz, flags (1 = flagged: the exact walk must decide), steps
-template <int kCertify>
-__global__ __launch_bounds__(64) void dda_probe_kernel(const TraceArgs a, const DdaGrid g, const float* origins, const float* dirs, float* out, unsigned n,
-                                                        float margin_scale) {
-    const unsigned i = blockIdx.x * 64u + threadIdx.x;
+template <int kCertify, int kLdsTop>
+__global__ __launch_bounds__(256) void dda_probe_kernel(const TraceArgs a, const DdaGrid g, const float* origins, const float* dirs, float* out, unsigned n,
+                                                         float margin_scale, unsigned max_steps) {
+    // the top level in LDS (kLdsTop: the super-brick bits are <= 32 KB, i.e. levels <= 12): every block copies them once
+    __shared__ uint32_t top_lds[kLdsTop ? 8192 : 1];
+    if (kLdsTop) {
+        const unsigned ns = 1u << (g.levels - 6);
+        const unsigned words = (ns * ns * ns + 31u) / 32u;
+        for (unsigned k = threadIdx.x; k < words; k += 256u) top_lds[k] = g.super_bits[k];
+        __syncthreads();
+    }
+    const uint32_t* sup = kLdsTop ? top_lds : g.super_bits;
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const SceneView sc = make_scene(a);
     const f3 o = ld3(origins + 3 * i), d = ld3(dirs + 3 * i);
@@ -98,16 +160,27 @@ __global__ __launch_bounds__(64) void dda_probe_kernel(const TraceArgs a, const 
         const int bx = j[0] >> 3, by = j[1] >> 3, bz = j[2] >> 3;
         const unsigned nb = 1u << (g.levels - 3);
         const unsigned blin = (unsigned(bx) * nb + unsigned(by)) * nb + unsigned(bz);
-        const bool brick_full = (g.brick_bits[blin >> 5] >> (blin & 31u)) & 1u;
         int stride = 8;
+        bool brick_full;
+        if (sup != nullptr) {                                                              // the super-brick first: 64 cells in one step when it is empty
+            const unsigned ns = nb >> 3;
+            const unsigned slin = (unsigned(bx >> 3) * ns + unsigned(by >> 3)) * ns + unsigned(bz >> 3);
+            const bool super_full = (sup[slin >> 5] >> (slin & 31u)) & 1u;
+            brick_full = super_full && ((g.brick_bits[blin >> 5] >> (blin & 31u)) & 1u);
+            if (!super_full) stride = 64;
+        } else {
+            brick_full = (g.brick_bits[blin >> 5] >> (blin & 31u)) & 1u;
+        }
         if (brick_full) {
             const unsigned bit = cell_bit_index(j[0], j[1], j[2]);
             const unsigned long long word = g.bricks[size_t(blin) * 8u + (bit >> 6)];
             if ((word >> (bit & 63u)) & 1ull) {                                         // a voxel: the hit
-                const size_t lin = (size_t(j[0]) << (2 * g.levels)) | (size_t(j[1]) << g.levels) | size_t(j[2]);
+                unsigned rank = unsigned(__popcll(word & ((1ull << (bit & 63u)) - 1ull)));  // its leaf word: the brick's leaves are one run, in mask-bit order
+                for (unsigned wq = 0; wq < (bit >> 6); wq++) rank += unsigned(__popcll(g.bricks[size_t(blin) * 8u + wq]));
+                const size_t lin = size_t(g.first_leaf[blin]) + rank;
                 const f3 oc = mk3(rm[0] + (float(j[0]) + 0.5f) * cell, rm[1] + (float(j[1]) + 0.5f) * cell, rm[2] + (float(j[2]) + 0.5f) * cell);
                 const f3 nrm = hit_normal(o, d, time, oc);
-                res[0] = 1.0f; res[1] = time; res[2] = __int_as_float(g.leaf[lin]); res[3] = nrm.x; res[4] = nrm.y; res[5] = nrm.z;
+                res[0] = 1.0f; res[1] = time; res[2] = __int_as_float(g.leaves[lin]); res[3] = nrm.x; res[4] = nrm.y; res[5] = nrm.z;
                 break;
             }
             const unsigned byte = unsigned(word >> (bit & 56u)) & 0xffu;
@@ -138,7 +211,7 @@ __global__ __launch_bounds__(64) void dda_probe_kernel(const TraceArgs a, const 
             if (stride > 1) j[k] = cell_of(pp[k], rm[k], cell, inv_cell, top);
             if (kCertify) flagged |= near_plane(pp[k], dd[k] * time, rm[k], cell, inv_cell, margin_scale);
         }
-        if (++steps > 600u) { flagged = true; break; }                                    // nowhere near the walk's 2048 trips, but no result either
+        if (++steps > max_steps) { flagged = true; break; }                                // no result: the exact walk decides (its own cap is 2048 trips)
     }
     (void)entered_axis;
     res[6] = flagged ? 1.0f : 0.0f;
@@ -147,11 +220,38 @@ __global__ __launch_bounds__(64) void dda_probe_kernel(const TraceArgs a, const 
 
 }  // namespace
 
-hipError_t launch_dda_probe(const TraceArgs& a, const void* bricks, const void* brick_bits, const void* leaf, int levels, const float* origins,
-                            const float* dirs, float* out, unsigned n, int certify, float margin_scale, hipStream_t s) {
-    DdaGrid g{static_cast<const unsigned long long*>(bricks), static_cast<const uint32_t*>(brick_bits), static_cast<const int32_t*>(leaf), levels};
-    if (certify) hipLaunchKernelGGL(dda_probe_kernel<1>, dim3((n + 63u) / 64u), dim3(64), 0, s, a, g, origins, dirs, out, n, margin_scale);
-    else hipLaunchKernelGGL(dda_probe_kernel<0>, dim3((n + 63u) / 64u), dim3(64), 0, s, a, g, origins, dirs, out, n, margin_scale);
+// grid arrays for a tree of `levels` cell levels: bricks 64 B per brick, one bit per brick, one bit per super-brick, 4 B per brick
+void dda_grid_sizes(int levels, size_t* brick_bytes, size_t* brick_bit_bytes, size_t* super_bit_bytes, size_t* first_leaf_bytes) {
+    const size_t nb = size_t(1) << (levels - 3), bricks = nb * nb * nb;
+    *brick_bytes = bricks * 64;
+    *brick_bit_bytes = (bricks + 31) / 32 * 4;
+    const size_t ns = levels >= 6 ? size_t(1) << (levels - 6) : 0, supers = ns * ns * ns;
+    *super_bit_bytes = supers ? (supers + 31) / 32 * 4 : 0;
+    *first_leaf_bytes = bricks * 4;
+}
+
+// fills the (zeroed) grid arrays from the 8-byte records in a.svo
+hipError_t launch_dda_build(const TraceArgs& a, int levels, void* bricks, void* brick_bits, void* super_bits, void* first_leaf, hipStream_t s) {
+    const size_t nb = size_t(1) << (levels - 3), n = nb * nb * nb;
+    hipLaunchKernelGGL(dda_build_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, a.svo, a.root_rec, levels, static_cast<unsigned long long*>(bricks),
+                       static_cast<uint32_t*>(brick_bits), static_cast<uint32_t*>(super_bits), static_cast<uint32_t*>(first_leaf));
+    return hipGetLastError();
+}
+
+hipError_t launch_dda_probe(const TraceArgs& a, const void* bricks, const void* brick_bits, const void* super_bits, const void* first_leaf, int levels,
+                            const float* origins, const float* dirs, float* out, unsigned n, int certify, float margin_scale, unsigned max_steps, int lds_top,
+                            hipStream_t s) {
+    DdaGrid g{static_cast<const unsigned long long*>(bricks), static_cast<const uint32_t*>(brick_bits), static_cast<const uint32_t*>(super_bits),
+              static_cast<const uint32_t*>(first_leaf), a.leaves, levels};
+    const dim3 grid((n + 255u) / 256u), block(256);
+    const bool lds = lds_top && super_bits != nullptr && levels <= 12;
+    if (certify) {
+        if (lds) hipLaunchKernelGGL((dda_probe_kernel<1, 1>), grid, block, 0, s, a, g, origins, dirs, out, n, margin_scale, max_steps);
+        else hipLaunchKernelGGL((dda_probe_kernel<1, 0>), grid, block, 0, s, a, g, origins, dirs, out, n, margin_scale, max_steps);
+    } else {
+        if (lds) hipLaunchKernelGGL((dda_probe_kernel<0, 1>), grid, block, 0, s, a, g, origins, dirs, out, n, margin_scale, max_steps);
+        else hipLaunchKernelGGL((dda_probe_kernel<0, 0>), grid, block, 0, s, a, g, origins, dirs, out, n, margin_scale, max_steps);
+    }
     return hipGetLastError();
 }
 

@@ -22,6 +22,8 @@ struct SceneW {
     float root_size;
     int levels;        // node levels L: root = 0, leaf parents = L - 1
     uint32_t parity;   // L & 1: level l is a TOP level iff ((l + parity) & 1) == 0 (parity 1: the root is the one sub of a virtual top)
+    uint32_t* touch_nodes;   // TraceArgs::touch_nodes / touch_leaves (null: off)
+    uint32_t* touch_leaves;
 };
 
 __device__ __forceinline__ SceneW make_scene_w(const TraceArgs& a) {
@@ -34,6 +36,8 @@ __device__ __forceinline__ SceneW make_scene_w(const TraceArgs& a) {
     sc.root_min = sc.root_center - splat3(0.5f * a.root_size);
     sc.levels = a.node_levels;
     sc.parity = uint32_t(a.node_levels) & 1u;
+    sc.touch_nodes = a.touch_nodes;
+    sc.touch_leaves = a.touch_leaves;
     return sc;
 }
 
@@ -155,6 +159,7 @@ __device__ __forceinline__ int walkw_step(WalkW<kRegular>& w, const SceneW& sc, 
                         make_uint4(w.mlo, w.mhi, w.base, ((w.info >> 19) & 7u) | ((w.info >> 16) & 7u) << 3 | next_octant << 6 | (w.info >> 24) << 16);
                 const uint32_t slot = ((w.info >> 16) & 7u) * 8u + w.octant;
                 const uint4 raw = *reinterpret_cast<const uint4*>(sc.wide + (w.base + wide_rank(w.mlo, w.mhi, slot)));
+                VX_TOUCH(sc.touch_nodes, (w.base + wide_rank(w.mlo, w.mhi, slot)) >> 2);
                 w.mlo = raw.x; w.mhi = raw.y; w.base = raw.z;
                 w.info = (raw.w & 0xffu) << 24 | (raw.w & 0xffu);
             }
@@ -240,6 +245,7 @@ __device__ __forceinline__ bool finish_ray_w(const SceneW& sc, int status, f3 o,
         return true;
     }
     hit.node = sc.leaves[leaf_index];
+    VX_TOUCH(sc.touch_leaves, leaf_index >> 4);
     const float size = __builtin_ldexpf(sc.root_size, -int(lvl));
     f3 delta = mk3(float((octant >> 2) & 1u), float((octant >> 1) & 1u), float(octant & 1u));
     f3 oc = center + (0.5f * size) * (delta - splat3(0.5f));

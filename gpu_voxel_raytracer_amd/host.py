@@ -106,12 +106,13 @@ class Stats(C.Structure):
                 ("node_order", C.c_uint32), ("queue_bytes", C.c_uint64),
                 ("queue_overflow_paths", C.c_uint64), ("halo_pack_ms", C.c_double), ("halo_unpack_ms", C.c_double),
                 ("halo_exchanges", C.c_uint64), ("cull_box_valid", C.c_uint32), ("cull_box_min", C.c_float * 3),
-                ("cull_box_max", C.c_float * 3), ("frame_lane_launches", C.c_uint32)]
+                ("cull_box_max", C.c_float * 3), ("frame_lane_launches", C.c_uint32), ("split_launches", C.c_uint32)]
 
 
 OPT_DENOISE_MODE, OPT_TAIL_CAPACITY, OPT_SCENE_FORMAT, OPT_HALO_ROWS, OPT_SKY_CULL, OPT_FRAME_LANES = 1, 2, 3, 4, 5, 6
 (OPT_TILE_ORDER, OPT_TILE_SPREAD, OPT_TRACE_BLOCKS, OPT_TAIL_FROM, OPT_TAIL_SPLIT, OPT_HOST_SCENE_BUILD, OPT_TRACER_OVERRIDE,
- OPT_TRACE_SPLIT, OPT_PATH_BLOCKS, OPT_SHADE_BLOCKS, OPT_RAYS_PER_WAVE, OPT_NODE_ORDER, OPT_HEAD_STAGGER, OPT_LONG_TILES, OPT_FUSED_TAIL) = range(7, 22)
+ OPT_TRACE_SPLIT, OPT_PATH_BLOCKS, OPT_SHADE_BLOCKS, OPT_RAYS_PER_WAVE, OPT_NODE_ORDER, OPT_HEAD_STAGGER, OPT_LONG_TILES, OPT_FUSED_TAIL,
+ OPT_TRACE_PRIORITY) = range(7, 23)      # include/vxrt_debug.h (the options of experiments)
 TILE_SPREAD_AUTO = 0xffffffff
 
 
@@ -128,7 +129,8 @@ ENV_KNOBS = {"VXRT_SKY_CULL": OPT_SKY_CULL, "VXRT_HALO_ROWS": OPT_HALO_ROWS, "VX
              "VXRT_TAIL_CAPACITY": OPT_TAIL_CAPACITY, "VXRT_WIDE": OPT_SCENE_FORMAT, "VXRT_SHADE_BLOCKS": OPT_SHADE_BLOCKS,
              "VXRT_RAYS_PER_WAVE": OPT_RAYS_PER_WAVE, "VXRT_TRACE_BLOCKS": OPT_TRACE_BLOCKS, "VXRT_FRAME_LANES": OPT_FRAME_LANES,
              "VXRT_SPREAD": OPT_TILE_SPREAD, "VXRT_TILE_ORDER": OPT_TILE_ORDER, "VXRT_TRACE_SPLIT": OPT_TRACE_SPLIT,
-             "VXRT_HOST_BUILD": OPT_HOST_SCENE_BUILD, "VXRT_NODE_ORDER": OPT_NODE_ORDER, "VXRT_HEAD_STAGGER": OPT_HEAD_STAGGER, "VXRT_LONG_TILES": OPT_LONG_TILES, "VXRT_FUSED_TAIL": OPT_FUSED_TAIL}
+             "VXRT_HOST_BUILD": OPT_HOST_SCENE_BUILD, "VXRT_NODE_ORDER": OPT_NODE_ORDER, "VXRT_HEAD_STAGGER": OPT_HEAD_STAGGER, "VXRT_LONG_TILES": OPT_LONG_TILES, "VXRT_FUSED_TAIL": OPT_FUSED_TAIL,
+             "VXRT_TRACE_PRIORITY": OPT_TRACE_PRIORITY}
 _env_knobs_enabled = os.environ.get("VXRT_ENV_KNOBS") == "1"      # the explicit opt-in of the A/B scripts (scripts/*.sh)
 
 
@@ -381,6 +383,33 @@ def detmath_probe(fn, x, y=None, device=0):
     return out
 
 
+class PinnedImage:
+    """A float32 image in pinned host memory (vxrt_host_alloc / vxrt_host_free): the destination vxrt_read_async wants.  `.array`
+    is a numpy view of it; valid until close() / garbage collection."""
+
+    def __init__(self, L, shape):
+        self._L = L
+        n = int(np.prod(shape)) * 4
+        self._ptr = C.c_void_p()
+        st = L.vxrt_host_alloc(C.c_size_t(n), C.byref(self._ptr))
+        if st != 0:
+            raise VxrtError(st, "vxrt_host_alloc", (L.vxrt_last_error() or b"").decode(errors="replace"))
+        buf = (C.c_float * (n // 4)).from_address(self._ptr.value) if n else (C.c_float * 0)()
+        self.array = np.frombuffer(buf, np.float32).reshape(shape)
+
+    def close(self):
+        if self._ptr:
+            self.array = None
+            self._L.vxrt_host_free(self._ptr)
+            self._ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context:
     """The render context: what `Context` is in the reference (src/context.rs:198-268), minus the window.
 
@@ -586,6 +615,37 @@ class Context:
         out = np.zeros((n.value, self.width, 4), np.float32)
         self._chk(self._L.vxrt_read(self._h, C.c_int(which), _p(out), C.c_size_t(out.nbytes)), "vxrt_read")
         return out
+
+    def read_into(self, which, arr):
+        """vxrt_read into a caller's float32 array of the image's size (no allocation per call)."""
+        self._chk(self._L.vxrt_read(self._h, C.c_int(which), _p(arr), C.c_size_t(arr.nbytes)), "vxrt_read")
+
+    def read_async(self, which, dst, slot=0):
+        """vxrt_read_async: snapshot image `which` as the stages enqueued so far leave it and start its transfer into `dst` (a
+        PinnedImage, or any C-contiguous float32 array of the image's size) without waiting; read_wait(slot) waits for it."""
+        arr = dst.array if isinstance(dst, PinnedImage) else dst
+        self._chk(self._L.vxrt_read_async(self._h, C.c_int(which), _p(arr), C.c_size_t(arr.nbytes), C.c_uint32(slot)), "vxrt_read_async")
+
+    def read_wait(self, slot=0):
+        self._chk(self._L.vxrt_read_wait(self._h, C.c_uint32(slot)), "vxrt_read_wait")
+
+    def pinned_image(self):
+        """A pinned host buffer of this context's image size (vxrt_host_alloc) for read_async."""
+        n = C.c_uint32(0)
+        self._chk(self._L.vxrt_local_rows(self._h, C.byref(n), None), "vxrt_local_rows")
+        return PinnedImage(self._L, (n.value, self.width, 4))
+
+    def touch_map(self, enable=True):
+        """vxrt_debug_touch_map (-DVXRT_VARIANTS=1 library): mark every 64-byte line of the scene that the frames from now on read."""
+        self._chk(self._L.vxrt_debug_touch_map(self._h, C.c_uint32(1 if enable else 0)), "vxrt_debug_touch_map")
+
+    def touch_count(self, reset=True):
+        """vxrt_debug_touch_count -> dict: lines / bytes of node records and leaf words touched since the map was cleared."""
+        out = (C.c_uint64 * 6)()
+        self._chk(self._L.vxrt_debug_touch_count(self._h, out, C.c_uint32(1 if reset else 0)), "vxrt_debug_touch_count")
+        n64, l64, n128, l128, nt, lt = (int(v) for v in out)
+        return {"node_lines_64": n64, "leaf_lines_64": l64, "node_lines_128": n128, "leaf_lines_128": l128, "node_lines_total": nt, "leaf_lines_total": lt,
+                "unique_bytes_64": 64 * (n64 + l64), "unique_bytes_128": 128 * (n128 + l128), "scene_bytes": 64 * (nt + lt)}
 
     def device_image(self, which):
         ptr = C.c_void_p()

@@ -14,6 +14,14 @@
  * and is not thread-safe; distinct contexts are independent (the reference renders from a single
  * thread, src/main.rs:34-38).  Multi-GPU = one process and one context per GPU, each rendering its
  * share of the frame's rows (vxrt_config.rank / nranks / band_rows).
+ *
+ * THIS HEADER IS THE CONTRACT: context, scene, camera and parameters, the render calls, read-back, statistics, the multi-GPU
+ * halo, errors — 40 entry points.  Two more headers ship beside it and a host that only renders needs neither:
+ *   vxrt_host.h   host-side helpers that need no context (the .vox decoder, the octree builder, the camera basis, the noise
+ *                 generator and the reference's noise archive format) — what src/vox.rs / create_octree / camera.rs do,
+ *                 callable on their own for tools and tests;
+ *   vxrt_debug.h  test hooks, diagnostics and the scheduling options of experiments (vxrt_debug_*, vxrt_create_tuned,
+ *                 VXRT_OPT_* from 7 on).  Nothing in there is needed to render, and none of it changes what a frame means.
  */
 #ifndef VXRT_H
 #define VXRT_H
@@ -106,9 +114,14 @@ typedef struct vxrt_config {
     uint32_t frames_in_flight;/* 0/1: every stage of a frame runs in submission order on one stream (the
                                  reference's single queue).  F = 2..16: the TRACE stage of up to F consecutive
                                  frames may run concurrently (one HIP stream each, ring of F+2 G-buffer slots);
-                                 temporal/denoise still run in frame order.  Results are identical.  Beyond 3 the
-                                 streams outnumber the 4 hardware queues a process gets by default (GPU_MAX_HW_QUEUES):
-                                 launches of streams that share a queue serialise.                          */
+                                 temporal/denoise still run in frame order.  Results are identical.
+                                 HARDWARE QUEUES: every launch in flight is a HIP stream, and a process's streams share
+                                 GPU_MAX_HW_QUEUES hardware queues — 4 unless the HOST exports another number before its
+                                 first HIP call (the HIP runtime reads it once; the library cannot set it afterwards and
+                                 reads no environment variable itself).  With F >= 3, or with RCCL / a copy stream in
+                                 the process, two busy streams can share a queue and their launches serialise: export
+                                 GPU_MAX_HW_QUEUES=8 in the host's environment (bench.py and host.py do; measured on a
+                                 rank of 8: 0.0266 ms per frame with 4 queues, 0.0178 with 8).  Nothing else differs. */
     uint32_t tracer;          /* scheduling of the trace stage; every choice gives bit-identical images:
                                  0 auto (4 when max_bounces >= 2, else 1), 1 monolithic kernel (one pixel per lane,
                                  all bounces, longest-tile-first), 2 wavefront (one launch per path segment, live
@@ -173,7 +186,9 @@ typedef struct vxrt_stats {
     float cull_box_min[3];    /* world units, before the per-frame margin is added                                              */
     float cull_box_max[3];
     uint32_t frame_lane_launches; /* trace launches whose waves held 8 frames of a pixel row (VXRT_OPT_FRAME_LANES)              */
+    uint32_t split_launches;  /* trace launches that went out as two grids of different stream priority (vxrt_debug.h: VXRT_OPT_TRACE_PRIORITY; ABI 6) */
 } vxrt_stats;
+
 
 /* Run-time options (none of them changes what a frame means; defaults are the reference's behaviour).
  *   VXRT_OPT_DENOISE_MODE  0 (default): denoise.comp evaluated exactly as the oracle restates it (bit-identical).
@@ -204,55 +219,15 @@ typedef struct vxrt_stats {
  *                          ray is the same in every frame).  0: always one frame per wave.  vxrt_stats.frame_lane_launches counts the
  *                          former.  Not used for scenes beyond the Infinity Cache (measured slower there).
  *
- * Scheduling options for experiments and tests (same image whatever they say; the library reads NO environment variable — this is
- * the only way in).  "create": accepted by vxrt_create_tuned only, because a launch in flight must not see them change or because
- * they size what the context allocates.
- *   VXRT_OPT_TILE_ORDER    1 (default): the tiles of a trace launch start longest first (csrc/trace.hip); 0: raster order.
- *   VXRT_OPT_TILE_SPREAD   how far the tiles that walk are spread between the sky tiles of a launch: 0 .. 256 = that many 256ths of
- *                          the launch, VXRT_TILE_SPREAD_AUTO (default) = decided on the device from the cost histogram.
- *   VXRT_OPT_TRACE_BLOCKS  blocks of the compacted tail's launches (default 2048).
- *   VXRT_OPT_TAIL_FROM     create: the hit at which a path moves from trace_kernel to the compacted tail (default 1 = the second hit).
- *   VXRT_OPT_TAIL_SPLIT    create: bit k = the tail compacts once more at path segment k (default: 0x2c — segments 2, 3 and 5 — from 6 bounces on).
- *   VXRT_OPT_HOST_SCENE_BUILD  1: vxrt_set_menger builds the scene on the host also where the device builder could (cross-check).
- *   VXRT_OPT_NODE_ORDER    the order of the scene's 8-byte records in memory, chosen before the scene is set: 0 (default) breadth-first,
- *                          level after level; 2 / 3: the last two / three node levels as depth-first treelets — below every node of
- *                          level depth - 2 / depth - 3 its children as one block, then child by child their children's blocks
- *                          (<= 576 bytes / <= 4.6 KB) — so that the end of a descent stays in one neighbourhood of memory (BASELINE
- *                          config 5's scene lives in HBM).  Node indices never reach an output and the children of a node stay
- *                          contiguous: same image, same walk code.  vxrt_stats.node_order reads what the scene in place has.
- *   VXRT_OPT_HEAD_STAGGER  1: with several trace launches in flight (one stream each), a launch's trace_kernel starts only when the previous
- *                          launch's trace_kernel has finished, so that it runs beside that launch's bounce_kernel (a short block of few
- *                          launches: the heads do not drain together).  Measured slower (-DVXRT_VARIANTS=1 builds only).  0 (default).
- *   VXRT_OPT_FUSED_TAIL    1: head and compacted tail of a trace launch run as ONE grid of persistent waves that take the launch's tiles
- *                          from a cursor and then its queued paths, chunk by chunk as they become complete — for launches that are
- *                          little more than their longest chains (a rank's share of a short block on many GPUs); 4-bounce tails,
- *                          8-byte records, scenes in cache.  Same image — and measured SLOWER (a scheduler in software pays for every
- *                          decision with device-scope memory round trips): -DVXRT_VARIANTS=1 builds only.  0 (default): trace_kernel,
- *                          then bounce_kernel.
- *   VXRT_OPT_LONG_TILES    per mille (0 = off .. 500) of a trace launch's tiles — the first of its longest-first order — that run as an
- *                          all-in-one grid on a second stream (a path's whole chain in one wave, begun when the launch begins) beside
- *                          the head + compacted tail of the others: for launches that are little more than their longest chains
- *                          (a rank's share of a short block on many GPUs).  Same image; measured slower (-DVXRT_VARIANTS=1 builds only).
- *   VXRT_OPT_TRACER_OVERRIDE   create: the internal schedule past vxrt_config.tracer's automatic choice: 0 all-in-one kernel, 4 head +
- *                          compacted tail; 2 / 3 / 5 (-DVXRT_VARIANTS=1 builds) wavefront, ray queues, path kernel.
- *   VXRT_OPT_TRACE_SPLIT / PATH_BLOCKS / SHADE_BLOCKS / RAYS_PER_WAVE   create: launch shapes of tracers 2, 3 and 5.                    */
+ */
 typedef enum vxrt_option { VXRT_OPT_DENOISE_MODE = 1, VXRT_OPT_TAIL_CAPACITY = 2, VXRT_OPT_SCENE_FORMAT = 3, VXRT_OPT_HALO_ROWS = 4,
-                           VXRT_OPT_SKY_CULL = 5, VXRT_OPT_FRAME_LANES = 6, VXRT_OPT_TILE_ORDER = 7, VXRT_OPT_TILE_SPREAD = 8,
-                           VXRT_OPT_TRACE_BLOCKS = 9, VXRT_OPT_TAIL_FROM = 10, VXRT_OPT_TAIL_SPLIT = 11, VXRT_OPT_HOST_SCENE_BUILD = 12,
-                           VXRT_OPT_TRACER_OVERRIDE = 13, VXRT_OPT_TRACE_SPLIT = 14, VXRT_OPT_PATH_BLOCKS = 15, VXRT_OPT_SHADE_BLOCKS = 16,
-                           VXRT_OPT_RAYS_PER_WAVE = 17, VXRT_OPT_NODE_ORDER = 18, VXRT_OPT_HEAD_STAGGER = 19, VXRT_OPT_LONG_TILES = 20, VXRT_OPT_FUSED_TAIL = 21 } vxrt_option;
-#define VXRT_TILE_SPREAD_AUTO 0xffffffffu
+                           VXRT_OPT_SKY_CULL = 5, VXRT_OPT_FRAME_LANES = 6,
+                           VXRT_OPT_LAST_ = 0x7fffffff /* vxrt_debug.h continues the list from 7 on (scheduling options of experiments) */ } vxrt_option;
 int vxrt_set_option(vxrt_ctx* ctx, vxrt_option option, uint32_t value);
-/* An (option, value) pair for vxrt_create_tuned. */
-typedef struct vxrt_tuning { uint32_t option; uint32_t value; } vxrt_tuning;
 
 /* ---- context: replaces Context::new / create_bindings / resize (src/context.rs:595-660, 936-1016,
  *      1430-1461).  resize drops the temporal history like the reference (:1440-1448). -------------- */
 int vxrt_create(const vxrt_config* cfg, vxrt_ctx** out);
-/* vxrt_create with `count` options applied before anything is allocated (vxrt_create = none).  The reference has no counterpart: its
- * tuning is compile-time constants in the shaders; this is where an A/B script or a test says what it wants instead of the process
- * environment. */
-int vxrt_create_tuned(const vxrt_config* cfg, const vxrt_tuning* tuning, size_t count, vxrt_ctx** out);
 int vxrt_destroy(vxrt_ctx* ctx);
 int vxrt_resize(vxrt_ctx* ctx, uint32_t width, uint32_t height);
 
@@ -262,6 +237,15 @@ int vxrt_set_voxels(vxrt_ctx* ctx, const int16_t (*pos)[3], const uint8_t (*mrgb
 /* vox::load + Context::voxels_from_vox + recreate_octree (src/context.rs:1817-1821). */
 int vxrt_load_vox(vxrt_ctx* ctx, const char* path);
 int vxrt_load_vox_memory(vxrt_ctx* ctx, const uint8_t* bytes, size_t len);
+/* BASELINE config 5: the procedural level-`level` Menger sponge clipped to [0, clip)^3 (0 = no clip), every voxel
+ * whose hash(x,y,z) % emissive_period == 0 emissive (0 = none), built on the device straight into the scene format without a voxel
+ * list or a reference-layout octree (level 7 clipped to 2048: ~1.05e9 voxels, 1.2 GB of nodes + 4.2 GB of leaf words).  The tree
+ * equals the one create_octree (src/context.rs:777-796) would build from the voxel list (vxrt_host.h: vxrt_menger_voxels_ex). */
+int vxrt_set_menger(vxrt_ctx* ctx, uint32_t level, uint32_t clip, const uint8_t mrgb[4], uint32_t emissive_period);
+/* Replaces a context's noise table: 512*128*128 floats in [0,1), host memory (the layers of resources/blue-noise-128.zip,
+ * src/context.rs:1016-1116; vxrt_host.h makes or reads such a table). */
+int vxrt_set_noise(vxrt_ctx* ctx, const float* table);
+
 
 /* ---- per-frame parameters: replaces Context::update_bindings (src/context.rs:2136-2162). ---------- */
 /* Camera{position, direction, fov} (src/camera.rs:5-9); the library applies Camera::axis_scaled. */
@@ -290,12 +274,24 @@ int vxrt_render_path(vxrt_ctx* ctx, uint32_t flags, uint32_t count, const float 
 int vxrt_render_spp(vxrt_ctx* ctx, uint32_t flags, uint32_t spp);
 int vxrt_sync(vxrt_ctx* ctx);
 int vxrt_reset_history(vxrt_ctx* ctx);          /* still_sample = 0 path, src/context.rs:1424 */
-int vxrt_set_frame_number(vxrt_ctx* ctx, uint32_t frame_number); /* next render uses frame_number+1 */
 
-/* ---- outputs.  The reference only blits denoised_color (src/context.rs:1131-1136); every image is
+/* ---- outputs.  The reference only blits denoised_color (src/context.rs:1131-1136, the present at :2046-2070); every image is
  *      readable here.  dst receives this context's rows in ascending frame-row order, rgba32f,
  *      local_rows*width*16 bytes (vxrt_local_rows; = height for a single-GPU context). ------------ */
-int vxrt_read(vxrt_ctx* ctx, vxrt_image which, float* dst, size_t bytes);
+int vxrt_read(vxrt_ctx* ctx, vxrt_image which, float* dst, size_t bytes);      /* waits for the GPU, then copies: synchronous */
+/* The same without stalling the render loop — what a host that shows (or encodes) EVERY frame wants in place of the reference's
+ * present (src/context.rs:2046-2070).  vxrt_read_async snapshots image `which` as the stages enqueued so far leave it (a device-side
+ * copy on the context's stream, so later frames may overwrite the image at once) and starts its transfer to `dst` on a copy stream of
+ * the context's own; it returns without waiting.  vxrt_read_wait(slot) returns when that transfer has arrived.  Two transfers can be
+ * in flight, slot 0 and slot 1: frame n + 1 renders while frame n travels, and a loop that alternates the slots costs
+ * max(render, transfer) per frame instead of their sum.  dst must stay valid and untouched until the wait, and should be PINNED
+ * host memory — vxrt_host_alloc, or the host's own hipHostMalloc / hipHostRegister — for the transfer to be asynchronous and at
+ * PCIe rate (pageable memory works, slowly).  Re-using a slot waits for its previous transfer first. */
+int vxrt_read_async(vxrt_ctx* ctx, vxrt_image which, float* dst, size_t bytes, uint32_t slot);
+int vxrt_read_wait(vxrt_ctx* ctx, uint32_t slot);
+/* Pinned host memory for vxrt_read_async, so that a host without HIP bindings of its own (the reference's Rust host) can have it. */
+int vxrt_host_alloc(size_t bytes, void** out);
+int vxrt_host_free(void* p);
 int vxrt_local_rows(const vxrt_ctx* ctx, uint32_t* count, uint32_t* rows /* optional: count entries */);
 /* Device pointer of an image (local rows, rgba32f) for zero-copy consumers on the same GPU. */
 int vxrt_device_image(vxrt_ctx* ctx, vxrt_image which, void** device_ptr, size_t* bytes);
@@ -335,7 +331,6 @@ typedef struct vxrt_halo_info {
     uint64_t message_bytes;     /* size of each of the four buffers (>= slots * rows * width * 36, whole 256-byte lines) */
 } vxrt_halo_info;
 int vxrt_halo_info_get(vxrt_ctx* ctx, vxrt_halo_info* out);
-int vxrt_halo_bytes(vxrt_ctx* ctx, size_t* bytes_per_neighbour);     /* = vxrt_halo_info.message_bytes */
 /* Asynchronous: one launch on the context's stream each, return at once.  The buffers must stay untouched until the launch
  * has run: order the communication against it with the two calls below. */
 int vxrt_halo_pack(vxrt_ctx* ctx, void* dev_to_prev, void* dev_to_next);
@@ -346,7 +341,6 @@ int vxrt_halo_unpack(vxrt_ctx* ctx, const void* dev_from_prev, const void* dev_f
  * so far has finished.  Events only; the host does not wait.  (Also what a zero-copy consumer of vxrt_device_image needs.) */
 int vxrt_stream_wait_context(vxrt_ctx* ctx, void* stream);
 int vxrt_context_wait_stream(vxrt_ctx* ctx, void* stream);
-/* Synchronous forms: pack / unpack and wait for the launch (the buffers are borrowed for the call only). */
 /* Host-only helper: VXRT_OPT_HALO_ROWS for the exchange after a frame rendered from camera A when the next frame comes from camera B —
  * the largest vertical image motion (rows) of any point at distance >= near_distance between the two, + 2, at most `band_rows` — pass
  * vxrt_halo_info.max_rows there, the depth the context's band layout can carry.  While the returned value is BELOW that cap the next
@@ -355,107 +349,10 @@ int vxrt_context_wait_stream(vxrt_ctx* ctx, void* stream);
  * reference has no counterpart (one GPU sees the whole history); a frame loop sets it one frame ahead on a camera path. */
 int vxrt_halo_rows_for_motion(const float pos_a[3], const float dir_a[3], const float pos_b[3], const float dir_b[3], float fov, uint32_t width,
                               uint32_t height, float near_distance, uint32_t band_rows, uint32_t* rows);
-int vxrt_halo_export(vxrt_ctx* ctx, void* dev_to_prev, void* dev_to_next);
-int vxrt_halo_import(vxrt_ctx* ctx, const void* dev_from_prev, const void* dev_from_next);
-
-/* ---- host-side scene preparation, callable without a GPU (src/vox.rs, src/context.rs:710-834,
- *      913-933, src/camera.rs).  Counts are returned through *n; nothing is written past cap. ------ */
-/* Test hook: the scene as the device holds it right now (8-byte records, 2 words each; leaf words).  Null arrays: sizes only. */
-int vxrt_debug_read_scene(vxrt_ctx* ctx, uint32_t* svo, size_t svo_cap, size_t* n_svo, int32_t* leaves, size_t leaf_cap, size_t* n_leaves);
-/* The device scene formats for a voxel list (csrc/kernels.h: SvoRecord = 2 words, WideRec = 4 words per record; leaf words as in
- * src/context.rs:732-735), built on the host exactly as vxrt_set_voxels builds them: for tools and tests.  Null arrays: sizes only. */
-int vxrt_build_records(const int16_t (*pos)[3], const uint8_t (*mrgb)[4], size_t n, uint32_t* svo, size_t svo_cap, size_t* n_svo,
-                       uint32_t* wide, size_t wide_cap, size_t* n_wide, int32_t* leaves, size_t leaf_cap, size_t* n_leaves, uint32_t* depth);
-int vxrt_vox_to_voxels(const uint8_t* bytes, size_t len, int16_t (*pos)[3], uint8_t (*mrgb)[4], size_t cap,
-                       size_t* n, uint32_t size_xyz[3]);
-int vxrt_build_octree(const int16_t (*pos)[3], const uint8_t (*mrgb)[4], size_t n, int32_t* words, size_t cap,
-                      size_t* n_words, uint32_t* depth);
-int vxrt_camera_axis_scaled(const float position[3], const float direction[3], float fov, uint32_t width,
-                            uint32_t height, float right[3], float up[3], float forward_ray[3]);
-/* Stand-in for the blue-noise table the reference does not ship (resources/blue-noise-128.zip,
- * .MISSING_LARGE_BLOBS): value i of seed s is  z = i*0x9E3779B9 + s;  z ^= z>>16; z *= 0x85EBCA6B;
- * z ^= z>>13; z *= 0xC2B2AE35; z ^= z>>16;  (z >> 8) * 2^-24. */
-int vxrt_noise_table(uint32_t seed, float* out, size_t n);
-/* ---- blue noise.  The reference indexes 512 layers of 128x128 blue noise loaded from
- *      resources/blue-noise-128.zip (src/context.rs:1016-1116), a file its repository does not ship.
- *      vxrt_blue_noise makes such a table on the GPU (void-and-cluster, include/vxrt_bluenoise.h): `layers`
- *      layers first_layer.. of size x size floats into the HOST buffer out (size: power of two, 16..128).
- *      The zip functions read / write the reference's archive format (entries in archive order, each
- *      BE u32 width | BE u32 height | BE f32 pixels; square, all the same size), so a generated table can be
- *      dropped into the reference as its missing resource.  vxrt_set_noise replaces a context's table
- *      (512*128*128 floats, host memory). ---------------------------------------------------------------- */
-int vxrt_blue_noise(int32_t device, uint32_t seed, uint32_t size, uint32_t first_layer, uint32_t layers, float* out);
-int vxrt_noise_zip_read(const char* path, float* out, size_t cap_floats, uint32_t* size, uint32_t* layers);
-int vxrt_noise_zip_write(const char* path, const float* table, uint32_t size, uint32_t layers);
-int vxrt_set_noise(vxrt_ctx* ctx, const float* table);
-
-/* ---- wider scene input.  vxrt_vox_scene_to_voxels: like vxrt_vox_to_voxels, plus, per flags:
- *      every shape instance of the file's nTRN/nGRP/nSHP scene graph with its translation and axis rotation
- *      (the reference renders models[0] at its raw coordinates and skips those chunks, src/context.rs:916,
- *      src/vox.rs:61); material types other than _diffuse/_emit taken as diffuse instead of rejected
- *      (src/vox.rs:82-89); the result shifted so that its minimum corner is the origin.  bounds: inclusive voxel
- *      bounding box in renderer axes (optional).  vxrt_default_scene_voxels: Context::create_voxels
- *      (src/context.rs:838-910), the start-up scene, with a seeded generator for its random colours. ------- */
-enum { VXRT_VOX_ALL_MODELS = 1, VXRT_VOX_LENIENT_MATERIALS = 2, VXRT_VOX_REBASE = 4 };
-int vxrt_vox_scene_to_voxels(const uint8_t* bytes, size_t len, uint32_t flags, int16_t (*pos)[3], uint8_t (*mrgb)[4],
-                             size_t cap, size_t* n, int32_t bounds_min[3], int32_t bounds_max[3]);
-int vxrt_default_scene_voxels(uint32_t seed, int16_t (*pos)[3], uint8_t (*mrgb)[4], size_t cap, size_t* n);
-
-/* Procedural level-`level` Menger sponge, side 3^level voxels at the origin (config 5 generator;
- * level 4 reproduces the voxel set of vox/menger.vox). */
-int vxrt_menger_voxels(uint32_t level, const uint8_t mrgb[4], int16_t (*pos)[3], uint8_t (*out_mrgb)[4], size_t cap,
-                       size_t* n);
-/* The same sponge clipped to [0, clip)^3 (0 = no clip) with every voxel whose hash(x,y,z) % emissive_period == 0
- * marked emissive (0 = none): the voxel-list form of the scene vxrt_set_menger builds procedurally. */
-int vxrt_menger_voxels_ex(uint32_t level, uint32_t clip, const uint8_t mrgb[4], uint32_t emissive_period, int16_t (*pos)[3],
-                          uint8_t (*out_mrgb)[4], size_t cap, size_t* n);
-/* BASELINE config 5: builds that scene straight into the device format without a voxel list
- * or a reference-layout octree (level 7 clipped to 2048: ~1.05e9 voxels, 1.2 GB of nodes + 4.2 GB of leaf words).
- * The tree equals the one create_octree (src/context.rs:777-796) would build from the voxel list. */
-int vxrt_set_menger(vxrt_ctx* ctx, uint32_t level, uint32_t clip, const uint8_t mrgb[4], uint32_t emissive_period);
-
-/* Test hook: evaluates function `fn` of include/vxrt_detmath.h on the device for host arrays x, y
- * (0 sin, 1 cos, 2 exp, 3 log, 4 pow, 5 sqrt, 6 div, 7 tan, 8 normalize/cross/dot chain) so that the
- * host-vs-device bit equality the numeric contract promises can be checked. */
-int vxrt_detmath_probe(int32_t device, int32_t fn, const float* x, const float* y, float* out, size_t n);
-
-/* Test hook: cast_bounded_ray (shaders/voxels.comp:134-247, max_distance 2^30) as the kernels implement it, for n caller-given
- * rays (origins, dirs: 3 floats each) through the current scene: hit flag, time, leaf word, normal (3 floats) per ray. */
-int vxrt_debug_cast_rays(vxrt_ctx* ctx, const float* origins, const float* dirs, size_t n, uint8_t* hit, float* time, int32_t* node,
-                         float* normal);
-
-/* Test hook: the path of pixel (x, y) of the NEXT frame (frame_number + 1, camera as set), cast by cast, as the kernels compute it.
- * log: room for 32 casts of 12 floats = origin, direction, hit flag, time, bits(leaf word), normal; *casts = how many were made.
- * Renders nothing and leaves the context as it was. */
-int vxrt_debug_path_log(vxrt_ctx* ctx, int32_t x, int32_t y, float* log, int32_t* casts);
-
-/* Diagnostics: duration (shader clocks) of each 16x16 tile of the last traced frame, row-major over
- * ceil(width/16) x ceil(local_rows/16) tiles — the data the longest-tile-first scheduler works from.  A tile none of
- * whose pixels walked the octree (sky, culled) reads 1; a tile that walked, its longest wave's duration (>= 4). */
-int vxrt_debug_tile_costs(vxrt_ctx* ctx, uint32_t* out, size_t n);
-
-/* Diagnostics: the launch order of the tracer's 8x8-pixel tiles as the last sort made it (order[k] = tile index, row-major over
- * ceil(width/8) x ceil(local_rows/8)), the per-tile costs it was made from, the number of tiles that walked the octree and how far
- * they were spread over the launch, in 1/256 (0 = plain longest-first; csrc/trace.hip: tile_scatter_kernel).  order and cost may
- * be null; n = the tile count.  VXRT_E_INVALID before a stream's first sort. */
-int vxrt_debug_tile_order(vxrt_ctx* ctx, uint32_t* order, uint32_t* cost, size_t n, uint32_t* walking_tiles, uint32_t* spread_256);
-
-/* Diagnostics: of this rank's pixels, how many primary rays of the next frame (camera as set) VXRT_OPT_SKY_CULL decides by its box
- * test instead of walking the octree.  They are counted in vxrt_stats.rays (each is one cast_bounded_ray of voxels.comp:134-247,
- * answered without a walk); for a camera at rest, rays per frame minus this = the rays that walked. */
-int vxrt_debug_culled_pixels(vxrt_ctx* ctx, uint64_t* count);
-/* Diagnostics of trace stream 0's last fused launch (VXRT_OPT_FUSED_TAIL): shader clocks to "every head block finished" and to the last
- * wave's end, chunks taken before / after that moment, idle sleeps, stamp polls, head claims, 0. */
-int vxrt_debug_fused_profile(vxrt_ctx* ctx, uint64_t out[8]);
 
 const char* vxrt_status_string(int status);
 const char* vxrt_last_error(void);               /* thread-local detail of the last failing call */
 uint32_t vxrt_abi_version(void);
-/* What this build of the library contains: VXRT_FEATURE_VARIANTS = it was compiled with -DVXRT_VARIANTS=1 and also holds the
- * schedules and the scene format that measured slower on MI355X and are kept for comparison (tracers 2, 3, 5; the wide scene
- * records).  The default build holds tracers 1 and 4 over the 8-byte records and refuses the others with VXRT_E_INVALID. */
-enum { VXRT_FEATURE_VARIANTS = 1 };
-uint32_t vxrt_build_features(void);
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "vxrt.h"
+#include "vxrt_host.h"
 
 namespace vxrt {
 

@@ -61,10 +61,13 @@ def require_variants(H, env=None, tracer=None, wide=None):
 
 @pytest.fixture(autouse=True)
 def _product_library_after_each_test():
-    yield
+    """Whatever library was in use before a test — the product, or the A/B build VXRT_LIB names — is in use again after it (ADVICE r5:
+    with VXRT_LIB set, the session used to stay on libvxrt_variants.so after the first case that had asked for it)."""
     from gpu_voxel_raytracer_amd import host
-    if host._LIB is not None and host.has_variants() and not os.environ.get("VXRT_LIB"):
-        host.use_library(None)
+    before = host._LIB
+    yield
+    if host._LIB is not before:
+        host._LIB = before           # None: lib() resolves it again on next use
 
 
 def have_reference():

@@ -1,5 +1,5 @@
-"""CPU: libvxrt.so loads without a GPU and exports every function include/vxrt.h declares (and the
-product never links the oracle)."""
+"""CPU: libvxrt.so loads without a GPU and exports every function its three headers declare — include/vxrt.h (the contract),
+vxrt_host.h (host-side helpers), vxrt_debug.h (test hooks and experiment options) — and the product never links the oracle."""
 import ctypes
 import os
 import re
@@ -8,10 +8,39 @@ import subprocess
 from conftest import ROOT
 
 
-def declared_functions():
-    text = open(os.path.join(ROOT, "include", "vxrt.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(vxrt_[a-z_0-9]+)\s*\(", text)))
+HEADERS = ("vxrt.h", "vxrt_host.h", "vxrt_debug.h")
+
+
+def declared_functions(headers=HEADERS):
+    names = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(vxrt_[a-z_0-9]+)\s*\(", text))
+    return sorted(names)
+
+
+def test_the_contract_header_holds_the_contract_only():
+    """include/vxrt.h is what a host binds to render — at most 40 entry points, no test hook, no experiment's
+    option; the helpers that need no context live in vxrt_host.h, everything else in vxrt_debug.h; no symbol is declared twice."""
+    contract, host, debug = (declared_functions((h,)) for h in HEADERS)
+    assert len(contract) <= 40, len(contract)
+    for must in ("vxrt_create", "vxrt_destroy", "vxrt_resize", "vxrt_set_voxels", "vxrt_load_vox", "vxrt_set_camera", "vxrt_set_scene_params",
+                 "vxrt_render", "vxrt_render_frames", "vxrt_render_path", "vxrt_render_spp", "vxrt_sync", "vxrt_read", "vxrt_read_async",
+                 "vxrt_read_wait", "vxrt_get_stats", "vxrt_halo_pack", "vxrt_halo_unpack", "vxrt_last_error", "vxrt_set_noise"):
+        assert must in contract, must
+    assert not [n for n in contract if n.startswith("vxrt_debug_")]
+    for lab in ("vxrt_create_tuned", "vxrt_detmath_probe", "vxrt_set_frame_number", "vxrt_build_features", "vxrt_build_records"):
+        assert lab in debug and lab not in contract, lab
+    assert [n for n in debug if n.startswith("vxrt_debug_")]
+    for tool in ("vxrt_vox_to_voxels", "vxrt_build_octree", "vxrt_camera_axis_scaled", "vxrt_blue_noise", "vxrt_noise_zip_write"):
+        assert tool in host and tool not in contract, tool
+    assert not (set(contract) & set(host)) and not (set(contract) & set(debug)) and not (set(host) & set(debug))
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "vxrt.h")).read(), flags=re.S)
+    opts = [int(v) for v in re.findall(r"VXRT_OPT_[A-Z_]+\s*=\s*(\d+)", text)]
+    assert opts and max(opts) <= 6, opts                   # the scheduling options of experiments (7 ..) are vxrt_debug.h's
+    dbg = open(os.path.join(ROOT, "include", "vxrt_debug.h")).read()
+    assert [int(v) for v in re.findall(r"#define VXRT_OPT_[A-Z_]+ \(\(vxrt_option\)(\d+)\)", dbg)] == list(range(7, 23))
 
 
 def test_every_declared_symbol_is_exported(H):
@@ -20,7 +49,7 @@ def test_every_declared_symbol_is_exported(H):
     lib = H.lib()
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.vxrt_abi_version() == 5
+    assert lib.vxrt_abi_version() == 6
     assert lib.vxrt_status_string(-13) == b"unexpected end of file"
 
 
@@ -66,6 +95,11 @@ def test_null_and_invalid_arguments_return_errors(H):
     assert lib.vxrt_render(None, 1) == H.E_INVALID
     assert lib.vxrt_read(None, 0, None, 0) == H.E_INVALID
     assert lib.vxrt_destroy(None) == 0
+    assert lib.vxrt_read_async(None, 0, None, ctypes.c_size_t(0), 0) == H.E_INVALID
+    assert lib.vxrt_read_wait(None, 0) == H.E_INVALID
+    assert lib.vxrt_host_alloc(ctypes.c_size_t(64), None) == H.E_INVALID
+    assert lib.vxrt_host_free(None) == 0
+    assert lib.vxrt_debug_touch_map(None, 1) == H.E_INVALID
     n = ctypes.c_size_t(0)
     assert lib.vxrt_vox_to_voxels(None, 0, None, None, 0, ctypes.byref(n), None) == H.E_INVALID
     assert lib.vxrt_menger_voxels(12, None, None, None, 0, ctypes.byref(n)) == H.E_INVALID
@@ -125,9 +159,10 @@ def test_header_is_plain_c_and_a_c99_client_links(tmp_path):
     that includes it links against libvxrt.so and sees the structs at the sizes the reference's Rust structs have (Uniforms: 148 B,
     src/context.rs:425-469)."""
     from gpu_voxel_raytracer_amd import _build
-    hdr = os.path.join(ROOT, "include", "vxrt.h")
-    chk = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-fsyntax-only", "-x", "c", hdr], capture_output=True, text=True)
-    assert chk.returncode == 0 and not chk.stderr.strip(), chk.stderr
+    for h in HEADERS:
+        hdr = os.path.join(ROOT, "include", h)
+        chk = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-fsyntax-only", "-x", "c", hdr], capture_output=True, text=True)
+        assert chk.returncode == 0 and not chk.stderr.strip(), chk.stderr
     src = tmp_path / "client.c"
     src.write_text('#include "vxrt.h"\n#include <stdio.h>\n'
                    'int main(void) { vxrt_uniforms u; vxrt_default_uniforms(&u);\n'
@@ -138,7 +173,7 @@ def test_header_is_plain_c_and_a_c99_client_links(tmp_path):
                             "-L" + os.path.dirname(_build.LIB), "-lvxrt", "-Wl,-rpath," + os.path.dirname(_build.LIB)], capture_output=True, text=True)
     assert build.returncode == 0, build.stderr
     run = subprocess.run([str(exe)], capture_output=True, text=True)
-    assert run.returncode == 0 and run.stdout.split() == ["5", "148", "12", "16", "0.05"], run.stdout
+    assert run.returncode == 0 and run.stdout.split() == ["6", "148", "12", "16", "0.05"], run.stdout
 
 
 def test_variants_library_loads_beside_the_product(H):
@@ -154,7 +189,7 @@ def test_variants_library_loads_beside_the_product(H):
     assert H.has_variants() and H.lib() is not product
     missing = [n for n in declared_functions() if not hasattr(H.lib(), n)]
     assert not missing, missing
-    assert H.lib().vxrt_abi_version() == product.vxrt_abi_version() == 5
+    assert H.lib().vxrt_abi_version() == product.vxrt_abi_version() == 6
     require_variants(H, tracer=4)            # a default-library case after it does not switch anything by itself ...
     assert H.has_variants()
     H.use_library(None)                      # ... the autouse fixture of conftest.py does, after every test

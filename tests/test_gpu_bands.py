@@ -118,6 +118,8 @@ def test_multirank_denoise_without_halo_is_refused(H, scenes, noise):
         Context(64, 64, rank=2, nranks=2)
     with pytest.raises(VxrtError):
         Context(64, 64, rank=0, nranks=2, band_rows=12)          # a multiple of 8 (the tracer's tiles); 16 for a denoise window
+    with pytest.raises(VxrtError):
+        Context(64, 64, rank=0, nranks=2, band_rows=6)           # 2, 4 or a multiple of 8: 6 is none of them (BandLayout refuses it too)
 
 
 @pytest.mark.parametrize("nranks,w,h,band", [(8, 96, 136, 8), (3, 64, 100, 8), (8, 96, 136, 4), (8, 72, 150, 2), (3, 64, 100, 4)])

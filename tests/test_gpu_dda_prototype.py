@@ -25,8 +25,6 @@ def test_unflagged_dda_rays_equal_the_octree_walk_bit_for_bit(H, scenes, scene, 
     from gpu_voxel_raytracer_amd import Camera, Context
     require_variants(H, tracer=5)                      # the prototype lives in the variants library
     pos, mrgb, size = scenes.load_scene(scene)
-    words, depth = H.build_octree(pos, mrgb)
-    g = D.grids(pos, mrgb, words, depth)
     w, h = 640, 360
     rng = np.random.default_rng(3)
     with Context(w, h, max_bounces=2) as ctx:
@@ -37,7 +35,7 @@ def test_unflagged_dda_rays_equal_the_octree_walk_bit_for_bit(H, scenes, scene, 
         d = (xs.reshape(-1, 1).astype(np.float32) * r - ys.reshape(-1, 1).astype(np.float32) * u).astype(np.float32) + f
         d = (d / np.sqrt((d * d).sum(1, keepdims=True, dtype=np.float32))).astype(np.float32)
         o = np.broadcast_to(cam.position, d.shape).astype(np.float32)
-        ow, od, _, _ = D.run(ctx, g, o, d, 1, 2.0)
+        ow, od = D.run(ctx, o, d, 1, 2.0)[:2]
         sets = [("primary", ow, od)]
         hit = ow[:, 0] != 0
         assert hit.sum() > 5000
@@ -46,10 +44,11 @@ def test_unflagged_dda_rays_equal_the_octree_walk_bit_for_bit(H, scenes, scene, 
         v = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
         flip = (v * ow[hit, 3:6]).sum(1) < 0
         v[flip] = -v[flip]
-        sets.append(("bounce",) + D.run(ctx, g, so, v, 1, 2.0)[:2])
+        sets.append(("bounce",) + D.run(ctx, so, v, 1, 2.0)[:2])
+        sets.append(("bounce, super-brick bits in LDS",) + D.run(ctx, so, v, 1, 2.0, lds_top=1)[:2])
         # axis-parallel and zero-component directions: never decided by the DDA
         z = v.copy(); z[:, 1] = 0.0
-        sets.append(("zero component",) + D.run(ctx, g, so[:4096], z[:4096], 1, 2.0)[:2])
+        sets.append(("zero component",) + D.run(ctx, so[:4096], z[:4096], 1, 2.0)[:2])
     for name, a, b in sets:
         flagged = b[:, 6] != 0
         same = (a[:, :6].view(np.uint32) == b[:, :6].view(np.uint32)).all(1) | ((a[:, 0] == 0) & (b[:, 0] == 0))

@@ -98,6 +98,42 @@ def test_moving_camera_reprojection(O, H, scenes, noise):
         assert (acc[hit][:, 3] < 0.5).mean() > 0.5
 
 
+def test_reference_loop_orbiting_camera_1080p_bit_exact(O, H, scenes, noise):
+    """the loop the reference runs (src/context.rs:2004-2075, 2136-2162) — per frame set the camera, the three
+    dispatches, hand the frame to the host — with its MAX_BOUNCES 3 (shaders/voxels.comp:4), an orbiting camera
+    (frame_loop.orbit_camera, the path bench.py's extra.reference_loop times), at 1920x1080, three frames, 5 x 5 denoise window:
+    accumulated and denoised colour of every frame bit-exact against the oracle's restatement of the three shaders.  The frames come
+    back through vxrt_read_async, two slots alternating, as a host that shows every frame would take them."""
+    from gpu_voxel_raytracer_amd import ACCUM_COLOR, ALL, DENOISED, Camera, Context
+    from gpu_voxel_raytracer_amd.frame_loop import orbit_camera
+    w, h, bounces, radius = 1920, 1080, 3, 2
+    ref = OraclePipeline(O, scenes, noise, "menger", w, h, bounces, radius)
+    pos, mrgb, size = scenes.load_scene("menger")
+    with Context(w, h, max_bounces=bounces, noise=noise) as ctx:
+        ctx.recreate_octree(pos, mrgb)
+        ctx.denoise_uniforms.radius = radius
+        den = [ctx.pinned_image(), ctx.pinned_image()]
+        cams = [orbit_camera(size, 0.62 + 0.25 * f / 960.0) for f in range(3)]
+        frames = []
+        for f, cam in enumerate(cams):
+            ctx.camera = Camera(*cam)
+            ctx.render(ALL)
+            if f >= 2:                                    # the slot's previous transfer (frame f - 1, 1-based) has to arrive before its buffer is used again
+                ctx.read_wait(f & 1)
+                frames[f - 2]["den"] = den[f & 1].array.copy()
+            frames.append({"acc": ctx.read(ACCUM_COLOR)})
+            ctx.read_async(DENOISED, den[f & 1], f & 1)   # travels while the next frame renders
+        for f in range(len(cams) - 2, len(cams)):
+            ctx.read_wait(f & 1)
+            frames[f]["den"] = den[f & 1].array.copy()
+        for b in den:
+            b.close()
+    for f, cam in enumerate(cams):
+        _, _, _, want_acc, want_den = ref.render(cam)
+        assert_bits_equal(frames[f]["acc"], want_acc, f"accumulated colour, frame {f + 1}")
+        assert_bits_equal(frames[f]["den"], want_den, f"denoised colour, frame {f + 1}")
+
+
 def test_resize_drops_history_and_scene_change_keeps_working(O, H, scenes, noise):
     from gpu_voxel_raytracer_amd import ALL, Camera, Context
     pos, mrgb, size = scenes.load_scene("castle")
