@@ -712,7 +712,7 @@ def pick_deal(world, steps, inflight=0, batch=0):
     bounce_kernel (220-235 us, drained again), 0.41-0.46 ms per block over the ranks; the all-in-one kernel needs 1.3 x the instructions
     but drains once: 0.37-0.44 ms.  And 8-row bands leave a rank only ~8 bands with geometry (1080 rows, 64-row period): the ranks'
     blocks differ by 16 %; 4-row bands — whose rows still pair up in the waves of a frame-lane launch (2 rows x 4 frames) — bring them
-    within 4 %: all-in-one + 4-row bands 0.405-0.423 ms for every rank (scripts/r5e.sh, r5j.sh; profiles/r05/short_block.txt).  Two
+    within 4 %: all-in-one + 4-row bands 0.405-0.423 ms for every rank (scripts/archive/r05/r5e.sh, r5j.sh; profiles/r05/short_block.txt).  Two
     and four ranks, and every steady-state run, keep the default: their launches are long enough for the pair to win."""
     short = steps < 2 * 16 * (inflight if inflight > 0 else (2 if world == 1 else 3))
     if short and world >= 8 and inflight <= 0 and batch <= 0:
@@ -860,16 +860,29 @@ def init_dist(need_gpu=True):
                 # one GPU — leaves a half-made group that nobody can destroy and that warns about it at exit; made by the first
                 # collective instead, it fails inside a registered group, which destroy_process_group below shuts down.  The device is
                 # set above, so the collectives know where they run.)
-                dist.init_process_group("nccl", timeout=datetime.timedelta(seconds=float(os.environ.get("VXRT_BENCH_NCCL_TIMEOUT", "120"))))
+                try:
+                    dist.init_process_group("nccl", timeout=datetime.timedelta(seconds=float(os.environ.get("VXRT_BENCH_NCCL_TIMEOUT", "120"))))
+                    store.set(f"pre_{rank}", "ok")
+                except Exception:
+                    store.set(f"pre_{rank}", "failed")
+                    raise
+                # nobody enters the first collective unless EVERY rank got this far: a rank whose init failed has said so,
+                # and its peers raise here instead of sitting in the all-reduce until the collective timeout.  (A failure INSIDE the first
+                # collective is symmetric in every case seen — two ranks on one device — and raises on all ranks; an asymmetric one would
+                # still end after the timeout, possibly by the NCCL watchdog's abort: a non-zero status, nothing restarted.)
+                pre = [store.get(f"pre_{r}").decode() for r in range(world)]
+                if any(w != "ok" for w in pre):
+                    raise RuntimeError(f"a peer could not initialise its RCCL process group ({pre})")
                 probe = torch.ones(1, device="cuda")
                 dist.all_reduce(probe)
                 torch.cuda.synchronize()
                 if int(probe.item()) != world:
                     raise RuntimeError(f"all_reduce over RCCL returned {probe.item()} for a world of {world}")
             except StopIteration:
-                pass
+                store.set(f"pre_{rank}", "ok")
             except Exception as e:  # noqa: BLE001
                 err = e
+                store.set(f"pre_{rank}", "failed")          # (the test hooks raise before the group is made: the peers must not wait for this word)
                 print(f"bench.py rank {rank}: RCCL did not come up ({e!r})", file=sys.stderr, flush=True)
             store.set(f"nccl_{rank}", "failed" if err is not None else "ok")
             words = [store.get(f"nccl_{r}").decode() for r in range(world)]       # blocks until every rank has spoken

@@ -12,8 +12,8 @@ SOURCES = ["api_context.hip", "api_scene.hip", "api_trace.hip", "api_frame.hip",
            "noise_zip.cpp", "vox_scene.cpp"]
 # -DVXRT_VARIANTS=1 (scripts/test_variants.sh): the schedules and the scene format that measured slower and are kept for comparison —
 # tracers 2 (wavefront), 3 (ray queues), 5 (per-lane path refill) and the wide records (two tree levels per 16-byte record)
-VARIANT_SOURCES = ["trace_wavefront.hip", "trace_paths.hip", "trace_pool.hip", "trace_dda.hip"]
-HEADERS = ["ctx.h", "halo_view.h", "kernels.h", "trace_common.h", "trace_tail_body.h", "ray_queue.h", "walk_wide.h", "scene_host.h", "vx_vec.h", os.path.join("..", "..", "include", "vxrt.h"),
+VARIANT_SOURCES = ["trace_wavefront.hip", "trace_paths.hip", "trace_pool.hip", "trace_dda.hip", "trace_fused.hip"]
+HEADERS = ["ctx.h", "halo_view.h", "kernels.h", "trace_common.h", "trace_block.h", "trace_tail_body.h", "ray_queue.h", "walk_wide.h", "scene_host.h", "vx_vec.h", os.path.join("..", "..", "include", "vxrt.h"),
            os.path.join("..", "..", "include", "vxrt_host.h"), os.path.join("..", "..", "include", "vxrt_debug.h"),
            os.path.join("..", "..", "include", "vxrt_detmath.h"),
            os.path.join("..", "..", "include", "vxrt_bluenoise.h")]

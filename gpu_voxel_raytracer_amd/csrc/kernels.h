@@ -41,6 +41,7 @@ struct WideRec {
     uint32_t mlo, mhi, base, top;
 };
 
+constexpr unsigned kSortBlocks = 64, kSortBins = 128;   // the tile sort (trace.hip): its scratch is [bin][block] + {walking tiles, spread}
 constexpr unsigned kRaySlots = 2048;  // ray counters, one per 64-byte line (TraceArgs::ray_counter)
 
 struct Cam {  // first 64 bytes of Uniforms, without padding

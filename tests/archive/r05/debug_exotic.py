@@ -1,7 +1,7 @@
 """ORACLE-BASED DIAGNOSTIC (not collected by pytest): the kernels' cast_bounded_ray (vxrt_debug_cast_rays) against the oracle's for
 rays with zero direction components — origins near / exactly on voxel planes, +0 and -0 — and for the logged ray of the stress failure."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import numpy as np
 from gpu_voxel_raytracer_amd import Context, scenes
 from oracle import oracle as O

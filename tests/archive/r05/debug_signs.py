@@ -1,6 +1,6 @@
 """ORACLE-BASED DIAGNOSTIC (not collected by pytest): device vs host bit equality (signs of zero included) on special values."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import numpy as np
 from gpu_voxel_raytracer_amd import host as H
 from oracle import oracle as O

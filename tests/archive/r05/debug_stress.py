@@ -2,7 +2,7 @@
 EVERY frame, one at a time, image by image and ray count by ray count, with the oracle; prints cameras and pixels that differ.
 usage: debug_stress.py <scene> <bounces> <cameras> [tracer] [seed offset]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import numpy as np
 from gpu_voxel_raytracer_amd import TRACE, Camera, Context, scenes
 from oracle import oracle as O

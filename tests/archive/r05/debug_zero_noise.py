@@ -1,7 +1,7 @@
 """ORACLE-BASED DIAGNOSTIC (not collected by pytest): traces with noise tables full of special values (exact 0, 0.5, 0.25 ...) so that
 the degenerate shading paths (plane_radius = 0, phi = 0, rand_dir = 0 ...) occur at every pixel; compares GPU and oracle per pixel."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import numpy as np
 from gpu_voxel_raytracer_amd import TRACE, Camera, Context, scenes
 from oracle import oracle as O
