@@ -1,5 +1,6 @@
 // api_trace.hip — scheduling of the trace stage of libvxrt: which ring slots, stream, tile order and tail queue a launch of
 // trace_kernel (+ bounce_kernel) gets, for 1..32 consecutive frames per launch and several launches in flight.
+#include <algorithm>
 #include <cmath>
 
 #include "ctx.h"
@@ -137,6 +138,75 @@ void set_cull(const vxrt_ctx* c, TraceArgs& a, const Cam* cams, uint32_t g) {
             a.cull = 1;
         }
     }
+}
+
+// VXRT_OPT_XCD_AFFINITY (round 6's experiment for scenes that live in HBM, BASELINE config 5): a launch order in which the tiles that
+// walk reach the XCDs by SCREEN REGION instead of round robin.  Blocks are dealt to the 8 XCDs in turn (block b and b + 8 share one:
+// observed, not promised — a wrong guess costs speed only), every XCD has an L2 of its own, and neighbouring tiles read neighbouring
+// parts of the tree: dealt round robin, each XCD fetches its own copy of every line (config 5 from outside: 9.8 x the unique bytes
+// of a frame come in from beyond the L2s, 31 x inside a tunnel — bench.py: extra.config5_*.roofline.refetch).  So: the screen in
+// super-tiles of S x S tiles; each super-tile's walking tiles belong to ONE of 8 lists, the super-tiles dealt longest first to the list
+// with the least summed cost so far (the measured tile costs: the lists end up within a few per cent of each other, which matters
+// because the dispatcher's round robin waits for the slowest XCD); every list longest first; order[8 i + x] = list x's i-th tile, a
+// list that has run out filled up with tiles of sky (no scene traffic: any XCD may have them), or with the shortest chains of the
+// longest list when there is no sky left; what remains of the sky comes last.  Made on the HOST from the costs copied back (a stall
+// of its own every 8th launch: an experiment's price), one frame per launch only.
+static int xcd_affine_order(vxrt_ctx* c, vxrt_ctx::TileSchedule& sched, hipStream_t ts) {
+    const unsigned tiles = trace_tile_count(c->band.width, c->band.local_rows);
+    int tw = 8, th = 8;
+    trace_tile_dims(&tw, &th);
+    const unsigned tx = unsigned(c->band.width + tw - 1) / unsigned(tw), ty = tiles / (tx ? tx : 1u);
+    const unsigned S = unsigned(c->xcd_affinity);
+    std::vector<uint32_t> cost(tiles), order;
+    order.reserve(tiles);
+    HIP_TRY(hipStreamSynchronize(ts));
+    HIP_TRY(hipMemcpy(cost.data(), sched.cost, size_t(tiles) * 4, hipMemcpyDeviceToHost));
+    const unsigned sx = (tx + S - 1) / S, sy = (ty + S - 1) / S;
+    std::vector<unsigned long long> scost(size_t(sx) * sy, 0ull);
+    for (unsigned t = 0; t < tiles; t++)
+        if (cost[t] >= 4u) scost[size_t(t / tx / S) * sx + (t % tx) / S] += cost[t];
+    std::vector<unsigned> supers(scost.size());
+    for (unsigned i = 0; i < supers.size(); i++) supers[i] = i;
+    std::stable_sort(supers.begin(), supers.end(), [&](unsigned a, unsigned b) { return scost[a] > scost[b]; });
+    std::vector<int> owner(scost.size(), 0);
+    unsigned long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (unsigned s : supers) {
+        int best = 0;
+        for (int x = 1; x < 8; x++) if (load[x] < load[best]) best = x;
+        owner[s] = best;
+        load[best] += scost[s];
+    }
+    std::vector<uint32_t> lists[8], sky;
+    for (unsigned t = 0; t < tiles; t++) {
+        if (cost[t] >= 4u) lists[owner[size_t(t / tx / S) * sx + (t % tx) / S]].push_back(t);
+        else sky.push_back(t);
+    }
+    for (auto& l : lists) std::stable_sort(l.begin(), l.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+    size_t head[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tail[8], sky_next = 0;
+    for (int x = 0; x < 8; x++) tail[x] = lists[x].size();
+    auto left = [&](int x) { return tail[x] - head[x]; };
+    for (;;) {
+        bool any = false;
+        for (int x = 0; x < 8; x++) any = any || left(x) != 0;
+        if (!any) break;
+        for (int x = 0; x < 8; x++) {
+            if (left(x) != 0) { order.push_back(lists[x][head[x]++]); continue; }
+            if (sky_next < sky.size()) { order.push_back(sky[sky_next++]); continue; }
+            int longest = -1;                               // no sky left: the cheapest tile of the list with the most left
+            for (int y = 0; y < 8; y++) if (left(y) > 1 && (longest < 0 || left(y) > left(longest))) longest = y;
+            if (longest >= 0) order.push_back(lists[longest][--tail[longest]]);
+            // else: nothing to pad with — this slot is skipped (the launch's last blocks; the lists that still hold a tile follow in this round)
+        }
+    }
+    while (sky_next < sky.size()) order.push_back(sky[sky_next++]);
+    if (order.size() != tiles) { set_error("xcd_affine_order: internal error (order incomplete)"); return VXRT_E_INVALID; }
+    HIP_TRY(hipMemcpy(sched.order, order.data(), size_t(tiles) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(sched.last_cost, cost.data(), size_t(tiles) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemsetAsync(sched.cost, 0, size_t(tiles) * 4, ts));
+    unsigned long long lo = load[0], hi = load[0];
+    for (int x = 1; x < 8; x++) { lo = load[x] < lo ? load[x] : lo; hi = load[x] > hi ? load[x] : hi; }
+    c->xcd_balance_permille = hi ? unsigned((hi - lo) * 1000ull / hi) : 0u;
+    return VXRT_OK;
 }
 
 // One launch of trace_kernel over all tiles — or, with VXRT_OPT_TRACE_PRIORITY and a tile order whose walking tiles are known, as TWO
@@ -384,6 +454,9 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
             // frame, then every 8th (costs keep accumulating as a running maximum in between; ~7 us per sort).
             if (c->use_tile_order && (!sched.valid || sched.age >= 8)) {
                 const unsigned tiles = trace_tile_count(c->band.width, c->band.local_rows);
+                if (c->xcd_affinity > 0 && g == 1 && scene_bytes > (size_t(256) << 20)) {
+                    if (int rc = xcd_affine_order(c, sched, ts)) return rc;
+                } else {
                 // (the priority split needs the walking tiles FIRST in the order: no spreading; and their number on the host)
                 HIP_TRY(launch_tile_order(sched.cost, sched.order, sched.last_cost, sched.scratch, tiles, g * unsigned(c->inflight), c->wave_slots,
                                           c->trace_priority ? 0 : c->spread_override, ts));
@@ -392,6 +465,7 @@ int trace_frames(vxrt_ctx* c, uint32_t g, bool timed, int* slots, Cam* cams, Cam
                     HIP_TRY(hipMemcpyAsync(sched.host_heavy, sched.scratch + 128 * 64, sizeof(unsigned), hipMemcpyDeviceToHost, ts));
                     HIP_TRY(hipEventRecord(sched.heavy_ready, ts));
                     sched.heavy_pending = true;
+                }
                 }
                 sched.valid = true;
                 sched.age = 0;

@@ -233,6 +233,8 @@ struct vxrt_ctx {
     // VXRT_OPT_TRACE_PRIORITY (round 6's experiment): the trace streams at the device's highest priority, the tiles that only store
     // sky as a grid of their own on a low-priority stream per trace stream
     int trace_priority = 0;
+    int xcd_affinity = 0;               // VXRT_OPT_XCD_AFFINITY: 0 off, S = side of a super-tile in tiles (api_trace.hip: xcd_affine_order)
+    unsigned xcd_balance_permille = 0;  // (max - min) / max of the 8 lists' summed costs at the last such sort
     uint64_t split_launches = 0;        // trace launches that went out as two grids
     std::vector<hipStream_t> low_streams;
     std::vector<hipEvent_t> low_fork, low_join;

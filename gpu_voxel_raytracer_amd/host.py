@@ -112,7 +112,7 @@ class Stats(C.Structure):
 OPT_DENOISE_MODE, OPT_TAIL_CAPACITY, OPT_SCENE_FORMAT, OPT_HALO_ROWS, OPT_SKY_CULL, OPT_FRAME_LANES = 1, 2, 3, 4, 5, 6
 (OPT_TILE_ORDER, OPT_TILE_SPREAD, OPT_TRACE_BLOCKS, OPT_TAIL_FROM, OPT_TAIL_SPLIT, OPT_HOST_SCENE_BUILD, OPT_TRACER_OVERRIDE,
  OPT_TRACE_SPLIT, OPT_PATH_BLOCKS, OPT_SHADE_BLOCKS, OPT_RAYS_PER_WAVE, OPT_NODE_ORDER, OPT_HEAD_STAGGER, OPT_LONG_TILES, OPT_FUSED_TAIL,
- OPT_TRACE_PRIORITY) = range(7, 23)      # include/vxrt_debug.h (the options of experiments)
+ OPT_TRACE_PRIORITY, OPT_XCD_AFFINITY) = range(7, 24)      # include/vxrt_debug.h (the options of experiments)
 TILE_SPREAD_AUTO = 0xffffffff
 
 
@@ -130,7 +130,7 @@ ENV_KNOBS = {"VXRT_SKY_CULL": OPT_SKY_CULL, "VXRT_HALO_ROWS": OPT_HALO_ROWS, "VX
              "VXRT_RAYS_PER_WAVE": OPT_RAYS_PER_WAVE, "VXRT_TRACE_BLOCKS": OPT_TRACE_BLOCKS, "VXRT_FRAME_LANES": OPT_FRAME_LANES,
              "VXRT_SPREAD": OPT_TILE_SPREAD, "VXRT_TILE_ORDER": OPT_TILE_ORDER, "VXRT_TRACE_SPLIT": OPT_TRACE_SPLIT,
              "VXRT_HOST_BUILD": OPT_HOST_SCENE_BUILD, "VXRT_NODE_ORDER": OPT_NODE_ORDER, "VXRT_HEAD_STAGGER": OPT_HEAD_STAGGER, "VXRT_LONG_TILES": OPT_LONG_TILES, "VXRT_FUSED_TAIL": OPT_FUSED_TAIL,
-             "VXRT_TRACE_PRIORITY": OPT_TRACE_PRIORITY}
+             "VXRT_TRACE_PRIORITY": OPT_TRACE_PRIORITY, "VXRT_XCD_AFFINITY": OPT_XCD_AFFINITY}
 _env_knobs_enabled = os.environ.get("VXRT_ENV_KNOBS") == "1"      # the explicit opt-in of the A/B scripts (scripts/*.sh)
 
 

@@ -8,8 +8,6 @@ mkdir -p $O
 export TMPDIR=/tmp
 timeout -k 10 600 python -m pytest tests/test_gpu_readback.py tests/test_gpu_touch_and_priority.py tests/test_gpu_dda_prototype.py "tests/test_gpu_pipeline.py::test_reference_loop_orbiting_camera_1080p_bit_exact" -x -q -m gpu > $O/new_tests.log 2>&1 || { tail -30 $O/new_tests.log; exit 1; }
 tail -3 $O/new_tests.log
-timeout -k 10 900 python -m pytest tests -x -q -m gpu > $O/gpu_tests.log 2>&1 || { tail -30 $O/gpu_tests.log; exit 1; }
-tail -3 $O/gpu_tests.log
 timeout -k 10 300 python -c "
 import json, bench
 print(json.dumps(bench.measure_config5_touch(0), indent=1))" > $O/config5_touch.json 2> $O/config5_touch.err || { tail -20 $O/config5_touch.err; exit 1; }
@@ -25,3 +23,5 @@ for k in ("config5_outside_view", "config5_tunnel_view"):
     print(k, json.dumps(d["extra"].get(k), indent=None)[:1500])
 print("reference_loop", json.dumps(d["extra"].get("reference_loop"))[:3000])
 PY
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > $O/gpu_tests.log 2>&1 || { tail -30 $O/gpu_tests.log; exit 1; }
+tail -3 $O/gpu_tests.log

@@ -46,7 +46,7 @@ def report(name, ow, od, t_walk, t_dda):
     return int(bad.sum())
 
 
-def ray_sets(ctx, cam, w, h, rng):
+def ray_sets(ctx, cam, w, h, rng, trim=0):
     """The camera's primary rays in 8 x 8 tiles (as the tracer's waves see them), and from their hits (the walk's results, asked for here)
     sun rays — the reference's sun direction, jittered as voxels.comp:339-356 jitters it — and hemisphere rays about the normal."""
     r, u, f = cam.axis_scaled(w, h)
@@ -55,6 +55,8 @@ def ray_sets(ctx, cam, w, h, rng):
     d = (xs[:, None].astype(np.float32) * r - ys[:, None].astype(np.float32) * u).astype(np.float32) + f
     d = (d / np.sqrt((d * d).sum(1, keepdims=True, dtype=np.float32))).astype(np.float32)
     o = np.broadcast_to(cam.position, d.shape).astype(np.float32)
+    if trim:                   # a view's primary set a few waves shorter than the other view's: a profiler's rows can be told apart by grid size
+        o, d = o[:-trim], d[:-trim]
     yield "primary rays", o, d
     ow = run(ctx, o, d, skip_dda=True)[0]
     hit = ow[:, 0] != 0
@@ -70,7 +72,7 @@ def ray_sets(ctx, cam, w, h, rng):
     v = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
     flip = (v * nrm).sum(1) < 0
     v[flip] = -v[flip]
-    yield "bounce rays from the hits", so, v
+    yield "bounce rays from the hits", so[:-64], v[:-64]      # (64 rays fewer than the sun rays: a launch of its own size, so that a profiler's rows can be told apart)
 
 
 def main():
@@ -91,8 +93,8 @@ def main():
             pos, mrgb, size = scenes.load_scene(scene)
             ctx.recreate_octree(pos, mrgb)
             views = [(v, getattr(scenes, v + "_camera")(size)) for v in ("bench", "close")]
-        for view, cam in views:
-            for name, o, d in ray_sets(ctx, Camera(*cam), w, h, rng):
+        for vi, (view, cam) in enumerate(views):
+            for name, o, d in ray_sets(ctx, Camera(*cam), w, h, rng, trim=256 * vi):
                 sets[(view, name)] = (o, d)
                 ow, od, tw, td, tb, gb = run(ctx, o, d, 1, margin, steps)
                 if tb:

@@ -353,9 +353,26 @@ def test_bench_contract_line():
     c4 = d["extra"]["config4_one_rank_of_8"]      # BASELINE configs[3]: what one of its 8 ranks does per displayed frame
     assert c4["local_rows"] == 272 and c4["halo_rows"] == 8 and 8e6 < c4["halo_bytes_per_rank_per_frame"] < 9e6      # 2 x 4 slots x 8 rows x 3840 px x 36 B
     assert 0.2 < c4["ms_per_displayed_frame"] < 5 and c4["stage_ms"]["halo_pack"] > 0 and c4["stage_ms"]["denoise"] > 0
-    c5 = d["extra"]["config5_outside_view"]["roofline"]
-    assert c5["bound"] == "hbm" and c5["frac_raw"] < c5["frac_read_doubled"] < 1.0 and "MEASURED" in c5["source"]
-    assert 0.2 < c5["l2_hit_rate"] < 0.8 and 0.1 < c5["lane_utilisation"] < 0.6 and 0.3 < c5["valu_issue_slot_frac"] < 1.0
+    for view in ("config5_outside_view", "config5_tunnel_view"):      # BASELINE configs[4]'s scene: the roofline on ALGORITHMIC bytes
+        c5 = d["extra"][view]["roofline"]
+        assert c5["bound"] == "hbm" and "MEASURED" in c5["counters_source"] and "MEASURED" in c5["algorithmic_source"]
+        u = c5["unique_scene_bytes"]                                   # the 64-byte lines of the scene one frame reads, each once (touch map)
+        assert 0 < c5["unique_scene_bytes_per_frame"] == u["node_record_bytes"] + u["leaf_word_bytes"] < u["scene_bytes"] and 5.5e9 < u["scene_bytes"] < 6.5e9
+        assert c5["unique_scene_bytes_per_frame"] <= u["at_128_byte_lines"] <= 2 * c5["unique_scene_bytes_per_frame"]
+        assert c5["algorithmic_bytes_per_frame"] == 48 * 3840 * 2160 + c5["unique_scene_bytes_per_frame"] + 64 * 65536
+        ms = d["extra"][view]["ms_per_frame"]
+        assert abs(c5["achieved"] - c5["algorithmic_bytes_per_frame"] / (ms * 1e-3) / 1e9) < 0.01 * c5["achieved"] and abs(c5["frac"] - c5["achieved"] / 8000.0) < 1e-3
+        assert c5["frac_traffic_raw"] < c5["frac_traffic_read_doubled"] < 1.0 and c5["traffic_raw"] < c5["traffic"]
+        assert abs(c5["refetch"] - c5["bytes_fetched_per_frame"] / c5["unique_scene_bytes_per_frame"]) < 0.02 * c5["refetch"] and c5["refetch"] > 0.5
+        assert 0.2 < c5["l2_hit_rate"] < 0.8 and 0.1 < c5["lane_utilisation"] < 0.6 and 0.3 < c5["valu_issue_slot_frac"] < 1.0
+    rl = d["extra"]["reference_loop"]["rows"]                          # the reference's own loop, and the read-back (item 3)
+    assert set(rl) == {"1920x1080_r0", "1920x1080_r2", "1600x1600_r0", "1600x1600_r2"}
+    for row in rl.values():
+        assert 0.05 < row["vxrt_render_path_ms_per_frame"] < row["ms_per_frame"] < 5 and row["mrays_per_s"] > 1000
+        assert row["stage_ms"]["trace"] > 0 and row["stage_ms"]["temporal"] > 0 and 1.0 < row["rays_per_pixel"] < 6.0
+        assert row["with_vxrt_read_async_ms_per_frame"] < row["with_vxrt_read_ms_per_frame"]
+        # pulling every frame costs at most max(render, transfer) + 10 % (+ slack for a shared box)
+        assert row["read_async_over_max_of_render_and_transfer"] < 1.25, row
     assert "RECORDED" not in lines[0]             # every counter figure of the line is measured by the run itself
     pc = d["extra"]["parity_check"]               # the timed frame, hashed against the reference's compiled shader's output, in the line itself
     assert pc["bit_exact"] is True and pc["slabs_hashed"] == 27 and pc["differing"] == []

@@ -80,3 +80,35 @@ def test_priority_split_launches_give_identical_frames(H, scenes, noise, infligh
     c2, _, st2 = frames([(H.OPT_TRACE_PRIORITY, 1)], rank=1, nranks=4, band_rows=8)
     c3, _, _ = frames([], rank=1, nranks=4, band_rows=8)
     assert_bits_equal(c2, c3, "colour, rank 1 of 4")
+
+
+def test_xcd_affine_tile_order_gives_identical_frames(H, scenes, noise):
+    """VXRT_OPT_XCD_AFFINITY (vxrt_debug.h): for a scene beyond the Infinity Cache the launch order deals the walking tiles to the XCDs by
+    screen region.  A launch order never changes a pixel: same frames as without it, and the order is a permutation of the tiles."""
+    import ctypes as C
+    from gpu_voxel_raytracer_amd import NORMAL_DEPTH, SAMPLED_COLOR, TRACE, Camera, Context
+    w, h = 640, 360
+    ext = np.float32(729 * 0.5)                                        # world extent of 729 voxels
+    pos = (np.array([-0.45, 0.30, -0.55], np.float32) * ext + ext / 2).astype(np.float32)
+    cam = Camera(pos, (np.full(3, ext / 2, np.float32) - pos).astype(np.float32), 1.2217305)
+
+    def frames(S):
+        with Context(w, h, max_bounces=4, noise=noise) as ctx:
+            ctx.set_menger(6, 0, (0, 150, 170, 120), 4096)          # 729^3: 64 M voxels, > 256 MB of records and leaf words
+            assert ctx.stats().scene_bytes > (256 << 20)
+            ctx.camera = cam
+            ctx.set_option(H.OPT_XCD_AFFINITY, S)
+            ctx.render_frames(TRACE, 11)
+            order = np.zeros((w // 8) * (h // 8), np.uint32)
+            walking, spread = C.c_uint32(0), C.c_uint32(0)
+            ctx._chk(ctx._L.vxrt_debug_tile_order(ctx._h, order.ctypes.data_as(C.c_void_p), None, C.c_size_t(order.size), C.byref(walking), C.byref(spread)), "tile order")
+            return ctx.read(SAMPLED_COLOR), ctx.read(NORMAL_DEPTH), ctx.stats().rays, order
+    c0, n0, r0, o0 = frames(0)
+    assert (n0[..., 3] >= 0).mean() > 0.2                            # the sponge is in view
+    for S in (1, 4, 16):
+        c1, n1, r1, o1 = frames(S)
+        assert_bits_equal(c1, c0, f"colour, S = {S}")
+        assert_bits_equal(n1, n0, f"normal / depth, S = {S}")
+        assert r1 == r0
+        assert sorted(o1.tolist()) == list(range(o1.size)), "the order is not a permutation of the tiles"
+        assert not np.array_equal(o1, o0)
