@@ -940,6 +940,39 @@ def reduce_sum(dist, torch, dev, values):
     return [int(v) for v in t.tolist()]
 
 
+def per_rank_report(dist, world, rank, block_s, start_ns, end_ns, extra=None):
+    """N > 1: what every rank saw of the timed blocks, gathered AFTER the timed region (nothing is exchanged inside it), so that the first run on
+    a real multi-GPU node explains itself: per rank the median / min / max of its own block time (barrier ->
+    its own queues drained), and per block how far apart the ranks LEFT the barrier (launch skew; CLOCK_MONOTONIC is shared by the
+    processes of one host) and how far apart they finished.  -> dict on rank 0, None elsewhere."""
+    if dist is None:
+        return None
+    mine = {"rank": rank, "block_s": [float(v) for v in block_s], "start_ns": [int(v) for v in start_ns], "end_ns": [int(v) for v in end_ns]}
+    if extra:
+        mine.update(extra)
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    if rank != 0:
+        return None
+    everyone.sort(key=lambda e: e["rank"])
+    nb = min(len(e["block_s"]) for e in everyone)
+    med = lambda xs: float(sorted(xs)[len(xs) // 2]) if xs else None  # noqa: E731
+    skew = [(max(e["start_ns"][b] for e in everyone) - min(e["start_ns"][b] for e in everyone)) * 1e-6 for b in range(nb)]
+    spread = [(max(e["end_ns"][b] for e in everyone) - min(e["end_ns"][b] for e in everyone)) * 1e-6 for b in range(nb)]
+    last = [max(range(len(everyone)), key=lambda r: everyone[r]["end_ns"][b]) for b in range(nb)]
+    ranks = []
+    for e in everyone:
+        row = {"rank": e["rank"], "block_ms": {"median": round(med(e["block_s"]) * 1e3, 4), "min": round(min(e["block_s"]) * 1e3, 4), "max": round(max(e["block_s"]) * 1e3, 4)},
+               "blocks_it_finished_last": sum(1 for r in last if r == e["rank"])}
+        for k, v in e.items():
+            if k not in ("rank", "block_s", "start_ns", "end_ns"):
+                row[k] = v
+        ranks.append(row)
+    return {"blocks": nb, "launch_skew_after_the_barrier_ms": {"median": round(med(skew), 4), "max": round(max(skew), 4)},
+            "finish_spread_ms": {"median": round(med(spread), 4), "max": round(max(spread), 4)}, "ranks": ranks,
+            "note": "block_ms: a rank's own clock from leaving the barrier to its own queues being empty; the line's ms_per_step is the max over ranks, block by block"}
+
+
 def block_count(est_block_s, asked):
     """>= 50 blocks and >= 1 s of GPU time (>= 0.25 s when asked for fewer blocks than that needs would take minutes)."""
     if asked > 0:
@@ -984,15 +1017,19 @@ def trace_bench(args):
     blocks = block_count(est, args.blocks)
 
     times, rays_blk, kernel_ms, launches, frames_timed, local_px = [], [], 0.0, 0, 0, 0
+    own_s, start_ns, end_ns = [], [], []
     for _ in range(blocks):
         ctx.reset_stats()
         barrier()
+        start_ns.append(time.monotonic_ns())
         t0 = time.perf_counter()
         ctx.render_frames(TRACE | TIMED, args.steps)   # K steps = K frames, submitted back to back
         ctx.sync()
         if dist is not None:
             torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        end_ns.append(time.monotonic_ns())
+        own_s.append(elapsed)
         st = ctx.stats()
         elapsed = reduce_max(dist, torch, red_dev, [elapsed])[0]
         rays = reduce_sum(dist, torch, red_dev, [st.rays])[0]
@@ -1006,6 +1043,7 @@ def trace_bench(args):
     # primary rays the sky cull answers without a walk (counted in `rays`: each is one cast_bounded_ray of the shader), all ranks
     culled = reduce_sum(dist, torch, red_dev, [ctx.culled_pixels()])[0]
     rccl = world_info(dist, torch, world, rank, device, backend)
+    per_rank = per_rank_report(dist, world, rank, own_s, start_ns, end_ns, {"local_rows": int(ctx.stats().local_rows), "rays_per_block": int(st.rays)})
 
     if rank == 0:
         order = np.argsort(times)
@@ -1094,6 +1132,8 @@ def trace_bench(args):
         }
         if rccl is not None:
             out["rccl"] = rccl
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if world == 1 and not args.no_extras:
             # secondary figures, measured in this run after the headline block (none of them is `value`)
             out["timing"]["latency_ms_one_frame_at_a_time"] = round(measure_latency(Context, Camera, TRACE, pos, mrgb, cam, device, args.bounces), 4)
@@ -1242,6 +1282,7 @@ def pipeline_bench(args):
         ctx.reset_stats()
         xchg[0] = 0.0
         barrier()
+        own["start_ns"].append(time.monotonic_ns())
         t0 = time.perf_counter()
         for _ in range(args.steps):
             frame(overlap)
@@ -1249,15 +1290,25 @@ def pipeline_bench(args):
         if dist is not None and backend == "nccl":
             torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        own["end_ns"].append(time.monotonic_ns())
+        own["block_s"].append(elapsed)
+        own["exchange_s"].append(xchg[0])
         st = ctx.stats()
         elapsed, x = reduce_max(dist, torch, red_dev, [elapsed, xchg[0]])
         rays = reduce_sum(dist, torch, red_dev, [st.rays])[0]
         return elapsed, x, rays, st
 
+    own = {"start_ns": [], "end_ns": [], "block_s": [], "exchange_s": []}
     elapsed, _, rays, st = timed_block(True)
     sync_elapsed, x, _, sync_st = timed_block(False) if world > 1 else (elapsed, 0.0, rays, st)
     info = ctx.halo_info()
     rccl = world_info(dist, torch, world, rank, device, backend)
+    # per rank: block 0 = the overlapped loop, block 1 = the synchronous pass, whose exchange time on this rank's host
+    # clock (pack + both messages on the wire + unpack, nothing overlapping) is the halo's wire time as this rank sees it
+    per_rank = per_rank_report(dist, world, rank, own["block_s"], own["start_ns"], own["end_ns"],
+                               {"local_rows": int(st.local_rows), "halo_exchange_ms_synchronous": round(own["exchange_s"][-1] / args.steps * 1e3, 4),
+                                "halo_pack_ms": round(st.halo_pack_ms / max(st.halo_exchanges, 1), 5), "halo_unpack_ms": round(st.halo_unpack_ms / max(st.halo_exchanges, 1), 5),
+                                "trace_ms_per_frame": round(st.trace_ms / args.steps, 4), "denoise_ms_per_frame": round(st.denoise_ms / args.steps, 4)})
     if rank == 0:
         px = w * h
         alg = (48 * spp + 16 * spp + 16 + 80 + 64) * px     # spp trace frames + their average + temporal + denoise
@@ -1288,6 +1339,8 @@ def pipeline_bench(args):
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5), "traffic": None}}
         if rccl is not None:
             out["rccl"] = rccl
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist is not None:

@@ -52,7 +52,8 @@ struct Cam {  // first 64 bytes of Uniforms, without padding
 // bands, band gb -> rank gb % nranks.  Whole ROUNDS of nranks bands are band_rows rows high (`full_bands` bands, rows [0, tail_y0)).
 // When the frame is not a whole number of rounds, the LAST round takes the remainder as well: its bands are `tail_rows` rows high, the
 // smallest multiple of the tile height (16 rows when band_rows is a multiple of 16, else 8) that covers the last round + remainder in
-// nranks bands — band_rows <= tail_rows < 2 band_rows + tile.  Every rank's row count is within one tile row of height / nranks, and no
+// nranks bands — band_rows <= tail_rows < 2 band_rows + tile.  The BUSIEST rank's row count is within one tile row of an even share
+// (height / nranks); the last rank(s) of that taller round, clipped by the frame's edge, may own up to tail_rows fewer.  No
 // band but the frame's very last (clipped by the frame's edge) is lower than band_rows, so a halo can be up to band_rows rows deep at
 // every band edge (round 5; round 4 put the remainder into an EXTRA round of LOWER bands, same balance — 272 / 256 rows at 2160 rows on
 // 8 ranks with 64-row bands either way — but the halo of the whole frame was capped at those bands' 16 rows: ADVICE r4).  Only a frame

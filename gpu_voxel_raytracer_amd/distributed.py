@@ -28,7 +28,7 @@ def band_rows_for(radius, height=None, nranks=None, minimum=16):
     Without a frame size: >= 8 radius, so that the halo is at most a quarter of the rows a rank owns.  With
     `height` and `nranks`: the candidate between 48 rows (three rows of tiles: one of them needs no neighbour, so the exchange has
     work to hide behind) and 8 radius that leaves the busiest rank the fewest rows; ties go to the taller band (less halo).  Since
-    the last round of bands is dealt in shorter bands (BandLayout: every rank within one tile row of height / nranks) the candidates
+    the last round of bands takes the remainder (BandLayout: the busiest rank within one tile row of height / nranks) the candidates
     differ by a tile row at most, and the tall band usually wins: 64 rows at radius 8 for 2160 rows on 8 ranks (272 rows on the
     busiest rank, 270 would be even; round 3's whole-band deal: 288 with 48-row bands, 320 with 64)."""
     if radius <= 0:
@@ -49,8 +49,9 @@ class BandLayout:
     """Row ownership and halo message layout; mirrors BandMap (csrc/kernels.h) and csrc/api_halo.hip / csrc/halo_view.h.
     Band gb -> rank gb % nranks.  Whole rounds of nranks bands are band_rows rows high (`full_bands` of them, rows [0, tail_y0)); when
     the frame is not a whole number of rounds the LAST round takes the remainder too, in bands `tail_rows` high — the smallest multiple
-    of the tile height (16, or 8 for 8-row bands) that covers it in nranks bands, band_rows <= tail_rows < 2 band_rows + tile — so every
-    rank owns within one tile row of height / nranks rows and no band but the frame's last is lower than band_rows (a frame lower than
+    of the tile height (16, or 8 for 8-row bands) that covers it in nranks bands, band_rows <= tail_rows < 2 band_rows + tile — so the
+    BUSIEST rank owns within one tile row of height / nranks rows (the last ranks of that taller round, clipped by the frame's edge, may
+    own up to tail_rows fewer: 1080 rows, 8 ranks, 64-row bands give 144 x 7 + 72) and no band but the frame's last is lower than band_rows (a frame lower than
     one round has only that round, in bands lower than band_rows)."""
 
     def __init__(self, width, height, nranks, band_rows=16, radius=None):

@@ -107,8 +107,9 @@ typedef struct vxrt_config {
                                * shares); a multiple of 16 if the denoise stage runs with radius > 0 (its tiles are 16 rows).
                                * That holds for the whole ROUNDS of nranks bands; when the frame is not a whole number of
                                * rounds the LAST round takes the remainder as well, in taller bands — the smallest multiple
-                               * of the tile height (16, 8 or band_rows) that covers it in nranks bands — so that every rank
-                               * owns within one tile row of height / nranks rows and no band with a band below it is lower
+                               * of the tile height (16, 8 or band_rows) that covers it in nranks bands — so that the BUSIEST
+                               * rank owns within one tile row of height / nranks rows (the last ranks of that round, clipped by
+                               * the frame's edge, may own up to a band fewer) and no band with a band below it is lower
                                * than band_rows.  vxrt_local_rows lists a context's rows; distributed.BandLayout states the rule. */
                               /* nranks = 0 or 1 -> the whole frame                                     */
     uint32_t frames_in_flight;/* 0/1: every stage of a frame runs in submission order on one stream (the

@@ -154,7 +154,10 @@ bool parse(Module& m, const uint32_t* w, size_t n) {
             case 11: {  // ExtInstImport
                 if (!need(2) || !idok(o[0])) return fail(m, "bad ExtInstImport");
                 const char* s = reinterpret_cast<const char*>(o + 1);
-                if (strncmp(s, "GLSL.std.450", 12) == 0) m.glsl_set = o[0];
+                // the name is bounded by the INSTRUCTION (in.n words, the first of them the result id), not by a NUL that a truncated
+                // module may lack (strncmp read up to 8 bytes past a one-word name at the module's end)
+                const size_t avail = (size_t(in.n) - 1) * 4;
+                if (avail >= 12 && memcmp(s, "GLSL.std.450", 12) == 0) m.glsl_set = o[0];
                 break;
             }
             case 15: if (!need(2) || !idok(o[1])) return fail(m, "bad EntryPoint"); if (o[0] == 5) m.entry = o[1]; break;   // GLCompute

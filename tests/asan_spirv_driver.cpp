@@ -65,6 +65,18 @@ int main(int argc, char** argv) {
         if (t == 0 && rc != 0) { printf("the unmodified module does not run on the synthetic bindings: %s\n", orc_spirv_error()); return 4; }
         if (rc == 0) ran++; else if (rc == -1 && orc_spirv_error()[0] != 0) refused++; else return 3;
     }
+    {   // a module cut off right behind an OpExtInstImport whose one name word has no NUL ("GLSL"): the name compare must stay inside the instruction
+        std::vector<uint32_t> m(words.begin(), words.begin() + 5);
+        m.push_back(3u << 16 | 11u);          // OpExtInstImport, 3 words: result id, one word of name
+        m.push_back(1u);
+        m.push_back(0x4c534c47u);             // "GLSL", no terminator, last word of the buffer
+        std::vector<uint32_t> exact(m);        // a heap block of exactly this size: ASan sees any read past it
+        exact.shrink_to_fit();
+        uint64_t n = 0;
+        const int rc = orc_spirv_dispatch(exact.data(), exact.size(), nullptr, 0, 0, 0, 1, 1, 0, 1, &n);
+        if (rc == 0) { printf("a module that ends inside its header ran\n"); return 5; }
+        refused++;
+    }
     printf("trials %d: ran to the end %d, refused %d\n", trials, ran, refused);
     return 0;
 }

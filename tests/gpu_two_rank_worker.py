@@ -32,6 +32,8 @@ def main():
         comm, red = "cpu", "cpu"
     gpu = torch.device("cuda", dev)
     rank, world = dist.get_rank(), dist.get_world_size()
+    if os.environ.get("VXRT_TEST_CONFIG4") == "1":
+        return config4(dist, torch, rank, world, dev, gpu, comm, red, backend)
     w, h, bounces, radius = 320, 200, 3, int(os.environ.get("VXRT_TEST_RADIUS", "3"))
     band, halo_rows = int(os.environ.get("VXRT_TEST_BAND", "16")), os.environ.get("VXRT_TEST_HALO_ROWS", "1")
     auto_rows = halo_rows == "auto"      # sized frame by frame from the camera path (distributed.halo_rows_for_motion)
@@ -91,6 +93,53 @@ def main():
     if rank == 0:
         out["backend"], out["world_size"] = backend, world
         print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def config4(dist, torch, rank, world, dev, gpu, comm, red, backend):
+    """BASELINE configs[3] at its size through the path a node runs: vox/castle.vox 3840x2160, 4 samples per pixel
+    per displayed frame, 8 bounces, temporal + denoise with the 17 x 17 window, one context per rank over interleaved bands
+    (distributed.band_rows_for), the halo — 8 rows per band edge, 36 B/px — through distributed.HaloExchange BETWEEN THE RANKS
+    (RCCL send / recv between devices with VXRT_TEST_BACKEND=nccl; staged through the host over gloo), overlapped with the denoise of
+    the interior tiles.  Rank 0 stitches the ranks' rows of two displayed frames and compares them with one context's, bit for bit."""
+    from gpu_voxel_raytracer_amd import ACCUM_COLOR, ALL, DENOISED, TEMPORAL, TRACE, Camera, Context, distributed, scenes
+    w, h, bounces, spp, radius, frames = 3840, 2160, 8, 4, 8, 2
+    band = distributed.band_rows_for(radius, h, world)
+    pos, mrgb, size = scenes.load_scene("castle")
+    cam = Camera(*scenes.close_camera(size))
+    layout = distributed.BandLayout(w, h, world, band, radius=radius)
+    ctx = Context(w, h, device=dev, max_bounces=bounces, rank=rank, nranks=world, band_rows=band, frames_in_flight=2, frames_per_launch=spp)
+    ctx.recreate_octree(pos, mrgb)
+    ctx.camera = cam
+    ctx.denoise_uniforms.radius = radius
+    halo = distributed.HaloExchange(ctx, dist, rank, world, gpu, torch, comm_device=comm)
+    for _ in range(frames):
+        ctx.render_spp(TRACE | TEMPORAL, spp)
+        distributed.finish_frame(ctx, world, radius, halo, overlap=True)
+    info = ctx.halo_info()
+    imgs = {k: distributed.gather_image(ctx.read(i), layout, rank, dist, torch, red) for k, i in (("accum", ACCUM_COLOR), ("denoised", DENOISED))}
+    st = ctx.stats()
+    rays = torch.tensor([st.rays], device=red)
+    dist.all_reduce(rays)
+    ctx.close()
+    if rank == 0:
+        single = Context(w, h, device=dev, max_bounces=bounces, frames_in_flight=2, frames_per_launch=spp)
+        single.recreate_octree(pos, mrgb)
+        single.camera = cam
+        single.denoise_uniforms.radius = radius
+        for _ in range(frames):
+            single.render_spp(ALL, spp)
+        want = {"accum": single.read(ACCUM_COLOR), "denoised": single.read(DENOISED)}
+        res = {"backend": backend, "world_size": world, "config4": True, "band_rows": band, "halo_rows": int(info.rows),
+               "halo_bytes_per_rank_per_frame": 2 * int(info.message_bytes), "halo_exchanges": halo.exchanges,
+               "rays_equal": int(rays.item()) == single.stats().rays, "geometry_pixels": int((single.read(1)[..., 3] >= 0).sum())}
+        for k in want:
+            a, b = imgs[k], want[k]
+            same = (a == b) | (np.isnan(a) & np.isnan(b))
+            res[k + "_differing_pixels"] = int((~same.all(-1)).sum())
+        single.close()
+        print(json.dumps(res), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

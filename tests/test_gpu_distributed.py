@@ -67,6 +67,10 @@ def test_pipeline_bench_two_ranks_on_one_gpu():
     assert hl["pack_ms"] > 0 and hl["unpack_ms"] > 0 and hl["exchange_ms_synchronous"] > 0 and d["value"] > 100.0
     s = d["stage_ms_per_frame"]
     assert s["trace"] > 0 and s["temporal"] > 0 and s["denoise"] > 0
+    pr = d["per_rank"]        # every rank's own view of the run, so that the first run on a node explains itself
+    assert pr["blocks"] == 2 and [r["rank"] for r in pr["ranks"]] == [0, 1] and pr["launch_skew_after_the_barrier_ms"]["median"] >= 0
+    for r in pr["ranks"]:     # block 0 = the overlapped loop, block 1 = the synchronous pass with the exchange on the host clock
+        assert r["halo_exchange_ms_synchronous"] > 0 and r["halo_pack_ms"] > 0 and r["halo_unpack_ms"] > 0 and r["local_rows"] in (1088, 1072) and r["block_ms"]["median"] > 0
 
 
 def run_bench(args, env=None, timeout=900):
@@ -97,6 +101,12 @@ def test_bench_starts_its_own_ranks():
     w = d["rccl"]
     assert w["backend"] == "gloo" and w["world_size"] == 2 and [e["rank"] for e in w["devices"]] == [0, 1]
     assert len({e["pid"] for e in w["devices"]}) == 2 and "x2" in d["config"]["parallelism"]
+    pr = d["per_rank"]        # per rank: its own block times, how far apart the ranks left the barrier and finished
+    assert pr["blocks"] == 5 and [r["rank"] for r in pr["ranks"]] == [0, 1] and sum(r["blocks_it_finished_last"] for r in pr["ranks"]) == 5
+    assert 0 <= pr["launch_skew_after_the_barrier_ms"]["median"] <= pr["launch_skew_after_the_barrier_ms"]["max"] < 50
+    for r in pr["ranks"]:
+        assert 0 < r["block_ms"]["min"] <= r["block_ms"]["median"] <= r["block_ms"]["max"] and r["local_rows"] == 540 and r["rays_per_block"] > 0
+    assert max(r["block_ms"]["median"] for r in pr["ranks"]) <= d["ms_per_step"] * 20 * 1.5
 
 
 def test_halo_messages_over_rccl_on_one_gpu():
@@ -130,6 +140,30 @@ def test_ranks_over_rccl_stitch_to_the_single_context_frame(nproc, radius):
         assert r["sampled_differing_pixels"] == 0 and r["accum_differing_pixels"] == 0 and r["denoised_differing_pixels"] == 0, (name, r)
     f = d["fast"]
     assert f["rays_equal"] and f["sampled_differing_pixels"] == 0 and f["accum_differs_only_where_treated_as_disocclusion"], f
+
+
+def check_config4(d, nproc, backend):
+    assert d["config4"] and d["backend"] == backend and d["world_size"] == nproc and d["halo_rows"] == 8 and d["halo_exchanges"] == 2
+    assert d["halo_bytes_per_rank_per_frame"] > 2 * 8 * 3840 * 36 and d["geometry_pixels"] > 4000000
+    assert d["rays_equal"] and d["accum_differing_pixels"] == 0 and d["denoised_differing_pixels"] == 0, d
+
+
+def test_config4_at_size_two_ranks_with_the_halo_between_processes():
+    """BASELINE configs[3] at its size (castle 3840x2160, 4 spp, 8 bounces, temporal + denoise r = 8) from two PROCESSES with the halo
+    through distributed.HaloExchange between them — over gloo here (the ranks share the one GPU, the messages are staged through the
+    host); tests/test_gpu_configs.py has the same config from 8 contexts in one process with the halo buffers handed over by pointer.
+    The stitched accumulated and denoised frames equal one context's, bit for bit."""
+    d = launch(2, [os.path.join(ROOT, "tests", "gpu_two_rank_worker.py")], env={"VXRT_TEST_CONFIG4": "1"})
+    check_config4(d, 2, "gloo")
+
+
+@needs_two_gpus
+def test_config4_at_size_over_rccl_between_devices():
+    """the same with one GPU per rank — as many ranks as the box has GPUs, up to 8 — and the halo device to device
+    over RCCL send / recv: the exchange itself exercised between devices.  Arms on the first box with at least two GPUs."""
+    n = min(gpu_count(), 8)
+    d = launch(n, [os.path.join(ROOT, "tests", "gpu_two_rank_worker.py")], env={"VXRT_TEST_CONFIG4": "1", "VXRT_TEST_BACKEND": "nccl"}, timeout=1500)
+    check_config4(d, n, "nccl")
 
 
 @needs_two_gpus
