@@ -50,6 +50,7 @@ struct SceneView {
     float root_size;
     float cell, inv_cell;  // edge of the finest cell a node's octant can be (root_size * 2^-levels), and its reciprocal
     int levels;            // node levels 0 .. levels-1
+    uint32_t pop_mask;     // ~1u when the root holds ONE occupied slot (walkf_step: a pop back to the root is then a certain miss), else ~0u
 #if VXRT_VARIANTS
     uint32_t* touch_nodes;   // TraceArgs::touch_nodes / touch_leaves (null: off)
     uint32_t* touch_leaves;
@@ -370,7 +371,21 @@ __device__ __forceinline__ int walkf_step(WalkF& w, const SceneView& sc, uint2* 
             w.iz = (w.iz << 1) | (w.octant & 1u);
             w.lvl++;
         } else {         // voxels.comp:225-234
+            // A pop that would go back to the ROOT of a tree whose root holds one occupied slot (every scene whose coordinates are
+            // >= 0: the root is centred on 0, src/context.rs:782-786) can only walk the root's other, empty octants — a sibling is
+            // never revisited — and end in `top == 0 -> false` (voxels.comp:226): a certain miss, 2-4 trips early, unless those trips
+            // would have run into the 2048-trip cap first (then the walk goes on and finds out).  Bit-exact (the parity suite ran with it),
+            // and measured SLOWER on one box, three alternations (round 6, scripts/r06/06_root_exit.sh): 0.1085-0.1095 against 0.1063-0.1084 ms
+            // per bench frame, 0.2698-0.2707 against 0.2647-0.2665 in the close view — a lane that leaves early does not shorten its
+            // wave, and the two extra instructions sit in every pop.  Off.
+#ifndef VXRT_ROOT_EXIT
+#define VXRT_ROOT_EXIT 0
+#endif
+#if VXRT_ROOT_EXIT
+            if ((w.has_next_mask & sc.pop_mask) == 0u && (w.has_next_mask == 0u || w.iterations < 2040)) return kWalkMiss;
+#else
             if (w.has_next_mask == 0u) return kWalkMiss;
+#endif
             const uint32_t l = 31u - uint32_t(__clz(int(w.has_next_mask)));
             w.has_next_mask &= ~(1u << l);
             const uint32_t up = w.lvl - l;
@@ -709,6 +724,8 @@ __device__ __forceinline__ SceneView make_scene(const TraceArgs& a) {
     sc.levels = a.stack_levels;
     sc.cell = __builtin_ldexpf(a.root_size, -a.stack_levels);
     sc.inv_cell = 1.0f / sc.cell;
+    const uint32_t occupied = (a.root_rec.masks | a.root_rec.masks >> 8) & 0xffu;
+    sc.pop_mask = (occupied & (occupied - 1u)) == 0u ? ~1u : ~0u;
 #if VXRT_VARIANTS
     sc.touch_nodes = a.touch_nodes;
     sc.touch_leaves = a.touch_leaves;

@@ -105,7 +105,7 @@ def test_bench_starts_its_own_ranks():
     assert pr["blocks"] == 5 and [r["rank"] for r in pr["ranks"]] == [0, 1] and sum(r["blocks_it_finished_last"] for r in pr["ranks"]) == 5
     assert 0 <= pr["launch_skew_after_the_barrier_ms"]["median"] <= pr["launch_skew_after_the_barrier_ms"]["max"] < 50
     for r in pr["ranks"]:
-        assert 0 < r["block_ms"]["min"] <= r["block_ms"]["median"] <= r["block_ms"]["max"] and r["local_rows"] == 540 and r["rays_per_block"] > 0
+        assert 0 < r["block_ms"]["min"] <= r["block_ms"]["median"] <= r["block_ms"]["max"] and r["local_rows"] in (544, 536) and r["rays_per_block"] > 0
     assert max(r["block_ms"]["median"] for r in pr["ranks"]) <= d["ms_per_step"] * 20 * 1.5
 
 
