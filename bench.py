@@ -267,14 +267,26 @@ def measure_reference_loop(Context, Camera, flags, scenes, device, frames=120):
                             ctx.sync()
                         else:
                             pull(f)
+                def median_ms(pull, count, blocks=3, after=None):
+                    """median over `blocks` runs of `count` frames (ms per frame): a one-time cost — a queue made on first use, fresh pinned
+                    pages — lands in one block and not in the figure"""
+                    t = []
+                    for _ in range(blocks):
+                        t0 = time.perf_counter()
+                        loop(8, count, pull)
+                        if after is not None:
+                            after()
+                        t.append((time.perf_counter() - t0) / count * 1e3)
+                    return sorted(t)[len(t) // 2]
                 loop(0, 8)
                 ctx.reset_stats()
                 t0 = time.perf_counter()
                 loop(8, frames, timed=True)
                 dt = time.perf_counter() - t0
                 st = ctx.stats()
-                row["ms_per_frame"] = round(dt / frames * 1e3, 4)
-                row["mrays_per_s"] = round(st.rays / dt / 1e6, 1)
+                row["ms_per_frame"] = round(median_ms(None, frames // 2), 4)          # without the stage events of the loop above
+                row["ms_per_frame_with_stage_events"] = round(dt / frames * 1e3, 4)
+                row["mrays_per_s"] = round(st.rays / frames / row["ms_per_frame"] / 1e3, 1)
                 row["rays_per_pixel"] = round(st.rays / frames / (w * h), 4)
                 row["stage_ms"] = {"trace": round(st.trace_ms / frames, 4), "temporal": round(st.temporal_ms / frames, 4), "denoise": round(st.denoise_ms / frames, 4)}
                 # ... the host takes every denoised frame: synchronously into pageable memory (vxrt_read)
@@ -284,21 +296,20 @@ def measure_reference_loop(Context, Camera, flags, scenes, device, frames=120):
                 def pull_sync(f):
                     ctx.read_into(DENOISED, img)
                 loop(0, 4, pull_sync)
-                t0 = time.perf_counter()
-                loop(8, frames // 2, pull_sync)
-                row["with_vxrt_read_ms_per_frame"] = round((time.perf_counter() - t0) / (frames // 2) * 1e3, 4)
+                row["with_vxrt_read_ms_per_frame"] = round(median_ms(pull_sync, frames // 3), 4)
                 # ... without blocking: two pinned buffers, frame f's transfer is waited for after frame f + 1 has been submitted
                 pinned = [ctx.pinned_image(), ctx.pinned_image()]
 
                 def pull_async(f):
                     ctx.read_async(DENOISED, pinned[f & 1], f & 1)
                     ctx.read_wait((f + 1) & 1)             # the previous frame has arrived: the host may show it
-                loop(0, 4, pull_async)
-                ctx.read_wait(0); ctx.read_wait(1)
-                t0 = time.perf_counter()
-                loop(8, frames, pull_async)
-                ctx.read_wait(0); ctx.read_wait(1)
-                row["with_vxrt_read_async_ms_per_frame"] = round((time.perf_counter() - t0) / frames * 1e3, 4)
+
+                def drain():
+                    ctx.read_wait(0)
+                    ctx.read_wait(1)
+                loop(0, 16, pull_async)
+                drain()
+                row["with_vxrt_read_async_ms_per_frame"] = round(median_ms(pull_async, frames // 2, after=drain), 4)
                 ctx.sync()
                 t0 = time.perf_counter()
                 for k in range(16):
