@@ -413,6 +413,37 @@ def price_padded(seq_pad, order, nr, L, b_adv, b_desc, b_pop):
     return cost + live.any(2).sum() * C_SHADE, trips, cost / max(trips, 1)
 
 
+def trip_sort(view="bench", split_round=3):
+    """Round 6: what is trip-count COHERENCE worth in the compacted tail?  The tail's lanes run at 28 % (31 % of the trips of a wave's longest
+    lane, on the oracle's step counts): a wave waits for its slowest cast, cast after cast.  If the 64 paths of a chunk had similar trip counts
+    — an ORACLE sort: no kernel knows a cast's length beforehand — the tail would cost:
+        tile order (ships) 36.5 M wave-instructions; sorted by a path's total trips 0.72 x; by its first cast 0.92 x; by its first, then its
+        second cast 0.75 x; in random order 1.12 x; re-sorted before EVERY cast (steps only) 0.45 x = the dense bound.
+    So the prize for a predictor of cast length is 12 % of the stage (total-trips sort) to 25 % (per cast) — and round 2's priced answer to
+    "run a cast for K trips, hand the stragglers over" (0.64-0.73 x the trips) is the buildable form of it, at 160 bytes of walk state per
+    straggler.  usage: python -c "import sim_schedule as S; S.trip_sort()" """
+    st = steps_for(view=view)
+    rays = tiles_of(st)[:, :, 1:]
+    alive = rays[:, :, split_round] > 0
+    paths = rays[alive][:, split_round:]
+    base = paths_sync_cost(paths)
+    rng = np.random.default_rng(1)
+    for label, order in (("tile order (ships)", np.arange(len(paths))), ("oracle: by a path's total trips", np.argsort(-paths.sum(1), kind="stable")),
+                         ("oracle: by the first cast's trips", np.argsort(-paths[:, 0], kind="stable")),
+                         ("oracle: by the first, then the second cast", np.lexsort((-paths[:, 1], -paths[:, 0]))), ("random order", rng.permutation(len(paths)))):
+        c = paths_sync_cost(paths[order])
+        print(f"{label:46s} {c / 1e6:8.2f} M wave-instructions ({c / base:.3f} x)")
+    pad = (-len(paths)) % 64
+    pp = np.concatenate([paths, np.zeros((pad, paths.shape[1]), paths.dtype)]).reshape(-1, 64, paths.shape[1])
+    tot = 0
+    for r in range(paths.shape[1]):
+        col = np.sort(paths[:, r][paths[:, r] > 0])[::-1]
+        col = np.concatenate([col, np.zeros((-len(col)) % 64, col.dtype)]).reshape(-1, 64)
+        tot += col.max(axis=1).sum()
+    print(f"lane utilisation in trips, tile order: {pp.sum() / (pp.max(axis=1).sum() * 64):.3f}; steps only: tile order {pp.max(axis=1).sum() * C_STEP / 1e6:.1f} M, "
+          f"re-sorted before every cast {tot * C_STEP / 1e6:.1f} M, dense {paths.sum() / 64 * C_STEP / 1e6:.1f} M")
+
+
 def level_profile(view="bench", w=1920, h=1080, bounces=4):
     """Round 5: where in the tree do the walk's trips happen?  Per node level (0 = the root) the advance / descend / pop trips of every ray of
     the bench frame, and what share of the walk's lane-level VALU cost (32 + 3 / 57 / 53 per trip) falls into the bottom two node levels —
