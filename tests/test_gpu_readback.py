@@ -92,3 +92,21 @@ def test_pageable_destination_resize_and_bad_arguments(H, scenes, noise):
         ctx.read_wait(1)
         assert_bits_equal(big.array, ctx.read(DENOISED), "after resize")
         big.close()
+
+
+def test_async_read_of_a_rank_s_band_set(H, scenes, noise):
+    """A multi-GPU context owns interleaved bands of the frame: the non-blocking read-back carries its local rows (vxrt_local_rows), as
+    vxrt_read does — what a rank hands to whoever assembles or shows the frame."""
+    from gpu_voxel_raytracer_amd import ACCUM_COLOR, SAMPLED_COLOR, TEMPORAL, TRACE
+    for rank in (0, 2):
+        with _ctx(scenes, noise, w=200, h=136, rank=rank, nranks=3, band_rows=8) as ctx:
+            ctx.denoise_uniforms.radius = 0
+            ctx.render(TRACE | TEMPORAL)
+            rows = ctx.local_rows()
+            buf = ctx.pinned_image()
+            assert buf.array.shape == (len(rows), 200, 4) and 0 < len(rows) < 136
+            for which in (SAMPLED_COLOR, ACCUM_COLOR):
+                ctx.read_async(which, buf, 1)
+                ctx.read_wait(1)
+                assert_bits_equal(buf.array, ctx.read(which), f"rank {rank} image {which}")
+            buf.close()
