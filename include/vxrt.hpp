@@ -225,6 +225,17 @@ class Context {
         check(vxrt_read(ctx_, which, img.data(), img.size() * sizeof(float)), "vxrt_read");
         return img;
     }
+    // floats of one image of this context (its local rows x width x 4)
+    size_t image_floats() const {
+        uint32_t rows = 0;
+        check(vxrt_local_rows(ctx_, &rows, nullptr), "vxrt_local_rows");
+        return size_t(rows) * width_ * 4;
+    }
+    // The non-blocking read-back (vxrt_read_async / vxrt_read_wait): what a host that shows or stores EVERY frame calls where the
+    // reference presents (src/context.rs:2046-2070).  Frame k: render(...); read_async(VXRT_DENOISED, buf[k & 1], k & 1); then
+    // read_wait((k + 1) & 1) and frame k - 1 is in buf[(k + 1) & 1] — it travelled while frame k rendered.
+    void read_async(vxrt_image which, class PinnedImage& dst, uint32_t slot);
+    void read_wait(uint32_t slot) { check(vxrt_read_wait(ctx_, slot), "vxrt_read_wait"); }
     vxrt_stats stats() {
         vxrt_stats s{};
         check(vxrt_get_stats(ctx_, &s), "vxrt_get_stats");
@@ -238,5 +249,30 @@ class Context {
     vxrt_ctx* ctx_ = nullptr;
     uint32_t width_, height_;
 };
+
+// Pinned host memory for Context::read_async (vxrt_host_alloc / vxrt_host_free): a host needs no HIP binding of its own for it.
+class PinnedImage {
+  public:
+    explicit PinnedImage(size_t floats) : floats_(floats) {
+        void* p = nullptr;
+        check(vxrt_host_alloc(floats * sizeof(float), &p), "vxrt_host_alloc");
+        data_ = static_cast<float*>(p);
+    }
+    ~PinnedImage() { if (data_) (void)vxrt_host_free(data_); }
+    PinnedImage(const PinnedImage&) = delete;
+    PinnedImage& operator=(const PinnedImage&) = delete;
+    float* data() { return data_; }
+    const float* data() const { return data_; }
+    size_t size() const { return floats_; }
+    size_t bytes() const { return floats_ * sizeof(float); }
+
+  private:
+    float* data_ = nullptr;
+    size_t floats_;
+};
+
+inline void Context::read_async(vxrt_image which, PinnedImage& dst, uint32_t slot) {
+    check(vxrt_read_async(ctx_, which, dst.data(), dst.bytes(), slot), "vxrt_read_async");
+}
 
 }  // namespace vxrt

@@ -71,8 +71,17 @@ int main(int argc, char** argv) {
             ctx.camera.position[i] = c + e * k[i];
             ctx.camera.direction[i] = c - ctx.camera.position[i];
         }
-        for (int f = 0; f < frames; f++) ctx.render(VXRT_ALL);
-        std::vector<float> img = ctx.read(VXRT_DENOISED);
+        // the reference presents every frame (src/context.rs:2046-2070); here every frame is taken to the host without stalling the
+        // loop: frame f travels into one of two pinned buffers while frame f + 1 renders (vxrt_read_async / vxrt_read_wait)
+        vxrt::PinnedImage shown[2] = {vxrt::PinnedImage(ctx.image_floats()), vxrt::PinnedImage(ctx.image_floats())};
+        for (int f = 0; f < frames; f++) {
+            ctx.render(VXRT_ALL);
+            ctx.read_async(VXRT_DENOISED, shown[f & 1], uint32_t(f & 1));
+            if (f > 0) ctx.read_wait(uint32_t((f + 1) & 1));        // frame f - 1 has arrived: this is where a viewer would show it
+        }
+        const int last = (frames - 1) & 1;
+        if (frames > 0) ctx.read_wait(uint32_t(last));
+        std::vector<float> img = frames > 0 ? std::vector<float>(shown[last].data(), shown[last].data() + shown[last].size()) : ctx.read(VXRT_DENOISED);
         const vxrt_stats st = ctx.stats();
         std::ofstream ppm(argv[7], std::ios::binary);
         ppm << "P6\n" << width << " " << height << "\n255\n";
