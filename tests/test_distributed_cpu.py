@@ -331,3 +331,47 @@ def test_halo_rows_for_motion_bounds_the_reprojection(H):
         assert H.halo_rows_for_motion(H.Camera(p0, d0, fov), H.Camera(p1, d1, fov), w, h, 0.25, 10 ** 6) == rows
         assert H.halo_rows_for_motion(H.Camera(p0, d0, fov), H.Camera(p1, d1, fov), w, h, 0.25, 16) == min(16, rows)
     assert H.halo_rows_for_motion(H.Camera(p0, d0, fov), H.Camera(p0, d0, fov), w, h, 0.25, 64) == 2
+
+
+def _per_rank_worker(rank, world, port, q):
+    import importlib.util
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    # rank r leaves the barrier r * 0.2 ms after rank 0 and needs (1 + r) ms per block
+    starts = [1_000_000_000 + b * 10_000_000 + rank * 200_000 for b in range(3)]
+    ends = [s + (1 + rank) * 1_000_000 for s in starts]
+    out = bench.per_rank_report(dist, world, rank, [(1 + rank) * 1e-3] * 3, starts, ends, {"local_rows": 540 - rank})
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_per_rank_report_over_two_gloo_ranks():
+    """bench.py: per_rank_report — what an N > 1 line says per rank — over a real world-size-2 gloo group: rank 0 gets
+    every rank's block times, the skew with which the ranks left the barrier, the finish spread and who finished last; the others None."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = [ctx.Process(target=_per_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[1] is None
+    r = got[0]
+    assert r["blocks"] == 3 and [e["rank"] for e in r["ranks"]] == [0, 1]
+    assert r["launch_skew_after_the_barrier_ms"] == {"median": 0.2, "max": 0.2}
+    assert r["finish_spread_ms"]["median"] == pytest.approx(1.2)
+    assert r["ranks"][0]["block_ms"]["median"] == 1.0 and r["ranks"][1]["block_ms"]["median"] == 2.0
+    assert r["ranks"][1]["blocks_it_finished_last"] == 3 and r["ranks"][0]["blocks_it_finished_last"] == 0
+    assert r["ranks"][0]["local_rows"] == 540 and r["ranks"][1]["local_rows"] == 539
