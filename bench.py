@@ -245,7 +245,8 @@ def measure_reference_loop(Context, Camera, flags, scenes, device, frames=120):
     denoise radius 0 (the reference's default) and 2.  Four more rows per case: the same loop when the host pulls EVERY denoised frame
     with `vxrt_read` (synchronous, pageable: what round 5 had), with `vxrt_read_async` into two pinned buffers (frame n travels while
     frame n + 1 renders), the transfer alone, and the same frames through `vxrt_render_path` (the whole camera path handed over: 16
-    frames per trace launch, two launches in flight) — the gap between "drop-in" and "pipelined" in one place."""
+    frames per trace launch, two launches in flight) — the gap between "drop-in" and "pipelined" in one place — and the same per-frame calls
+    from a host that does not wait for a frame before it submits the next (`frames_in_flight` 2, one sync at the end)."""
     from gpu_voxel_raytracer_amd import DENOISED
     from gpu_voxel_raytracer_amd.frame_loop import orbit_camera
     ALL, TIMED = flags
@@ -320,6 +321,22 @@ def measure_reference_loop(Context, Camera, flags, scenes, device, frames=120):
                 row["read_async_over_max_of_render_and_transfer"] = round(row["with_vxrt_read_async_ms_per_frame"] / max(row["ms_per_frame"], row["transfer_alone_ms"]), 3)
                 for pb in pinned:
                     pb.close()
+            with Context(w, h, device=device, max_bounces=3, frames_in_flight=2) as ctx:    # the same calls, but the host does not wait for a frame
+                ctx.recreate_octree(pos, mrgb)                                              # before it submits the next (what wgpu's queue gives the reference
+                ctx.denoise_uniforms.radius = radius                                        # too: submit returns at once): two frames' trace stages overlap
+                for f in range(8):
+                    ctx.camera = Camera(*path[f])
+                    ctx.render(ALL)
+                ctx.sync()
+                t = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    for f in range(8, 8 + frames):
+                        ctx.camera = Camera(*path[f])
+                        ctx.render(ALL)
+                    ctx.sync()
+                    t.append((time.perf_counter() - t0) / frames * 1e3)
+                row["without_waiting_for_each_frame_ms_per_frame"] = round(sorted(t)[1], 4)
             with Context(w, h, device=device, max_bounces=3, frames_in_flight=2, frames_per_launch=16) as ctx:   # the same frames, the path handed over
                 ctx.recreate_octree(pos, mrgb)
                 ctx.denoise_uniforms.radius = radius
