@@ -371,6 +371,7 @@ def test_bench_contract_line():
         assert 0.05 < row["vxrt_render_path_ms_per_frame"] < row["ms_per_frame"] < 5 and row["mrays_per_s"] > 1000
         assert row["stage_ms"]["trace"] > 0 and row["stage_ms"]["temporal"] > 0 and 1.0 < row["rays_per_pixel"] < 6.0
         assert row["with_vxrt_read_async_ms_per_frame"] < row["with_vxrt_read_ms_per_frame"]
+        assert row["vxrt_render_path_ms_per_frame"] * 0.9 < row["without_waiting_for_each_frame_ms_per_frame"] < row["ms_per_frame"]   # two frames' trace stages overlap
         # pulling every frame costs at most max(render, transfer) + 10 % (+ slack for a shared box)
         assert row["read_async_over_max_of_render_and_transfer"] < 1.25, row
     assert "RECORDED" not in lines[0]             # every counter figure of the line is measured by the run itself
