@@ -381,10 +381,12 @@ int apply_option(vxrt_ctx* c, uint32_t option, uint32_t value, bool at_create) {
         case VXRT_OPT_TRACE_PRIORITY:   // the streams are made at creation
             if (!create_only()) return VXRT_E_INVALID;
             if (value > 1) { set_error("trace priority must be 0 or 1"); return VXRT_E_INVALID; }
+            if (value != 0 && !needs_variants("the priority split of a trace launch is not in this build of libvxrt (compile with -DVXRT_VARIANTS=1: it measured slower)")) return VXRT_E_INVALID;
             c->trace_priority = int(value);
             return VXRT_OK;
         case VXRT_OPT_XCD_AFFINITY:
             if (value > 64) { set_error("xcd affinity: 0 (off) or the side of a super-tile in tiles, 1..64"); return VXRT_E_INVALID; }
+            if (value != 0 && !needs_variants("the XCD-affine launch order is not in this build of libvxrt (compile with -DVXRT_VARIANTS=1: an experiment, - 2 % at best)")) return VXRT_E_INVALID;
             c->xcd_affinity = int(value);
             for (vxrt_ctx::TileSchedule& t : c->schedules) t.age = 8;     // the next launch re-sorts
             return VXRT_OK;

@@ -48,11 +48,13 @@ extern "C" {
  *                          as TWO grids — the tiles that walk on the high-priority stream, the tiles that only store sky on a
  *                          low-priority stream of their own — so that the dispatcher prefers the long chains whenever both have blocks
  *                          waiting (round 6's experiment for a rank's share of a short block on many GPUs; needs a tile order, i.e. the
- *                          second launch of a stream on; head + compacted tail or the all-in-one kernel, 8-byte records).  0 (default).
+ *                          second launch of a stream on; head + compacted tail or the all-in-one kernel, 8-byte records).  Measured 3 % slower:
+ *                          -DVXRT_VARIANTS=1 builds only.  0 (default).
  *   VXRT_OPT_XCD_AFFINITY  S = 1 .. 64: for a scene beyond the Infinity Cache (BASELINE config 5) and one frame per launch, the launch order
  *                          deals the tiles that walk to the 8 XCDs by screen region (super-tiles of S x S tiles, balanced by measured
  *                          cost, longest first inside each XCD's list) instead of round robin, so that an XCD's L2 serves one region's
- *                          part of the tree (csrc/api_trace.hip: xcd_affine_order; made on the host: an experiment).  0 (default): off.  */
+ *                          part of the tree (csrc/api_trace.hip: xcd_affine_order; made on the host: an experiment; fetch - 20 %, time - 2 %:
+ *                          -DVXRT_VARIANTS=1 builds only).  0 (default): off.  */
 #define VXRT_OPT_TILE_ORDER ((vxrt_option)7)
 #define VXRT_OPT_TILE_SPREAD ((vxrt_option)8)
 #define VXRT_OPT_TRACE_BLOCKS ((vxrt_option)9)

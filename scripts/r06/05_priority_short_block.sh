@@ -3,6 +3,8 @@
 # that walk as a grid on a HIGH-priority stream, the tiles of sky on a low-priority one (VXRT_OPT_TRACE_PRIORITY) — for EVERY rank's band
 # set, each alone on the GPU (emulated), against the same deal without it.  Stop rule: the slowest rank <= 0.39 ms, or leave the deal alone.
 export VXRT_ENV_KNOBS=1 GPU_MAX_HW_QUEUES=8
+# (the option lost and lives in the -DVXRT_VARIANTS=1 library since: both arms run in it; the recorded run had it in the product library)
+export VXRT_LIB=${GRAFT_REPO_ROOT:-$(pwd)}/gpu_voxel_raytracer_amd/libvxrt_variants.so
 O=gpurun_out/r6f
 mkdir -p $O
 out=$O/short_block.txt

@@ -12,6 +12,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gpu_voxel_raytracer_amd import SAMPLED_COLOR, TIMED, TRACE, Camera, Context, host, scenes  # noqa: E402
 
+host.use_library(host.variants_library())      # the option is an experiment: the product refuses it
 sizes = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 4, 8, 16, 32]
 with Context(3840, 2160, max_bounces=8, frames_in_flight=1, frames_per_launch=1) as ctx:
     ctx.set_menger(*scenes.CONFIG5)

@@ -60,6 +60,9 @@ def test_priority_split_launches_give_identical_frames(H, scenes, noise, infligh
     pos, mrgb, size = scenes.load_scene("menger")
     cam = Camera(*scenes.bench_camera(size))
     n = 3 * inflight * batch + 1
+    with pytest.raises(H.VxrtError, match="VXRT_VARIANTS"):          # measured slower: like every schedule that lost, the product refuses it
+        Context(64, 64, tuning=[(H.OPT_TRACE_PRIORITY, 1)])
+    require_variants(H, tracer=5)
 
     def frames(tuning, **kw):
         with Context(480, 272, max_bounces=4, noise=noise, frames_in_flight=inflight, frames_per_launch=batch, tracer=tracer, tuning=tuning, **kw) as ctx:
@@ -87,6 +90,7 @@ def test_xcd_affine_tile_order_gives_identical_frames(H, scenes, noise):
     screen region.  A launch order never changes a pixel: same frames as without it, and the order is a permutation of the tiles."""
     import ctypes as C
     from gpu_voxel_raytracer_amd import NORMAL_DEPTH, SAMPLED_COLOR, TRACE, Camera, Context
+    require_variants(H, tracer=5)                                    # an experiment's option: the variants library holds it
     w, h = 640, 360
     ext = np.float32(729 * 0.5)                                        # world extent of 729 voxels
     pos = (np.array([-0.45, 0.30, -0.55], np.float32) * ext + ext / 2).astype(np.float32)
