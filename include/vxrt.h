@@ -204,7 +204,7 @@ typedef struct vxrt_stats {
  *                          records, two levels per 16-byte record (half the dependent loads of a descent, ~35 % more instructions
  *                          per step: slower on MI355X for every scene measured, kept for comparison).  Same image either way.
  *                          Must be chosen before the scene is set (the wide records are built with the scene).  Needs a
- *                          library built with -DVXRT_VARIANTS=1 (vxrt_build_features); the default build refuses 1.
+ *                          library built with -DVXRT_VARIANTS=1 (vxrt_debug.h: vxrt_build_features); the default build refuses 1.
  *   VXRT_OPT_HALO_ROWS     multi-GPU: the fewest rows beyond each band edge that a halo exchange carries (default 1).  The exchange
  *                          carries max(denoise radius, this) rows; temporal.comp's reprojection (:85-113) sees that many rows of the
  *                          neighbouring bands' history, so set it to the largest vertical image motion per frame, in rows, that
